@@ -1,0 +1,177 @@
+/* mi355vits.h — C ABI of libmi355vits.so, the MI355X-native VITS inference engine that stands
+ * in for the one third-party call on the Mimic 3 hot path.
+ *
+ * Reference interface each entry point replaces (paths relative to the mimic3 repository):
+ *
+ *   mi355vits_create*          onnxruntime.InferenceSession(str(generator_path), sess_options=...,
+ *                              providers=...)                      mimic3_tts/voice.py:403-405
+ *   mi355vits_run              self.onnx_model.run(None, inputs)   mimic3_tts/voice.py:230
+ *                              (feed dict built at voice.py:180-218: "input" int64 [B,Tx],
+ *                              "input_lengths" int64 [B], "scales" f32[3] = noise_scale,
+ *                              length_scale, noise_w; "sid" int64 [B] iff multi-speaker)
+ *     + MI355VITS_WANT_PCM16   audio_float_to_int16(audio)         mimic3_tts/utils.py:237-244
+ *                              (called right after run, inside the timed region, voice.py:231)
+ *   mi355vits_destroy          the session's finaliser (voice.py:71-72 keeps sessions in a
+ *                              process-wide cache, so they live until exit)
+ *   mi355vits_get_config       TrainingConfig.model / .audio       mimic3_tts/config.py:112-143,30-60
+ *
+ * Plain pointers and sizes only; no torch / numpy types.  All calls return 0 on success or a
+ * negative MI355VITS_ERR_* code; mi355vits_last_error() gives the message.  Never aborts the
+ * process, never returns partial audio (the reference raises Python exceptions at this level,
+ * SURVEY.md §8b).  `run` is serialised per handle (internal mutex), so a handle may be shared by
+ * the server's worker threads like the reference's shared sessions (voice.py:277-292).
+ */
+#ifndef MI355VITS_H
+#define MI355VITS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355VITS_MAX_STAGES 8
+
+/* Hyper-parameters of the voice (mirror of ModelConfig + the constants upstream VITS hard-codes).
+ * Stored verbatim in the .m355 weight container header. */
+typedef struct mi355vits_config {
+    int32_t num_symbols;
+    int32_t n_speakers;
+    int32_t inter_channels;
+    int32_t hidden_channels;
+    int32_t filter_channels;
+    int32_t n_heads;
+    int32_t n_layers;
+    int32_t kernel_size;
+    int32_t resblock; /* 1 or 2 */
+    int32_t n_resblock_kernels;
+    int32_t resblock_kernel_sizes[MI355VITS_MAX_STAGES];
+    int32_t resblock_n_dilations[MI355VITS_MAX_STAGES];
+    int32_t resblock_dilations[MI355VITS_MAX_STAGES * MI355VITS_MAX_STAGES];
+    int32_t n_upsamples;
+    int32_t upsample_rates[MI355VITS_MAX_STAGES];
+    int32_t upsample_kernel_sizes[MI355VITS_MAX_STAGES];
+    int32_t upsample_initial_channel;
+    int32_t gin_channels;
+    int32_t window_size;
+    int32_t flow_n_flows;
+    int32_t flow_wn_layers;
+    int32_t flow_wn_kernel;
+    int32_t flow_wn_dilation_rate;
+    int32_t dp_kernel_size;
+    int32_t dp_dds_layers;
+    int32_t dp_n_flows;
+    int32_t dp_num_bins;
+    float dp_tail_bound;
+    int32_t sample_rate;
+    int32_t hop_length;
+} mi355vits_config;
+
+typedef struct mi355vits_engine* mi355vits_handle;
+
+enum {
+    MI355VITS_OK = 0,
+    MI355VITS_ERR_INVALID = -1,  /* bad argument / shape / id out of range */
+    MI355VITS_ERR_IO = -2,       /* weight file unreadable */
+    MI355VITS_ERR_FORMAT = -3,   /* not an .m355 container, or tensors missing / mis-shaped */
+    MI355VITS_ERR_DEVICE = -4,   /* HIP runtime error */
+    MI355VITS_ERR_NOMEM = -5,
+    MI355VITS_ERR_INTERNAL = -6
+};
+
+/* run flags */
+#define MI355VITS_WANT_FLOAT 1u   /* float32 waveform [B, l_max]: what onnx_model.run returns */
+#define MI355VITS_WANT_PCM16 2u   /* int16 [B, l_max]: audio_float_to_int16, per utterance */
+#define MI355VITS_DEVICE_ONLY 4u  /* leave audio in HBM, return lengths only (see mi355vits_fetch) */
+#define MI355VITS_DEBUG_TAPS 8u   /* keep named intermediates for mi355vits_get_tap (tests) */
+
+typedef struct mi355vits_run_args {
+    int32_t batch;             /* B >= 1 */
+    int32_t tx_max;            /* padded phoneme length Tx >= 1 */
+    const int64_t* ids;        /* [B, tx_max]  "input" */
+    const int64_t* lengths;    /* [B]          "input_lengths", 0 <= len <= tx_max */
+    const float* scales;       /* [3]          "scales" = noise_scale, length_scale, noise_w */
+    const int64_t* sid;        /* [B] or NULL  "sid" (required iff multi-speaker) */
+    uint64_t seed;             /* Philox key for the two Gaussian draws */
+    uint64_t utterance_base;   /* global index of row 0: noise does not depend on batch split */
+    const float* noise_w;      /* optional injected N(0,1) [B, 2, tx_max] (parity tests) */
+    const float* noise_z;      /* optional injected N(0,1) [B, inter_channels, noise_z_frames] */
+    int32_t noise_z_frames;
+    const int32_t* forced_durations; /* optional [B, tx_max]: overrides ceil(exp(logw)*length_scale) */
+    uint32_t flags;
+} mi355vits_run_args;
+
+typedef struct mi355vits_result {
+    int32_t batch;
+    int64_t l_max;     /* samples per row = hop * max_b frames_b */
+    int64_t ty_max;    /* latent frames of the longest row */
+    float* audio;      /* [B, l_max] or NULL; row b valid up to lengths[b] (rest is padding) */
+    int16_t* pcm;      /* [B, l_max] or NULL */
+    int64_t* lengths;  /* [B] valid samples per row */
+    float* peaks;      /* [B] max |audio| over each row's valid samples */
+    void* owner_;      /* private */
+} mi355vits_result;
+
+const char* mi355vits_version(void);
+
+/* Load a voice from an .m355 container (mimic3_amd/weights.py) onto HIP device `device`. */
+int mi355vits_create(const char* weights_path, int device, mi355vits_handle* out);
+int mi355vits_create_from_buffer(const void* blob, size_t blob_bytes, int device, mi355vits_handle* out);
+void mi355vits_destroy(mi355vits_handle h);
+int mi355vits_get_config(mi355vits_handle h, mi355vits_config* out);
+
+/* One synthesis call.  `out` is filled with callee-allocated (pinned) host buffers; release
+ * them with mi355vits_free_result.  With MI355VITS_DEVICE_ONLY the audio stays in the engine's
+ * workspace until the next run; mi355vits_fetch copies it out afterwards. */
+int mi355vits_run(mi355vits_handle h, const mi355vits_run_args* args, mi355vits_result* out);
+int mi355vits_fetch(mi355vits_handle h, uint32_t want_flags, mi355vits_result* out);
+void mi355vits_free_result(mi355vits_result* r);
+
+/* Message of the last error on this handle (or, with h == NULL, of the last failed create on the
+ * calling thread).  Valid until the next call on the same handle / thread. */
+const char* mi355vits_last_error(mi355vits_handle h);
+
+/* Per-kernel timing with HIP events on the engine's own stream (bench.py roofline leg).
+ * enable(1) brackets every launch with an event pair; report() synchronises and writes one
+ * line per kernel name: "name calls total_ms flops bytes\n".  Returns bytes written. */
+int mi355vits_profile_enable(mi355vits_handle h, int on);
+int mi355vits_profile_reset(mi355vits_handle h);
+long mi355vits_profile_report(mi355vits_handle h, char* buf, size_t cap);
+
+/* Wall time of the last run on the engine's stream, HIP events around the whole call (ms). */
+float mi355vits_last_run_ms(mi355vits_handle h);
+
+/* Debug taps (needs MI355VITS_DEBUG_TAPS on the last run): copy the named intermediate to
+ * `out` (capacity in floats); dims receives up to 4 extents.  Returns element count or < 0. */
+long mi355vits_get_tap(mi355vits_handle h, const char* name, float* out, size_t capacity, int64_t dims[4]);
+long mi355vits_list_taps(mi355vits_handle h, char* buf, size_t cap);
+
+/* Kernel unit-test hook: one Conv1d through a chosen implementation on host buffers.
+ * impl: 0 = generic VALU kernel, 1 = fp32-MFMA kernel.  See tests/test_kernels_*.py. */
+typedef struct mi355vits_conv_test {
+    int32_t impl, B, Cin, Cout, T, K, dilation;
+    const float* x;       /* [B,Cin,T] */
+    const float* w;       /* [Cout,Cin,K] */
+    const float* bias;    /* [Cout] or NULL */
+    const float* res;     /* [B,Cout,T] or NULL */
+    const int32_t* in_len;  /* [B] or NULL */
+    const int32_t* out_len; /* [B] or NULL */
+    float in_slope;       /* leaky-relu slope on the input, 1 = identity */
+    int32_t relu;         /* relu on the output */
+    float out_scale;
+    int32_t res_sub;      /* y = res - conv instead of res + conv */
+    float* y;             /* [B,Cout,T], also the accumulate source when accumulate != 0 */
+    int32_t accumulate;
+} mi355vits_conv_test;
+int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t);
+int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Cout, int Tin, int K, int stride,
+                                    const float* x, const float* w, const float* bias, float in_slope, float* y);
+/* MFMA fragment-layout self test: returns 0 when the 32x32x2 and 16x16x4 f32 MFMA lane maps
+ * assumed by the kernels hold on this device; max abs error in *err. */
+int mi355vits_test_mfma_layout(int device, float* err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355VITS_H */

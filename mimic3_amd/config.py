@@ -162,6 +162,9 @@ class VitsConfig:
         for k in ("length_scale", "noise_scale", "noise_w"):
             if k in infer and infer[k] is not None:
                 setattr(cfg, k, float(infer[k]))
+        for k, v in d.get("vits_constants", {}).items():  # written by to_json(); absent in a trainer config.json
+            if hasattr(cfg, k):
+                setattr(cfg, k, type(getattr(cfg, k))(v))
         cfg.validate()
         return cfg
 

@@ -1,0 +1,273 @@
+// c_api.cpp — extern "C" surface of libmi355vits.so (include/mi355vits.h).  Exceptions stop here:
+// every entry point returns a status code and records a message, never aborts the process.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using namespace m355;
+
+struct mi355vits_engine {
+    std::unique_ptr<Engine> eng;
+    std::string err;
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+template <typename F>
+int guarded(mi355vits_handle h, F&& fn) {
+    std::string* err = h ? &h->err : &g_create_error;
+    try {
+        fn();
+        return MI355VITS_OK;
+    } catch (const EngineError& e) {
+        *err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        *err = "out of host memory";
+        return MI355VITS_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        *err = e.what();
+        return std::string(e.what()).rfind("HIP error", 0) == 0 ? MI355VITS_ERR_DEVICE : MI355VITS_ERR_INTERNAL;
+    } catch (...) {
+        *err = "unknown error";
+        return MI355VITS_ERR_INTERNAL;
+    }
+}
+
+int create_common(WeightsFile& wf, int device, mi355vits_handle* out) {
+    auto* h = new mi355vits_engine();
+    h->eng.reset(new Engine(wf, device));
+    *out = h;
+    return MI355VITS_OK;
+}
+}  // namespace
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16)); }
+    ~DevBuf() { (void)hipFree(p); }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+}  // namespace
+
+extern "C" {
+
+const char* mi355vits_version(void) {
+#ifdef MI355_EMU
+    return "mi355vits 0.1.0 (hipemu CPU test build)";
+#else
+    return "mi355vits 0.1.0 (gfx950)";
+#endif
+}
+
+int mi355vits_create(const char* weights_path, int device, mi355vits_handle* out) {
+    if (out) *out = nullptr;
+    return guarded(nullptr, [&] {
+        if (!weights_path || !out) throw EngineError(MI355VITS_ERR_INVALID, "weights_path and out must not be null");
+        WeightsFile wf;
+        wf.load(weights_path);
+        create_common(wf, device, out);
+    });
+}
+
+int mi355vits_create_from_buffer(const void* blob, size_t blob_bytes, int device, mi355vits_handle* out) {
+    if (out) *out = nullptr;
+    return guarded(nullptr, [&] {
+        if (!blob || !out) throw EngineError(MI355VITS_ERR_INVALID, "blob and out must not be null");
+        WeightsFile wf;
+        // copy into 64-byte aligned storage so tensor data is float-aligned whatever the caller passed
+        wf.storage.resize(blob_bytes + 64);
+        unsigned char* base = wf.storage.data();
+        base += (64 - reinterpret_cast<uintptr_t>(base) % 64) % 64;
+        memcpy(base, blob, blob_bytes);
+        wf.parse(base, blob_bytes);
+        create_common(wf, device, out);
+    });
+}
+
+void mi355vits_destroy(mi355vits_handle h) {
+    if (!h) return;
+    try {
+        std::lock_guard<std::mutex> lk(h->eng->mu);
+    } catch (...) {
+    }
+    delete h;
+}
+
+int mi355vits_get_config(mi355vits_handle h, mi355vits_config* out) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!out) throw EngineError(MI355VITS_ERR_INVALID, "out must not be null");
+        *out = h->eng->config();
+    });
+}
+
+int mi355vits_run(mi355vits_handle h, const mi355vits_run_args* args, mi355vits_result* out) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    int rc = guarded(h, [&] {
+        if (!args) throw EngineError(MI355VITS_ERR_INVALID, "args must not be null");
+        h->eng->run(*args, out);
+    });
+    if (rc != MI355VITS_OK && out) mi355vits_free_result(out);  // never hand back partial audio
+    return rc;
+}
+
+int mi355vits_fetch(mi355vits_handle h, uint32_t want_flags, mi355vits_result* out) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    int rc = guarded(h, [&] { h->eng->fetch(want_flags, out); });
+    if (rc != MI355VITS_OK && out) mi355vits_free_result(out);
+    return rc;
+}
+
+void mi355vits_free_result(mi355vits_result* r) { free_result_impl(r); }
+
+const char* mi355vits_last_error(mi355vits_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mi355vits_profile_enable(mi355vits_handle h, int on) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    h->eng->profiler().enabled = on != 0;
+    return MI355VITS_OK;
+}
+int mi355vits_profile_reset(mi355vits_handle h) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    return guarded(h, [&] { h->eng->profiler().clear(); });
+}
+long mi355vits_profile_report(mi355vits_handle h, char* buf, size_t cap) {
+    if (!h || !buf || cap == 0) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    long n = 0;
+    int rc = guarded(h, [&] {
+        const std::string s = h->eng->profiler().report();
+        n = (long)std::min(s.size(), cap - 1);
+        memcpy(buf, s.data(), (size_t)n);
+        buf[n] = 0;
+    });
+    return rc == MI355VITS_OK ? n : rc;
+}
+float mi355vits_last_run_ms(mi355vits_handle h) {
+    if (!h) return -1.0f;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    return h->eng->last_run_ms();
+}
+
+long mi355vits_get_tap(mi355vits_handle h, const char* name, float* out, size_t capacity, int64_t dims[4]) {
+    if (!h || !name || !dims) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    long n = 0;
+    int rc = guarded(h, [&] { n = h->eng->get_tap(name, out, capacity, dims); });
+    return rc == MI355VITS_OK ? n : rc;
+}
+long mi355vits_list_taps(mi355vits_handle h, char* buf, size_t cap) {
+    if (!h || !buf || cap == 0) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    const std::string s = h->eng->list_taps();
+    const size_t n = std::min(s.size(), cap - 1);
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+    return (long)n;
+}
+
+// kernel unit-test hooks (host buffers in, host buffers out)
+int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t) {
+    return guarded(nullptr, [&] {
+        if (!t || !t->x || !t->w || !t->y) throw EngineError(MI355VITS_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(device));
+        const size_t nx = (size_t)t->B * t->Cin * t->T, ny = (size_t)t->B * t->Cout * t->T;
+        const size_t nw = (size_t)t->Cout * t->Cin * t->K;
+        DevBuf dx(nx * 4), dy(ny * 4), dw(nw * 4), db(t->Cout * 4), dres(ny * 4), dil(t->B * 4), dol(t->B * 4);
+        std::vector<float> packed;
+        HIP_CHECK(hipMemcpy(dx.p, t->x, nx * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dy.p, t->y, ny * 4, hipMemcpyHostToDevice));
+        ConvArgs a;
+        a.x = dx.as<float>(); a.x_bs = (long)t->Cin * t->T; a.x_ld = t->T;
+        a.y = dy.as<float>(); a.y_bs = (long)t->Cout * t->T; a.y_ld = t->T;
+        a.B = t->B; a.Cin = t->Cin; a.Cout = t->Cout; a.T = t->T; a.K = t->K; a.dil = t->dilation;
+        a.pad = (t->K * t->dilation - t->dilation) / 2;
+        a.in_slope = t->in_slope; a.relu = t->relu; a.out_scale = t->out_scale; a.res_sub = t->res_sub;
+        a.accumulate = t->accumulate;
+        if (t->bias) { HIP_CHECK(hipMemcpy(db.p, t->bias, t->Cout * 4, hipMemcpyHostToDevice)); a.bias = db.as<float>(); }
+        if (t->res) {
+            HIP_CHECK(hipMemcpy(dres.p, t->res, ny * 4, hipMemcpyHostToDevice));
+            a.res = dres.as<float>(); a.res_bs = a.y_bs; a.res_ld = t->T;
+        }
+        if (t->in_len) { HIP_CHECK(hipMemcpy(dil.p, t->in_len, t->B * 4, hipMemcpyHostToDevice)); a.in_len = dil.as<int>(); }
+        if (t->out_len) { HIP_CHECK(hipMemcpy(dol.p, t->out_len, t->B * 4, hipMemcpyHostToDevice)); a.out_len = dol.as<int>(); }
+        if (t->impl == 1) {
+            if (!conv1d_mfma_supported(t->Cin, t->Cout, t->K, t->dilation)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the MFMA kernel");
+            packed.resize(mfma_packed_floats(t->Cout, t->Cin, t->K));
+            pack_conv_weights_mfma(t->w, t->Cout, t->Cin, t->K, packed.data());
+            DevBuf dp(packed.size() * 4);
+            HIP_CHECK(hipMemcpy(dp.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+            a.w = dp.as<float>();
+            launch_conv1d_mfma(a, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        } else {
+            HIP_CHECK(hipMemcpy(dw.p, t->w, nw * 4, hipMemcpyHostToDevice));
+            a.w = dw.as<float>();
+            launch_conv1d_generic(a, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(t->y, dy.p, ny * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Cout, int Tin, int K, int stride,
+                                    const float* x, const float* w, const float* bias, float in_slope, float* y) {
+    (void)impl;
+    return guarded(nullptr, [&] {
+        if (!x || !w || !y) throw EngineError(MI355VITS_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(device));
+        const size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tin * stride, nw = (size_t)Cin * Cout * K;
+        DevBuf dx(nx * 4), dy(ny * 4), dw(nw * 4), db(Cout * 4);
+        HIP_CHECK(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, w, nw * 4, hipMemcpyHostToDevice));
+        ConvTArgs a;
+        a.x = dx.as<float>(); a.x_bs = (long)Cin * Tin; a.x_ld = Tin;
+        a.y = dy.as<float>(); a.y_bs = (long)Cout * Tin * stride; a.y_ld = Tin * stride;
+        a.w = dw.as<float>();
+        if (bias) { HIP_CHECK(hipMemcpy(db.p, bias, Cout * 4, hipMemcpyHostToDevice)); a.bias = db.as<float>(); }
+        a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.K = K; a.stride = stride; a.pad = (K - stride) / 2;
+        a.in_slope = in_slope;
+        launch_conv_transpose1d(a, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int mi355vits_test_mfma_layout(int device, float* err) {
+    return guarded(nullptr, [&] {
+        HIP_CHECK(hipSetDevice(device));
+        DevBuf d((1024 + 256) * 4);
+        launch_mfma_selftest(d.as<float>(), nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        std::vector<float> h(1280);
+        HIP_CHECK(hipMemcpy(h.data(), d.p, 1280 * 4, hipMemcpyDeviceToHost));
+        float worst = 0.0f;
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j) {
+                float ref = 0;
+                for (int k = 0; k < 2; ++k) ref += (float)(i + 100 * k + 1) * (float)(3 * j - 7 * k + 2);
+                worst = std::max(worst, std::fabs(ref - h[i * 32 + j]));
+            }
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) {
+                float ref = 0;
+                for (int k = 0; k < 4; ++k) ref += (float)(i + 100 * k + 1) * (float)(3 * j - 7 * k + 2);
+                worst = std::max(worst, std::fabs(ref - h[1024 + i * 16 + j]));
+            }
+        if (err) *err = worst;
+        if (worst > 1e-3f) throw EngineError(MI355VITS_ERR_INTERNAL, "MFMA fragment layout differs from the one the kernels assume");
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,1082 @@
+// engine.cpp — weight upload (with the load-time repacks the kernels want) and the launch sequence of one
+// synthesis call: text encoder -> stochastic duration predictor -> length regulator -> flow^-1 -> HiFi-GAN
+// -> tanh / peak / int16.  Everything runs on one HIP stream; the only host round trip inside a call is
+// the 4*B-byte read of the frame counts that size the second half of the graph.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace m355 {
+
+// =================================================================================================
+// .m355 container
+// =================================================================================================
+namespace {
+struct Reader {
+    const unsigned char* p;
+    size_t n, pos = 0;
+    void need(size_t k) const {
+        if (pos + k > n) throw EngineError(MI355VITS_ERR_FORMAT, "weight container truncated");
+    }
+    template <typename T> T get() {
+        need(sizeof(T));
+        T v;
+        memcpy(&v, p + pos, sizeof(T));
+        pos += sizeof(T);
+        return v;
+    }
+};
+}  // namespace
+
+void WeightsFile::parse(const void* blob, size_t n) {
+    Reader r{static_cast<const unsigned char*>(blob), n};
+    r.need(8);
+    if (memcmp(r.p, "M355VITS", 8) != 0) throw EngineError(MI355VITS_ERR_FORMAT, "not an M355VITS weight container");
+    r.pos = 8;
+    const uint32_t version = r.get<uint32_t>();
+    const uint32_t clen = r.get<uint32_t>();
+    if (version != 1) throw EngineError(MI355VITS_ERR_FORMAT, "unsupported container version");
+    if (clen != sizeof(mi355vits_config)) throw EngineError(MI355VITS_ERR_FORMAT, "config block size mismatch");
+    r.need(clen);
+    memcpy(&cfg, r.p + r.pos, clen);
+    r.pos += clen;
+    const uint32_t nt = r.get<uint32_t>();
+    struct Ent { std::string name; std::vector<int> dims; uint64_t off; };
+    std::vector<Ent> ents;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const uint16_t nl = r.get<uint16_t>();
+        r.need(nl);
+        Ent e;
+        e.name.assign(reinterpret_cast<const char*>(r.p + r.pos), nl);
+        r.pos += nl;
+        const uint32_t nd = r.get<uint32_t>();
+        if (nd > 8) throw EngineError(MI355VITS_ERR_FORMAT, "tensor rank too large");
+        for (uint32_t d = 0; d < nd; ++d) e.dims.push_back((int)r.get<uint32_t>());
+        e.off = r.get<uint64_t>();
+        ents.push_back(std::move(e));
+    }
+    const uint64_t dbytes = r.get<uint64_t>();
+    r.pos += (64 - r.pos % 64) % 64;
+    if (r.pos + dbytes > n) throw EngineError(MI355VITS_ERR_FORMAT, "weight container truncated (data section)");
+    for (auto& e : ents) {
+        size_t cnt = 1;
+        for (int d : e.dims) cnt *= (size_t)d;
+        if (e.off + cnt * 4 > dbytes) throw EngineError(MI355VITS_ERR_FORMAT, "tensor " + e.name + " out of bounds");
+        HostTensor t;
+        t.dims = e.dims;
+        t.count = cnt;
+        t.data = reinterpret_cast<const float*>(r.p + r.pos + e.off);
+        tensors[e.name] = t;
+    }
+}
+
+void WeightsFile::load(const std::string& path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw EngineError(MI355VITS_ERR_IO, "cannot open weight file: " + path);
+    const std::streamsize sz = f.tellg();
+    f.seekg(0);
+    storage.resize((size_t)sz + 64);
+    // keep float data 4-byte aligned: the data section starts on a 64-byte file offset
+    unsigned char* base = storage.data();
+    base += (64 - reinterpret_cast<uintptr_t>(base) % 64) % 64;
+    if (!f.read(reinterpret_cast<char*>(base), sz)) throw EngineError(MI355VITS_ERR_IO, "cannot read weight file: " + path);
+    parse(base, (size_t)sz);
+}
+
+const HostTensor& WeightsFile::get(const std::string& name, std::initializer_list<int> dims) const {
+    auto it = tensors.find(name);
+    if (it == tensors.end()) throw EngineError(MI355VITS_ERR_FORMAT, "missing tensor: " + name);
+    if (it->second.dims != std::vector<int>(dims)) {
+        std::ostringstream os;
+        os << "tensor " << name << " has shape [";
+        for (int d : it->second.dims) os << d << ",";
+        os << "] expected [";
+        for (int d : dims) os << d << ",";
+        os << "]";
+        throw EngineError(MI355VITS_ERR_FORMAT, os.str());
+    }
+    return it->second;
+}
+
+// =================================================================================================
+// arena / profiler
+// =================================================================================================
+DeviceArena::~DeviceArena() {
+    if (base_) (void)hipFree(base_);
+}
+void DeviceArena::reserve(size_t bytes, hipStream_t s) {
+    if (bytes <= cap_) return;
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (base_) HIP_CHECK(hipFree(base_));
+    base_ = nullptr;
+    cap_ = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) throw EngineError(MI355VITS_ERR_NOMEM, "out of device memory (workspace)");
+    base_ = static_cast<unsigned char*>(p);
+    cap_ = want;
+}
+void* DeviceArena::alloc_bytes(size_t bytes) {
+    const size_t need = padded(bytes);
+    if (off_ + need > cap_) throw EngineError(MI355VITS_ERR_INTERNAL, "workspace arena overflow (sizing bug)");
+    void* p = base_ + off_;
+    off_ += need;
+    return p;
+}
+
+Profiler::~Profiler() {
+    for (auto e : pool) (void)hipEventDestroy(e);
+    for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+}
+hipEvent_t Profiler::get_event() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+int Profiler::begin(const char* name, double flops, double bytes) {
+    auto it = ids.find(name);
+    int id;
+    if (it == ids.end()) {
+        id = (int)names.size();
+        names.emplace_back(name);
+        ids[name] = id;
+    } else {
+        id = it->second;
+    }
+    Rec r{id, get_event(), get_event(), flops, bytes};
+    HIP_CHECK(hipEventRecord(r.a, stream));
+    recs.push_back(r);
+    return (int)recs.size() - 1;
+}
+void Profiler::end(int rec) { (void)hipEventRecord(recs[rec].b, stream); }
+void Profiler::clear() {
+    (void)hipStreamSynchronize(stream);
+    for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+    recs.clear();
+}
+std::string Profiler::report() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    struct Agg { long calls = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::vector<Agg> agg(names.size());
+    for (auto& r : recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0;
+        Agg& a = agg[r.name_id];
+        a.calls++;
+        a.ms += ms;
+        a.flops += r.flops;
+        a.bytes += r.bytes;
+    }
+    std::ostringstream os;
+    os.precision(9);
+    for (size_t i = 0; i < names.size(); ++i)
+        if (agg[i].calls) os << names[i] << " " << agg[i].calls << " " << agg[i].ms << " " << agg[i].flops << " " << agg[i].bytes << "\n";
+    return os.str();
+}
+
+// =================================================================================================
+// engine: construction / weight upload
+// =================================================================================================
+size_t Engine::stage(const float* p, size_t n) {
+    const size_t off = (host_stage_.size() + 63) & ~size_t(63);
+    host_stage_.resize(off + n);
+    if (n) memcpy(host_stage_.data() + off, p, n * sizeof(float));
+    return off;
+}
+
+const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<float>& w, const std::vector<float>* bias,
+                                   int Cout, int Cin, int K, int epi) {
+    if (w.size() != (size_t)Cout * Cin * K) throw EngineError(MI355VITS_ERR_INTERNAL, "add_conv_data size: " + key);
+    ConvW c;
+    c.Cout = Cout; c.Cin = Cin; c.K = K; c.epi = epi;
+    c.raw = stage(w.data(), w.size());
+    if (bias) c.bias = stage(bias->data(), bias->size());
+    if (conv1d_mfma_supported(Cin, Cout, K, 1)) {
+        std::vector<float> pk(mfma_packed_floats(Cout, Cin, K), 0.0f);
+        pack_conv_weights_mfma_mode(w.data(), Cout, Cin, K, epi == EPI_GATE ? EPI_GATE : EPI_STD, pk.data());
+        c.packed = stage(pk.data(), pk.size());
+    }
+    return convs_[key] = c;
+}
+
+const ConvW& Engine::add_conv(const WeightsFile& wf, const std::string& key, const std::string& tensor, int Cout, int Cin,
+                              int K, bool bias, int epi) {
+    const HostTensor& w = wf.get(tensor + ".weight", {Cout, Cin, K});
+    std::vector<float> wv(w.data, w.data + w.count);
+    if (bias) {
+        const HostTensor& b = wf.get(tensor + ".bias", {Cout});
+        std::vector<float> bv(b.data, b.data + b.count);
+        return add_conv_data(key, wv, &bv, Cout, Cin, K, epi);
+    }
+    return add_conv_data(key, wv, nullptr, Cout, Cin, K, epi);
+}
+
+void Engine::add_vec(const WeightsFile& wf, const std::string& name, std::initializer_list<int> dims) {
+    const HostTensor& t = wf.get(name, dims);
+    vecs_[name] = stage(t.data, t.count);
+}
+const float* Engine::vec(const std::string& name) const {
+    auto it = vecs_.find(name);
+    if (it == vecs_.end()) throw EngineError(MI355VITS_ERR_INTERNAL, "unknown tensor: " + name);
+    return dev_weights_ + it->second;
+}
+const ConvW& Engine::cw(const std::string& key) const {
+    auto it = convs_.find(key);
+    if (it == convs_.end()) throw EngineError(MI355VITS_ERR_INTERNAL, "unknown conv: " + key);
+    return it->second;
+}
+
+static std::string S(const char* fmt, int a = 0, int b = 0, int c = 0) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), fmt, a, b, c);
+    return buf;
+}
+
+static void validate_config(const mi355vits_config& c) {
+    auto bad = [](const std::string& m) { throw EngineError(MI355VITS_ERR_FORMAT, "invalid voice config: " + m); };
+    if (c.num_symbols < 1 || c.n_speakers < 1) bad("num_symbols / n_speakers");
+    if (c.hidden_channels < 2 || c.hidden_channels % 2 || c.inter_channels < 2 || c.inter_channels % 2) bad("channel counts must be even");
+    if (c.n_heads < 1 || c.hidden_channels % c.n_heads) bad("hidden_channels % n_heads");
+    if (c.resblock != 1 && c.resblock != 2) bad("resblock must be 1 or 2");
+    if (c.n_upsamples < 1 || c.n_upsamples > MI355VITS_MAX_STAGES) bad("n_upsamples");
+    if (c.n_resblock_kernels < 1 || c.n_resblock_kernels > MI355VITS_MAX_STAGES) bad("n_resblock_kernels");
+    long hop = 1;
+    int ch = c.upsample_initial_channel;
+    for (int i = 0; i < c.n_upsamples; ++i) {
+        if (c.upsample_rates[i] < 1 || c.upsample_kernel_sizes[i] < c.upsample_rates[i]) bad("upsample stage");
+        if ((c.upsample_kernel_sizes[i] - c.upsample_rates[i]) % 2) bad("upsample kernel - rate must be even");
+        if (ch % 2) bad("upsample channels must halve evenly");
+        ch /= 2;
+        hop *= c.upsample_rates[i];
+    }
+    if (ch % 2) bad("decoder channel counts must be even");
+    if (hop != c.hop_length) bad("hop_length must equal the product of upsample_rates");
+    for (int j = 0; j < c.n_resblock_kernels; ++j) {
+        if (c.resblock_kernel_sizes[j] < 1 || c.resblock_kernel_sizes[j] % 2 == 0) bad("resblock kernel sizes must be odd");
+        if (c.resblock_n_dilations[j] < 1 || c.resblock_n_dilations[j] > MI355VITS_MAX_STAGES) bad("resblock dilations");
+    }
+    if (c.n_speakers > 1 && c.gin_channels < 1) bad("multi-speaker voice needs gin_channels");
+    if (c.dp_num_bins < 2 || c.dp_num_bins > 16) bad("dp_num_bins");
+    if (c.dp_n_flows < 2 || c.flow_n_flows < 1 || c.flow_wn_layers < 1) bad("flow depth");
+    if (c.flow_wn_kernel % 2 == 0 || c.dp_kernel_size % 2 == 0) bad("flow / dp kernels must be odd");
+    if (c.window_size < 0 || c.n_layers < 1 || c.kernel_size < 1) bad("encoder");
+}
+
+Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device) {
+    validate_config(cfg_);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        throw EngineError(MI355VITS_ERR_DEVICE, "no HIP device available (the MI355X engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw EngineError(MI355VITS_ERR_INVALID, "device index out of range");
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreate(&ev_start_));
+    HIP_CHECK(hipEventCreate(&ev_end_));
+    prof_.stream = stream_;
+    const char* fg = getenv("MI355VITS_FORCE_GENERIC");
+    force_generic_ = fg && fg[0] == '1';
+
+    const mi355vits_config& c = cfg_;
+    const int H = c.hidden_channels, F = c.filter_channels, I = c.inter_channels, half = I / 2;
+    const int hd = H / c.n_heads, nrel = 2 * c.window_size + 1;
+    const int gin = c.n_speakers > 1 ? c.gin_channels : 0;
+
+    auto add_dds = [&](const std::string& p, int C) {
+        for (int i = 0; i < c.dp_dds_layers; ++i) {
+            add_vec(wf, p + S(".convs_sep.%d.weight", i), {C, 1, c.dp_kernel_size});
+            add_vec(wf, p + S(".convs_sep.%d.bias", i), {C});
+            add_conv(wf, p + S(".convs_1x1.%d", i), p + S(".convs_1x1.%d", i), C, C, 1, true);
+            add_vec(wf, p + S(".norms_1.%d.gamma", i), {C});
+            add_vec(wf, p + S(".norms_1.%d.beta", i), {C});
+            add_vec(wf, p + S(".norms_2.%d.gamma", i), {C});
+            add_vec(wf, p + S(".norms_2.%d.beta", i), {C});
+        }
+    };
+
+    // ---- text encoder
+    add_vec(wf, "enc_p.emb.weight", {c.num_symbols, H});
+    for (int i = 0; i < c.n_layers; ++i) {
+        const std::string a = S("enc_p.encoder.attn_layers.%d", i);
+        std::vector<float> wq(3 * (size_t)H * H), bq(3 * (size_t)H);
+        const char* names[3] = {".conv_q", ".conv_k", ".conv_v"};
+        for (int q = 0; q < 3; ++q) {
+            const HostTensor& w = wf.get(a + names[q] + ".weight", {H, H, 1});
+            const HostTensor& b = wf.get(a + names[q] + ".bias", {H});
+            memcpy(wq.data() + (size_t)q * H * H, w.data, sizeof(float) * H * H);
+            memcpy(bq.data() + (size_t)q * H, b.data, sizeof(float) * H);
+        }
+        add_conv_data(S("enc.%d.qkv", i), wq, &bq, 3 * H, H, 1);
+        add_conv(wf, S("enc.%d.o", i), a + ".conv_o", H, H, 1, true);
+        add_vec(wf, a + ".emb_rel_k", {1, nrel, hd});
+        add_vec(wf, a + ".emb_rel_v", {1, nrel, hd});
+        add_vec(wf, S("enc_p.encoder.norm_layers_1.%d.gamma", i), {H});
+        add_vec(wf, S("enc_p.encoder.norm_layers_1.%d.beta", i), {H});
+        add_conv(wf, S("enc.%d.ffn1", i), S("enc_p.encoder.ffn_layers.%d.conv_1", i), F, H, c.kernel_size, true);
+        add_conv(wf, S("enc.%d.ffn2", i), S("enc_p.encoder.ffn_layers.%d.conv_2", i), H, F, c.kernel_size, true);
+        add_vec(wf, S("enc_p.encoder.norm_layers_2.%d.gamma", i), {H});
+        add_vec(wf, S("enc_p.encoder.norm_layers_2.%d.beta", i), {H});
+    }
+    add_conv(wf, "enc.proj", "enc_p.proj", 2 * I, H, 1, true);
+
+    // ---- stochastic duration predictor (inference half)
+    add_conv(wf, "dp.pre", "dp.pre", H, H, 1, true);
+    add_conv(wf, "dp.proj", "dp.proj", H, H, 1, true);
+    add_dds("dp.convs", H);
+    if (gin) {
+        add_vec(wf, "dp.cond.weight", {H, gin, 1});
+        add_vec(wf, "dp.cond.bias", {H});
+    }
+    {
+        const HostTensor& m = wf.get("dp.flows.0.m", {2, 1});
+        const HostTensor& l = wf.get("dp.flows.0.logs", {2, 1});
+        ea_m_[0] = m.data[0]; ea_m_[1] = m.data[1];
+        ea_logs_[0] = l.data[0]; ea_logs_[1] = l.data[1];
+    }
+    for (int j = 1; j < c.dp_n_flows; ++j) {
+        const std::string p = S("dp.flows.%d", 1 + 2 * j);
+        add_vec(wf, p + ".pre.weight", {H, 1, 1});
+        add_vec(wf, p + ".pre.bias", {H});
+        add_dds(p + ".convs", H);
+        add_conv(wf, p + ".proj", p + ".proj", 3 * c.dp_num_bins - 1, H, 1, true);
+    }
+
+    // ---- residual coupling flow.  The channel flips between couplings are folded into the weights:
+    // after an odd number of flips the logical tensor is the physical one reversed, so that coupling reads
+    // its x0 from the physical upper half through a channel-reversed `pre` and writes its x1 into the
+    // physical lower half through a channel-reversed `post`; after an even number it is the identity.
+    for (int j = 0; j < c.flow_n_flows; ++j) {
+        const int e = c.flow_n_flows - 1 - j;  // execution index (reverse order)
+        const bool rev = (e % 2) == 0;
+        const std::string f = S("flow.flows.%d", 2 * j);
+        {
+            const HostTensor& w = wf.get(f + ".pre.weight", {H, half, 1});
+            const HostTensor& b = wf.get(f + ".pre.bias", {H});
+            std::vector<float> wv(w.count), bv(b.data, b.data + b.count);
+            for (int co = 0; co < H; ++co)
+                for (int q = 0; q < half; ++q) wv[(size_t)co * half + q] = w.data[(size_t)co * half + (rev ? half - 1 - q : q)];
+            add_conv_data(S("flow.%d.pre", j), wv, &bv, H, half, 1);
+        }
+        for (int l = 0; l < c.flow_wn_layers; ++l) {
+            add_conv(wf, S("flow.%d.in.%d", j, l), f + S(".enc.in_layers.%d", l), 2 * H, H, c.flow_wn_kernel, true, EPI_GATE);
+            const int rs = l < c.flow_wn_layers - 1 ? 2 * H : H;
+            add_conv(wf, S("flow.%d.rs.%d", j, l), f + S(".enc.res_skip_layers.%d", l), rs, H, 1, true);
+        }
+        if (gin) {
+            add_vec(wf, f + ".enc.cond_layer.weight", {2 * H * c.flow_wn_layers, gin, 1});
+            add_vec(wf, f + ".enc.cond_layer.bias", {2 * H * c.flow_wn_layers});
+        }
+        {
+            const HostTensor& w = wf.get(f + ".post.weight", {half, H, 1});
+            const HostTensor& b = wf.get(f + ".post.bias", {half});
+            std::vector<float> wv(w.count), bv(b.count);
+            for (int p = 0; p < half; ++p) {
+                const int src = rev ? half - 1 - p : p;
+                memcpy(wv.data() + (size_t)p * H, w.data + (size_t)src * H, sizeof(float) * H);
+                bv[p] = b.data[src];
+            }
+            add_conv_data(S("flow.%d.post", j), wv, &bv, half, H, 1);
+        }
+    }
+    flow_reversed_out_ = (c.flow_n_flows % 2) == 1;
+
+    // ---- HiFi-GAN decoder
+    const int C0 = c.upsample_initial_channel;
+    {
+        const HostTensor& w = wf.get("dec.conv_pre.weight", {C0, I, 7});
+        const HostTensor& b = wf.get("dec.conv_pre.bias", {C0});
+        std::vector<float> wv(w.count), bv(b.data, b.data + b.count);
+        for (int co = 0; co < C0; ++co)
+            for (int ci = 0; ci < I; ++ci)
+                memcpy(wv.data() + ((size_t)co * I + ci) * 7, w.data + ((size_t)co * I + (flow_reversed_out_ ? I - 1 - ci : ci)) * 7,
+                       sizeof(float) * 7);
+        add_conv_data("dec.conv_pre", wv, &bv, C0, I, 7);
+    }
+    int ch = C0;
+    for (int i = 0; i < c.n_upsamples; ++i) {
+        add_vec(wf, S("dec.ups.%d.weight", i), {ch, ch / 2, c.upsample_kernel_sizes[i]});
+        add_vec(wf, S("dec.ups.%d.bias", i), {ch / 2});
+        ch /= 2;
+        for (int j = 0; j < c.n_resblock_kernels; ++j) {
+            const int n = i * c.n_resblock_kernels + j;
+            const int rk = c.resblock_kernel_sizes[j];
+            for (int m = 0; m < c.resblock_n_dilations[j]; ++m) {
+                if (c.resblock == 2) {
+                    add_conv(wf, S("dec.rb.%d.c.%d", n, m), S("dec.resblocks.%d.convs.%d", n, m), ch, ch, rk, true);
+                } else {
+                    add_conv(wf, S("dec.rb.%d.c1.%d", n, m), S("dec.resblocks.%d.convs1.%d", n, m), ch, ch, rk, true);
+                    add_conv(wf, S("dec.rb.%d.c2.%d", n, m), S("dec.resblocks.%d.convs2.%d", n, m), ch, ch, rk, true);
+                }
+            }
+        }
+    }
+    add_vec(wf, "dec.conv_post.weight", {1, ch, 7});
+    if (gin) {
+        add_vec(wf, "dec.cond.weight", {C0, gin, 1});
+        add_vec(wf, "dec.cond.bias", {C0});
+        add_vec(wf, "emb_g.weight", {c.n_speakers, gin});
+    }
+
+    // ---- one upload
+    void* p = nullptr;
+    if (hipMalloc(&p, host_stage_.size() * sizeof(float) + 256) != hipSuccess)
+        throw EngineError(MI355VITS_ERR_NOMEM, "out of device memory (weights)");
+    dev_weights_ = static_cast<float*>(p);
+    HIP_CHECK(hipMemcpy(dev_weights_, host_stage_.data(), host_stage_.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float>().swap(host_stage_);
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (dev_weights_) (void)hipFree(dev_weights_);
+    if (ev_start_) (void)hipEventDestroy(ev_start_);
+    if (ev_end_) (void)hipEventDestroy(ev_end_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// =================================================================================================
+// launch helpers
+// =================================================================================================
+void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
+    a.Cin = w.Cin;
+    a.Cout = w.Cout;
+    a.K = w.K;
+    a.bias = P(w.bias);
+    a.pad = (w.K * a.dil - a.dil) / 2;
+    if ((a.epi == EPI_GATE) != (w.epi == EPI_GATE)) throw EngineError(MI355VITS_ERR_INTERNAL, "conv epilogue / packing mismatch");
+    const double flops = 2.0 * a.B * (double)a.T * w.Cout * w.Cin * w.K;
+    double ch_io = (double)w.Cin + (a.epi == EPI_GATE ? a.H : w.Cout);
+    if (a.res) ch_io += w.Cout;
+    if (a.accumulate) ch_io += w.Cout;
+    if (a.epi == EPI_RESSKIP) ch_io += w.Cout;  // h and skip are read-modify-write
+    const double bytes = 4.0 * a.B * (double)a.T * ch_io + 4.0 * (double)w.Cout * w.Cin * w.K;
+    ProfScope ps(prof_, label, flops, bytes);
+    if (!force_generic_ && w.packed != NO_OFF) {
+        a.w = P(w.packed);
+        launch_conv1d_mfma(a, stream_);
+    } else {
+        a.w = P(w.raw);
+        launch_conv1d_generic(a, stream_);
+    }
+}
+
+void Engine::tap(const char* name, const float* dev, std::initializer_list<int64_t> dims) {
+    if (!taps_on_) return;
+    size_t cnt = 1;
+    for (auto d : dims) cnt *= (size_t)d;
+    for (auto& t : taps_)
+        if (t.name == name) return;
+    Tap t;
+    t.name = name;
+    t.dims.assign(dims.begin(), dims.end());
+    t.count = cnt;
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, cnt * sizeof(float) + 16));
+    t.dev = static_cast<float*>(p);
+    HIP_CHECK(hipMemcpyAsync(t.dev, dev, cnt * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+    taps_.push_back(std::move(t));
+}
+
+long Engine::get_tap(const std::string& name, float* out, size_t cap, int64_t dims[4]) {
+    for (auto& t : taps_)
+        if (t.name == name) {
+            for (int i = 0; i < 4; ++i) dims[i] = i < (int)t.dims.size() ? t.dims[i] : 1;
+            if (out) {
+                if (cap < t.count) throw EngineError(MI355VITS_ERR_INVALID, "tap buffer too small");
+                HIP_CHECK(hipStreamSynchronize(stream_));
+                HIP_CHECK(hipMemcpy(out, t.dev, t.count * sizeof(float), hipMemcpyDeviceToHost));
+            }
+            return (long)t.count;
+        }
+    throw EngineError(MI355VITS_ERR_INVALID, "no such tap: " + name);
+}
+std::string Engine::list_taps() const {
+    std::string s;
+    for (auto& t : taps_) s += t.name + "\n";
+    return s;
+}
+
+float Engine::last_run_ms() {
+    if (!timed_) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, ev_start_, ev_end_) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// =================================================================================================
+// K1-K4 text encoder
+// =================================================================================================
+void Engine::text_encoder(int B, int Tx) {
+    const mi355vits_config& c = cfg_;
+    const int H = c.hidden_channels, F = c.filter_channels, I = c.inter_channels;
+    const long xbs = (long)H * Tx;
+    {
+        ProfScope ps(prof_, "embed", 0, 4.0 * B * H * Tx);
+        launch_embed(d_ids_, d_len_, vec("enc_p.emb.weight"), B, Tx, H, c.num_symbols, sqrtf((float)H), d_x_, stream_);
+    }
+    for (int i = 0; i < c.n_layers; ++i) {
+        const std::string a = S("enc_p.encoder.attn_layers.%d", i);
+        ConvArgs q;
+        q.x = d_x_; q.x_bs = xbs; q.x_ld = Tx;
+        q.y = d_qkv_; q.y_bs = 3 * xbs; q.y_ld = Tx;
+        q.B = B; q.T = Tx;
+        conv("enc.qkv", cw(S("enc.%d.qkv", i)), q);
+        {
+            const double fl = 4.0 * B * (double)Tx * Tx * H;
+            ProfScope ps(prof_, "enc.attention", fl, 4.0 * B * 4 * H * Tx);
+            launch_rel_attention(d_qkv_, vec(a + ".emb_rel_k"), vec(a + ".emb_rel_v"), d_len_, B, Tx, H, c.n_heads,
+                                 c.window_size, d_att_, stream_);
+        }
+        ConvArgs o;
+        o.x = d_att_; o.x_bs = xbs; o.x_ld = Tx;
+        o.y = d_x2_; o.y_bs = xbs; o.y_ld = Tx;
+        o.res = d_x_; o.res_bs = xbs; o.res_ld = Tx;
+        o.B = B; o.T = Tx;
+        conv("enc.o", cw(S("enc.%d.o", i)), o);
+        {
+            LNArgs ln;
+            ln.x = d_x2_; ln.y = d_x_; ln.B = B; ln.C = H; ln.T = Tx;
+            ln.gamma = vec(S("enc_p.encoder.norm_layers_1.%d.gamma", i));
+            ln.beta = vec(S("enc_p.encoder.norm_layers_1.%d.beta", i));
+            ProfScope ps(prof_, "layernorm", 0, 8.0 * B * H * Tx);
+            launch_layernorm(ln, stream_);
+        }
+        ConvArgs f1;
+        f1.x = d_x_; f1.x_bs = xbs; f1.x_ld = Tx;
+        f1.y = d_ffn_; f1.y_bs = (long)F * Tx; f1.y_ld = Tx;
+        f1.in_len = d_len_; f1.relu = 1;
+        f1.B = B; f1.T = Tx;
+        conv("enc.ffn1", cw(S("enc.%d.ffn1", i)), f1);
+        ConvArgs f2;
+        f2.x = d_ffn_; f2.x_bs = (long)F * Tx; f2.x_ld = Tx;
+        f2.y = d_x2_; f2.y_bs = xbs; f2.y_ld = Tx;
+        f2.in_len = d_len_; f2.out_len = d_len_; f2.mask_before_res = 1;
+        f2.res = d_x_; f2.res_bs = xbs; f2.res_ld = Tx;
+        f2.B = B; f2.T = Tx;
+        conv("enc.ffn2", cw(S("enc.%d.ffn2", i)), f2);
+        {
+            LNArgs ln;
+            ln.x = d_x2_; ln.y = d_x_; ln.B = B; ln.C = H; ln.T = Tx;
+            ln.gamma = vec(S("enc_p.encoder.norm_layers_2.%d.gamma", i));
+            ln.beta = vec(S("enc_p.encoder.norm_layers_2.%d.beta", i));
+            if (i == c.n_layers - 1) ln.out_len = d_len_;  // x = x * x_mask after the last layer
+            ProfScope ps(prof_, "layernorm", 0, 8.0 * B * H * Tx);
+            launch_layernorm(ln, stream_);
+        }
+    }
+    tap("x", d_x_, {B, H, Tx});
+    ConvArgs p;
+    p.x = d_x_; p.x_bs = xbs; p.x_ld = Tx;
+    p.y = d_stats_; p.y_bs = 2L * I * Tx; p.y_ld = Tx;
+    p.out_len = d_len_;
+    p.B = B; p.T = Tx;
+    conv("enc.proj", cw("enc.proj"), p);
+    tap("stats", d_stats_, {B, 2 * I, Tx});
+}
+
+// =================================================================================================
+// K5 stochastic duration predictor (reverse) + K6 durations
+// =================================================================================================
+void Engine::dds(const std::string& key, float* X, float* Y1, float* Y2, int B, int T) {
+    const mi355vits_config& c = cfg_;
+    const int C = c.hidden_channels;
+    const long bs = (long)C * T;
+    int dil = 1;
+    for (int i = 0; i < c.dp_dds_layers; ++i) {
+        {
+            ProfScope ps(prof_, "dds.dwconv_ln_gelu", 0, 8.0 * B * C * T);
+            launch_dds_dwconv_ln_gelu(X, vec(key + S(".convs_sep.%d.weight", i)), vec(key + S(".convs_sep.%d.bias", i)),
+                                      vec(key + S(".norms_1.%d.gamma", i)), vec(key + S(".norms_1.%d.beta", i)), d_len_,
+                                      B, C, T, c.dp_kernel_size, dil, Y1, stream_);
+        }
+        ConvArgs a;
+        a.x = Y1; a.x_bs = bs; a.x_ld = T;
+        a.y = Y2; a.y_bs = bs; a.y_ld = T;
+        a.B = B; a.T = T;
+        conv("dds.1x1", cw(key + S(".convs_1x1.%d", i)), a);
+        {
+            LNArgs ln;
+            ln.x = Y2; ln.y = X; ln.add_to = X; ln.gelu = 1;
+            ln.B = B; ln.C = C; ln.T = T;
+            ln.gamma = vec(key + S(".norms_2.%d.gamma", i));
+            ln.beta = vec(key + S(".norms_2.%d.beta", i));
+            ProfScope ps(prof_, "layernorm", 0, 12.0 * B * C * T);
+            launch_layernorm(ln, stream_);
+        }
+        dil *= c.dp_kernel_size;
+    }
+}
+
+void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
+    const mi355vits_config& c = cfg_;
+    const int H = c.hidden_channels;
+    const long bs = (long)H * Tx;
+    const int nth = 3 * c.dp_num_bins - 1;
+    // h = proj(DDS(pre(x) [+ cond(g)])) * mask
+    ConvArgs pre;
+    pre.x = d_x_; pre.x_bs = bs; pre.x_ld = Tx;
+    pre.y = d_d0_; pre.y_bs = bs; pre.y_ld = Tx;
+    pre.cond = d_cond_dp_; pre.cond_bs = H;
+    pre.B = B; pre.T = Tx;
+    conv("dp.pre", cw("dp.pre"), pre);
+    dds("dp.convs", d_d0_, d_d1_, d_d2_, B, Tx);
+    ConvArgs pr;
+    pr.x = d_d0_; pr.x_bs = bs; pr.x_ld = Tx;
+    pr.y = d_h_; pr.y_bs = bs; pr.y_ld = Tx;
+    pr.in_len = d_len_; pr.out_len = d_len_;
+    pr.B = B; pr.T = Tx;
+    conv("dp.proj", cw("dp.proj"), pr);
+    tap("dp.h", d_h_, {B, H, Tx});
+
+    {
+        ProfScope ps(prof_, "sdp.noise");
+        launch_sdp_noise(d_z2_, d_noise_w_, B, Tx, args.scales[2], args.seed, args.utterance_base, stream_);
+    }
+    int ch0 = 0;  // physical channel that is logical channel 0
+    for (int j = c.dp_n_flows - 1; j >= 1; --j) {
+        ch0 ^= 1;  // Flip
+        const std::string p = S("dp.flows.%d", 1 + 2 * j);
+        {
+            ProfScope ps(prof_, "convflow.pre", 0, 12.0 * B * H * Tx);
+            launch_convflow_pre(d_z2_, ch0, vec(p + ".pre.weight"), vec(p + ".pre.bias"), d_h_, B, H, Tx, d_d0_, stream_);
+        }
+        dds(p + ".convs", d_d0_, d_d1_, d_d2_, B, Tx);
+        ConvArgs a;
+        a.x = d_d0_; a.x_bs = bs; a.x_ld = Tx;
+        a.y = d_theta_; a.y_bs = (long)nth * Tx; a.y_ld = Tx;
+        a.in_len = d_len_; a.out_len = d_len_;
+        a.B = B; a.T = Tx;
+        conv("convflow.proj", cw(p + ".proj"), a);
+        {
+            ProfScope ps(prof_, "spline");
+            launch_spline_inverse(d_z2_, ch0, d_theta_, d_len_, B, Tx, c.dp_num_bins, c.dp_tail_bound,
+                                  1.0f / sqrtf((float)H), stream_);
+        }
+    }
+    ch0 ^= 1;  // Flip before the ElementwiseAffine
+    {
+        ProfScope ps(prof_, "durations");
+        // logical channel 0 uses EA parameters [0]
+        launch_durations(d_z2_, ch0, ea_m_[0], ea_logs_[0], d_len_, d_forced_, B, Tx, args.scales[1], d_logw_, d_wceil_,
+                         d_cum_, d_ylen_, stream_);
+    }
+    tap("logw", d_logw_, {B, 1, Tx});
+}
+
+// =================================================================================================
+// K6/K7 expand + K8 flow^-1 + K9-K12 decoder
+// =================================================================================================
+void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
+    const mi355vits_config& c = cfg_;
+    const int H = c.hidden_channels, I = c.inter_channels, half = I / 2;
+    const int Tx = Tx_;
+    const long zbs = (long)I * Ty, hbs = (long)H * Ty;
+    {
+        ProfScope ps(prof_, "expand_prior", 0, 4.0 * B * I * Ty * 3);
+        launch_expand_prior(d_stats_, d_cum_, d_ylen_, d_noise_z_, args.noise_z_frames, B, I, Tx, Ty, args.scales[0],
+                            args.seed, args.utterance_base, d_z_, stream_);
+    }
+    tap("z_p", d_z_, {B, I, Ty});
+
+    for (int j = c.flow_n_flows - 1; j >= 0; --j) {
+        const int e = c.flow_n_flows - 1 - j;
+        const bool rev = (e % 2) == 0;
+        float* x0 = d_z_ + (rev ? (long)half * Ty : 0);
+        float* x1 = d_z_ + (rev ? 0 : (long)half * Ty);
+        ConvArgs pre;
+        pre.x = x0; pre.x_bs = zbs; pre.x_ld = Ty;
+        pre.y = d_fh_; pre.y_bs = hbs; pre.y_ld = Ty;
+        pre.out_len = d_ylen_;
+        pre.B = B; pre.T = Ty;
+        conv("flow.pre", cw(S("flow.%d.pre", j)), pre);
+        for (int l = 0; l < c.flow_wn_layers; ++l) {
+            int dil = 1;
+            for (int q = 0; q < l; ++q) dil *= c.flow_wn_dilation_rate;
+            ConvArgs in;
+            in.x = d_fh_; in.x_bs = hbs; in.x_ld = Ty;
+            in.y = d_fu_; in.y_bs = hbs; in.y_ld = Ty;
+            in.epi = EPI_GATE; in.H = H; in.dil = dil;
+            if (!d_cond_flow_.empty()) {
+                in.cond = d_cond_flow_[j] + (long)l * 2 * H;
+                in.cond_bs = 2L * H * c.flow_wn_layers;
+            }
+            in.B = B; in.T = Ty;
+            conv("flow.in_gate", cw(S("flow.%d.in.%d", j, l)), in);
+            ConvArgs rs;
+            rs.x = d_fu_; rs.x_bs = hbs; rs.x_ld = Ty;
+            rs.y = d_fh_; rs.y_bs = hbs; rs.y_ld = Ty;
+            rs.y2 = d_fskip_; rs.y2_bs = hbs; rs.y2_ld = Ty;
+            rs.epi = EPI_RESSKIP; rs.H = H; rs.skip_init = (l == 0);
+            rs.out_len = d_ylen_;
+            rs.B = B; rs.T = Ty;
+            conv("flow.res_skip", cw(S("flow.%d.rs.%d", j, l)), rs);
+        }
+        ConvArgs post;
+        post.x = d_fskip_; post.x_bs = hbs; post.x_ld = Ty;
+        post.y = x1; post.y_bs = zbs; post.y_ld = Ty;
+        post.res = x1; post.res_bs = zbs; post.res_ld = Ty; post.res_sub = 1;
+        post.in_len = d_ylen_; post.out_len = d_ylen_;
+        post.B = B; post.T = Ty;
+        conv("flow.post_couple", cw(S("flow.%d.post", j)), post);
+    }
+    tap("z", d_z_, {B, I, Ty});
+
+    // ---- decoder
+    const int C0 = c.upsample_initial_channel;
+    ConvArgs cp;
+    cp.x = d_z_; cp.x_bs = zbs; cp.x_ld = Ty;
+    cp.y = d_bufC_; cp.y_bs = (long)C0 * Ty; cp.y_ld = Ty;
+    cp.in_len = d_ylen_;
+    cp.cond = d_cond_dec_; cp.cond_bs = C0;
+    cp.B = B; cp.T = Ty;
+    conv("dec.conv_pre", cw("dec.conv_pre"), cp);
+    tap("dec.conv_pre", d_bufC_, {B, C0, Ty});
+
+    int ch = C0;
+    long T = Ty;
+    const int nk = c.n_resblock_kernels;
+    for (int i = 0; i < c.n_upsamples; ++i) {
+        const int r = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+        ConvTArgs u;
+        u.x = d_bufC_; u.x_bs = (long)ch * T; u.x_ld = (int)T;
+        u.y = d_bufA_; u.y_bs = (long)(ch / 2) * T * r; u.y_ld = (int)(T * r);
+        u.w = vec(S("dec.ups.%d.weight", i)); u.bias = vec(S("dec.ups.%d.bias", i));
+        u.B = B; u.Cin = ch; u.Cout = ch / 2; u.Tin = (int)T; u.K = k; u.stride = r; u.pad = (k - r) / 2;
+        u.in_slope = 0.1f;
+        u.in_len = d_slen_ + (long)i * B;
+        {
+            const int taps = (k + r - 1) / r;
+            ProfScope ps(prof_, "dec.upsample", 2.0 * B * (double)T * r * ch * (ch / 2) * taps,
+                         4.0 * B * ((double)ch * T + (double)(ch / 2) * T * r));
+            launch_conv_transpose1d(u, stream_);
+        }
+        ch /= 2;
+        T *= r;
+        const long sbs = (long)ch * T;
+        const int* slen = d_slen_ + (long)(i + 1) * B;  // rows end at their own length (batched == unbatched)
+        tap(S("dec.ups.%d", i).c_str(), d_bufA_, {B, ch, T});
+        for (int j = 0; j < nk; ++j) {
+            const int n = i * nk + j;
+            const int nd = c.resblock_n_dilations[j];
+            const float* src = d_bufA_;
+            float* pp[2] = {d_bufB_, d_bufT_};
+            for (int m = 0; m < nd; ++m) {
+                const int dil = c.resblock_dilations[j * MI355VITS_MAX_STAGES + m];
+                const bool last = (m == nd - 1);
+                if (c.resblock == 2) {
+                    // x = x + conv_{k,d}(lrelu(x))
+                    float* dst = last ? d_bufC_ : pp[m & 1];
+                    ConvArgs a;
+                    a.x = src; a.x_bs = sbs; a.x_ld = (int)T;
+                    a.y = dst; a.y_bs = sbs; a.y_ld = (int)T;
+                    a.res = src; a.res_bs = sbs; a.res_ld = (int)T;
+                    a.in_slope = 0.1f; a.dil = dil; a.in_len = slen;
+                    if (last) { a.out_scale = 1.0f / nk; a.accumulate = (j > 0); }
+                    a.B = B; a.T = (int)T;
+                    conv(i == 0 ? "dec.rb.s0" : (i == 1 ? "dec.rb.s1" : "dec.rb.s2+"), cw(S("dec.rb.%d.c.%d", n, m)), a);
+                    src = dst;
+                } else {
+                    // xt = c2(lrelu(c1(lrelu(x)))); x = xt + x
+                    // the pair's output may overwrite its own residual source in place (c2 reads `mid`, and each
+                    // thread reads res[co,t] before writing y[co,t]); only the stage input bufA must survive.
+                    float* mid = d_bufT_;
+                    float* dst = last ? d_bufC_ : d_bufB_;
+                    ConvArgs a1;
+                    a1.x = src; a1.x_bs = sbs; a1.x_ld = (int)T;
+                    a1.y = mid; a1.y_bs = sbs; a1.y_ld = (int)T;
+                    a1.in_slope = 0.1f; a1.dil = dil; a1.in_len = slen;
+                    a1.B = B; a1.T = (int)T;
+                    conv("dec.rb1.c1", cw(S("dec.rb.%d.c1.%d", n, m)), a1);
+                    ConvArgs a2;
+                    a2.x = mid; a2.x_bs = sbs; a2.x_ld = (int)T;
+                    a2.y = dst; a2.y_bs = sbs; a2.y_ld = (int)T;
+                    a2.res = src; a2.res_bs = sbs; a2.res_ld = (int)T;
+                    a2.in_slope = 0.1f; a2.dil = 1; a2.in_len = slen;
+                    if (last) { a2.out_scale = 1.0f / nk; a2.accumulate = (j > 0); }
+                    a2.B = B; a2.T = (int)T;
+                    conv("dec.rb1.c2", cw(S("dec.rb.%d.c2.%d", n, m)), a2);
+                    src = dst;
+                }
+            }
+        }
+        tap(S("dec.mrf.%d", i).c_str(), d_bufC_, {B, ch, T});
+    }
+    HIP_CHECK(hipMemsetAsync(d_peaks_, 0, sizeof(unsigned) * B, stream_));
+    {
+        ProfScope ps(prof_, "dec.conv_post_tanh", 2.0 * B * (double)T * ch * 7, 4.0 * B * (double)T * (ch + 1));
+        launch_conv_post_tanh(d_bufC_, (long)ch * T, (int)T, vec("dec.conv_post.weight"), ch, 7, B, (int)T, d_alen_, d_audio_,
+                              T, d_peaks_, stream_);
+    }
+}
+
+// =================================================================================================
+// one synthesis call
+// =================================================================================================
+namespace {
+struct ResultOwner {
+    void* audio = nullptr;
+    void* pcm = nullptr;
+    void* lengths = nullptr;
+    void* peaks = nullptr;
+};
+}  // namespace
+
+void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
+    const mi355vits_config& c = cfg_;
+    if (!out) throw EngineError(MI355VITS_ERR_INVALID, "result pointer is null");
+    memset(out, 0, sizeof(*out));
+    if (args.batch < 1 || args.tx_max < 1) throw EngineError(MI355VITS_ERR_INVALID, "batch and tx_max must be >= 1");
+    if (!args.ids || !args.lengths || !args.scales) throw EngineError(MI355VITS_ERR_INVALID, "input, input_lengths and scales are required");
+    const bool multi = c.n_speakers > 1;
+    if (multi && !args.sid) throw EngineError(MI355VITS_ERR_INVALID, "multi-speaker voice: feed 'sid' is required");
+    const int B = args.batch, Tx = args.tx_max;
+    if ((long)B * Tx > (1L << 26)) throw EngineError(MI355VITS_ERR_INVALID, "batch * tx_max too large");
+    for (int i = 0; i < 3; ++i)
+        if (!std::isfinite(args.scales[i])) throw EngineError(MI355VITS_ERR_INVALID, "scales must be finite");
+    if (args.scales[0] < 0 || args.scales[2] < 0) throw EngineError(MI355VITS_ERR_INVALID, "noise scales must be >= 0");
+    if (!(args.scales[1] > 0)) throw EngineError(MI355VITS_ERR_INVALID, "length_scale must be > 0");
+    std::vector<int> len32(B);
+    for (int b = 0; b < B; ++b) {
+        if (args.lengths[b] < 0 || args.lengths[b] > Tx) throw EngineError(MI355VITS_ERR_INVALID, "input_lengths out of range");
+        len32[b] = (int)args.lengths[b];
+        for (int t = 0; t < len32[b]; ++t) {
+            const int64_t id = args.ids[(long)b * Tx + t];
+            if (id < 0 || id >= c.num_symbols) throw EngineError(MI355VITS_ERR_INVALID, "phoneme id out of range");
+        }
+        if (multi && (args.sid[b] < 0 || args.sid[b] >= c.n_speakers)) throw EngineError(MI355VITS_ERR_INVALID, "speaker id out of range");
+    }
+    if (args.noise_z && args.noise_z_frames < 1) throw EngineError(MI355VITS_ERR_INVALID, "noise_z_frames must be >= 1");
+
+    HIP_CHECK(hipSetDevice(device_));
+    have_result_ = false;
+    taps_on_ = (args.flags & MI355VITS_DEBUG_TAPS) != 0;
+    for (auto& t : taps_) (void)hipFree(t.dev);
+    taps_.clear();
+
+    const int H = c.hidden_channels, F = c.filter_channels, I = c.inter_channels;
+    const int nth = 3 * c.dp_num_bins - 1;
+    const int C0 = c.upsample_initial_channel;
+    const int gin = multi ? c.gin_channels : 0;
+    auto pad = [](size_t bytes) { return DeviceArena::padded(bytes); };
+
+    // ---------------- phase A workspace
+    const size_t fBT = (size_t)B * Tx;
+    size_t need_a = pad(fBT * 8) + pad((size_t)B * 8) + 6 * pad((size_t)B * 4) + 3 * pad(fBT * 4);
+    need_a += 3 * pad(fBT * H * 4) + pad(fBT * 3 * H * 4) + pad(fBT * F * 4) + pad(fBT * 2 * I * 4);  // x,x2,att,qkv,ffn,stats
+    need_a += 4 * pad(fBT * H * 4) + pad(fBT * nth * 4) + 2 * pad(fBT * 2 * 4) + pad(fBT * 4);          // h,d0,d1,d2,theta,z2,noise_w,logw
+    if (gin) need_a += pad((size_t)B * H * 4) + pad((size_t)B * C0 * 4) + (size_t)c.flow_n_flows * pad((size_t)B * 2 * H * c.flow_wn_layers * 4);
+    arena_a_.reserve(need_a + 4096, stream_);
+    arena_a_.reset();
+    d_ids_ = arena_a_.alloc<long long>(fBT);
+    d_sid_ = arena_a_.alloc<long long>(B);
+    d_len_ = arena_a_.alloc<int>(B);
+    d_ylen_ = arena_a_.alloc<int>(B);
+    d_alen_ = arena_a_.alloc<int>(B);
+    d_peaks_ = arena_a_.alloc<unsigned>(B);
+    d_wceil_ = arena_a_.alloc<int>(fBT);
+    d_cum_ = arena_a_.alloc<int>(fBT);
+    d_forced_ = nullptr;
+    if (args.forced_durations) d_forced_ = arena_a_.alloc<int>(fBT);
+    d_x_ = arena_a_.alloc<float>(fBT * H);
+    d_x2_ = arena_a_.alloc<float>(fBT * H);
+    d_att_ = arena_a_.alloc<float>(fBT * H);
+    d_qkv_ = arena_a_.alloc<float>(fBT * 3 * H);
+    d_ffn_ = arena_a_.alloc<float>(fBT * F);
+    d_stats_ = arena_a_.alloc<float>(fBT * 2 * I);
+    d_h_ = arena_a_.alloc<float>(fBT * H);
+    d_d0_ = arena_a_.alloc<float>(fBT * H);
+    d_d1_ = arena_a_.alloc<float>(fBT * H);
+    d_d2_ = arena_a_.alloc<float>(fBT * H);
+    d_theta_ = arena_a_.alloc<float>(fBT * nth);
+    d_z2_ = arena_a_.alloc<float>(fBT * 2);
+    d_noise_w_ = nullptr;
+    if (args.noise_w) d_noise_w_ = arena_a_.alloc<float>(fBT * 2);
+    d_logw_ = arena_a_.alloc<float>(fBT);
+    d_cond_dp_ = nullptr;
+    d_cond_dec_ = nullptr;
+    d_cond_flow_.clear();
+    if (gin) {
+        d_cond_dp_ = arena_a_.alloc<float>((size_t)B * H);
+        d_cond_dec_ = arena_a_.alloc<float>((size_t)B * C0);
+        for (int j = 0; j < c.flow_n_flows; ++j) d_cond_flow_.push_back(arena_a_.alloc<float>((size_t)B * 2 * H * c.flow_wn_layers));
+    }
+
+    HIP_CHECK(hipEventRecord(ev_start_, stream_));
+    timed_ = false;
+    HIP_CHECK(hipMemcpyAsync(d_ids_, args.ids, fBT * 8, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_len_, len32.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+    if (multi) HIP_CHECK(hipMemcpyAsync(d_sid_, args.sid, (size_t)B * 8, hipMemcpyHostToDevice, stream_));
+    if (args.forced_durations) HIP_CHECK(hipMemcpyAsync(d_forced_, args.forced_durations, fBT * 4, hipMemcpyHostToDevice, stream_));
+    if (args.noise_w) HIP_CHECK(hipMemcpyAsync(d_noise_w_, args.noise_w, fBT * 2 * 4, hipMemcpyHostToDevice, stream_));
+    // len32 must stay alive until the copy has been consumed: pageable copies are staged synchronously by HIP.
+
+    if (gin) {
+        ProfScope ps(prof_, "speaker_cond");
+        launch_speaker_cond(vec("emb_g.weight"), d_sid_, vec("dp.cond.weight"), vec("dp.cond.bias"), B, gin, H, d_cond_dp_, stream_);
+        launch_speaker_cond(vec("emb_g.weight"), d_sid_, vec("dec.cond.weight"), vec("dec.cond.bias"), B, gin, C0, d_cond_dec_, stream_);
+        for (int j = 0; j < c.flow_n_flows; ++j) {
+            const std::string f = S("flow.flows.%d", 2 * j);
+            launch_speaker_cond(vec("emb_g.weight"), d_sid_, vec(f + ".enc.cond_layer.weight"), vec(f + ".enc.cond_layer.bias"), B, gin,
+                                2 * H * c.flow_wn_layers, d_cond_flow_[j], stream_);
+        }
+    }
+
+    B_ = B;
+    Tx_ = Tx;
+    text_encoder(B, Tx);
+    duration_predictor(B, Tx, args);
+
+    // ---------------- the one host round trip: frame counts size the rest of the graph
+    h_ylen_.resize(B);
+    HIP_CHECK(hipMemcpyAsync(h_ylen_.data(), d_ylen_, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    int Ty = 1;
+    for (int b = 0; b < B; ++b) {
+        if (h_ylen_[b] < 1 || h_ylen_[b] > (1 << 22)) throw EngineError(MI355VITS_ERR_INVALID, "predicted duration out of range (bad weights or length_scale?)");
+        Ty = std::max(Ty, h_ylen_[b]);
+    }
+    if (args.noise_z && args.scales[0] != 0.0f && args.noise_z_frames < Ty)
+        throw EngineError(MI355VITS_ERR_INVALID, "noise_z has fewer frames than the utterance needs");
+    if (taps_on_) {
+        // w_ceil as floats for the tap interface
+        std::vector<int> wc(fBT);
+        HIP_CHECK(hipMemcpy(wc.data(), d_wceil_, fBT * 4, hipMemcpyDeviceToHost));
+        std::vector<float> wf32(wc.begin(), wc.end());
+        Tap t;
+        t.name = "w_ceil";
+        t.dims = {B, 1, Tx};
+        t.count = fBT;
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, fBT * 4 + 16));
+        t.dev = static_cast<float*>(p);
+        HIP_CHECK(hipMemcpy(t.dev, wf32.data(), fBT * 4, hipMemcpyHostToDevice));
+        taps_.push_back(std::move(t));
+    }
+    Ty_ = Ty;
+    const long hop = c.hop_length;
+    L_ = (long)Ty * hop;
+
+    // ---------------- phase B workspace
+    size_t max_stage = (size_t)C0 * Ty;
+    {
+        size_t ch = C0, T = Ty;
+        for (int i = 0; i < c.n_upsamples; ++i) {
+            ch /= 2;
+            T *= c.upsample_rates[i];
+            max_stage = std::max(max_stage, ch * T);
+        }
+    }
+    const size_t fBTy = (size_t)B * Ty;
+    size_t need_b = pad(fBTy * I * 4) + 3 * pad(fBTy * H * 4);
+    if (args.noise_z && args.scales[0] != 0.0f) need_b += pad((size_t)B * I * args.noise_z_frames * 4);
+    need_b += 4 * pad((size_t)B * max_stage * 4) + pad((size_t)B * L_ * 4) + pad((size_t)B * L_ * 2);
+    need_b += pad((size_t)(c.n_upsamples + 1) * B * 4);
+    arena_b_.reserve(need_b + 4096, stream_);
+    arena_b_.reset();
+    d_z_ = arena_b_.alloc<float>(fBTy * I);
+    d_fh_ = arena_b_.alloc<float>(fBTy * H);
+    d_fskip_ = arena_b_.alloc<float>(fBTy * H);
+    d_fu_ = arena_b_.alloc<float>(fBTy * H);
+    d_noise_z_ = nullptr;
+    if (args.noise_z && args.scales[0] != 0.0f) {
+        d_noise_z_ = arena_b_.alloc<float>((size_t)B * I * args.noise_z_frames);
+        HIP_CHECK(hipMemcpyAsync(d_noise_z_, args.noise_z, (size_t)B * I * args.noise_z_frames * 4, hipMemcpyHostToDevice, stream_));
+    }
+    d_bufA_ = arena_b_.alloc<float>((size_t)B * max_stage);
+    d_bufB_ = arena_b_.alloc<float>((size_t)B * max_stage);
+    d_bufT_ = arena_b_.alloc<float>((size_t)B * max_stage);
+    d_bufC_ = arena_b_.alloc<float>((size_t)B * max_stage);
+    d_audio_ = arena_b_.alloc<float>((size_t)B * L_);
+    d_pcm_ = arena_b_.alloc<int16_t>((size_t)B * L_);
+    std::vector<int> alen(B);
+    for (int b = 0; b < B; ++b) alen[b] = (int)(h_ylen_[b] * hop);
+    HIP_CHECK(hipMemcpyAsync(d_alen_, alen.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+    std::vector<int> slen((size_t)(c.n_upsamples + 1) * B);
+    {
+        long f = 1;
+        for (int i = 0; i <= c.n_upsamples; ++i) {
+            for (int b = 0; b < B; ++b) slen[(size_t)i * B + b] = (int)(h_ylen_[b] * f);
+            if (i < c.n_upsamples) f *= c.upsample_rates[i];
+        }
+    }
+    d_slen_ = arena_b_.alloc<int>(slen.size());
+    HIP_CHECK(hipMemcpyAsync(d_slen_, slen.data(), slen.size() * 4, hipMemcpyHostToDevice, stream_));
+
+    flow_and_decoder(B, Ty, args);
+
+    have_pcm_ = false;
+    if (args.flags & MI355VITS_WANT_PCM16) {
+        ProfScope ps(prof_, "pcm16", 0, 6.0 * B * (double)L_);
+        launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B, (int)L_, d_pcm_, L_, stream_);
+        have_pcm_ = true;
+    }
+    HIP_CHECK(hipEventRecord(ev_end_, stream_));
+    timed_ = true;
+    have_result_ = true;
+    copy_out(args.flags, out);
+}
+
+void Engine::copy_out(uint32_t want, mi355vits_result* out) {
+    const int B = B_;
+    auto* own = new ResultOwner();
+    out->owner_ = own;
+    out->batch = B;
+    out->l_max = L_;
+    out->ty_max = Ty_;
+    own->lengths = malloc(sizeof(int64_t) * B);
+    own->peaks = malloc(sizeof(float) * B);
+    out->lengths = static_cast<int64_t*>(own->lengths);
+    out->peaks = static_cast<float*>(own->peaks);
+    if (!out->lengths || !out->peaks) throw EngineError(MI355VITS_ERR_NOMEM, "out of host memory");
+    for (int b = 0; b < B; ++b) out->lengths[b] = (int64_t)h_ylen_[b] * cfg_.hop_length;
+    std::vector<unsigned> pk(B);
+    HIP_CHECK(hipMemcpyAsync(pk.data(), d_peaks_, sizeof(unsigned) * B, hipMemcpyDeviceToHost, stream_));
+    const bool dev_only = (want & MI355VITS_DEVICE_ONLY) != 0;
+    if (!dev_only && (want & MI355VITS_WANT_FLOAT)) {
+        HIP_CHECK(hipHostMalloc(&own->audio, sizeof(float) * (size_t)B * L_ + 16, hipHostMallocDefault));
+        out->audio = static_cast<float*>(own->audio);
+        HIP_CHECK(hipMemcpyAsync(out->audio, d_audio_, sizeof(float) * (size_t)B * L_, hipMemcpyDeviceToHost, stream_));
+    }
+    if (!dev_only && (want & MI355VITS_WANT_PCM16)) {
+        if (!have_pcm_) {
+            launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B, (int)L_, d_pcm_, L_, stream_);
+            have_pcm_ = true;
+        }
+        HIP_CHECK(hipHostMalloc(&own->pcm, sizeof(int16_t) * (size_t)B * L_ + 16, hipHostMallocDefault));
+        out->pcm = static_cast<int16_t*>(own->pcm);
+        HIP_CHECK(hipMemcpyAsync(out->pcm, d_pcm_, sizeof(int16_t) * (size_t)B * L_, hipMemcpyDeviceToHost, stream_));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int b = 0; b < B; ++b) memcpy(&out->peaks[b], &pk[b], 4);
+}
+
+void Engine::fetch(uint32_t want, mi355vits_result* out) {
+    if (!out) throw EngineError(MI355VITS_ERR_INVALID, "result pointer is null");
+    memset(out, 0, sizeof(*out));
+    if (!have_result_) throw EngineError(MI355VITS_ERR_INVALID, "fetch: no completed run on this handle");
+    HIP_CHECK(hipSetDevice(device_));
+    copy_out(want & ~MI355VITS_DEVICE_ONLY, out);
+}
+
+void free_result_impl(mi355vits_result* r) {
+    if (!r || !r->owner_) return;
+    auto* own = static_cast<ResultOwner*>(r->owner_);
+    if (own->audio) (void)hipHostFree(own->audio);
+    if (own->pcm) (void)hipHostFree(own->pcm);
+    free(own->lengths);
+    free(own->peaks);
+    delete own;
+    memset(r, 0, sizeof(*r));
+}
+
+}  // namespace m355

@@ -1,0 +1,177 @@
+// engine.h — host side of the MI355X VITS engine: weight container, device arenas, per-kernel
+// event profiler and the launch sequence of one synthesis call.
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mi355vits.h"
+#include "kernels.h"
+
+namespace m355 {
+
+struct EngineError : std::runtime_error {
+    int code;
+    EngineError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// ---------------------------------------------------------------- .m355 container (mimic3_amd/weights.py)
+struct HostTensor {
+    std::vector<int> dims;
+    const float* data = nullptr;
+    size_t count = 0;
+};
+struct WeightsFile {
+    mi355vits_config cfg{};
+    std::map<std::string, HostTensor> tensors;
+    std::vector<unsigned char> storage;      // owns the bytes when loaded from a file
+    void parse(const void* blob, size_t n);  // tensors point into `blob`
+    void load(const std::string& path);
+    const HostTensor& get(const std::string& name, std::initializer_list<int> dims) const;
+};
+
+// ---------------------------------------------------------------- grow-only bump allocator in HBM
+class DeviceArena {
+  public:
+    ~DeviceArena();
+    void reserve(size_t bytes, hipStream_t s);  // may reallocate (synchronises the stream first)
+    void reset() { off_ = 0; }
+    template <typename T> T* alloc(size_t n) { return reinterpret_cast<T*>(alloc_bytes(n * sizeof(T))); }
+    size_t capacity() const { return cap_; }
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+  private:
+    void* alloc_bytes(size_t bytes);
+    unsigned char* base_ = nullptr;
+    size_t cap_ = 0, off_ = 0;
+};
+
+// ---------------------------------------------------------------- HIP-event profiler on the engine stream
+struct Profiler {
+    struct Rec { int name_id; hipEvent_t a, b; double flops, bytes; };
+    bool enabled = false;
+    std::vector<std::string> names;
+    std::unordered_map<std::string, int> ids;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipStream_t stream = nullptr;
+    ~Profiler();
+    int begin(const char* name, double flops, double bytes);
+    void end(int rec);
+    void clear();
+    std::string report();  // synchronises
+  private:
+    hipEvent_t get_event();
+};
+struct ProfScope {
+    Profiler& p;
+    int rec;
+    ProfScope(Profiler& prof, const char* name, double flops = 0, double bytes = 0) : p(prof), rec(-1) {
+        if (p.enabled) rec = p.begin(name, flops, bytes);
+    }
+    ~ProfScope() {
+        if (rec >= 0) p.end(rec);
+    }
+};
+
+struct Tap {
+    std::string name;
+    float* dev;
+    std::vector<int64_t> dims;
+    size_t count;
+};
+
+constexpr size_t NO_OFF = ~size_t(0);
+
+// one dense Conv1d's parameters, as offsets (floats) into the device weight arena
+struct ConvW {
+    size_t raw = NO_OFF;     // [Cout,Cin,K]
+    size_t packed = NO_OFF;  // MFMA fragment order (absent when Cin is odd)
+    size_t bias = NO_OFF;
+    int Cout = 0, Cin = 0, K = 1;
+    int epi = EPI_STD;  // tile map the packed copy was built for
+};
+
+// ---------------------------------------------------------------- the engine
+class Engine {
+  public:
+    Engine(const WeightsFile& wf, int device);
+    ~Engine();
+    void run(const mi355vits_run_args& args, mi355vits_result* out);
+    void fetch(uint32_t want, mi355vits_result* out);
+    const mi355vits_config& config() const { return cfg_; }
+    Profiler& profiler() { return prof_; }
+    float last_run_ms();
+    long get_tap(const std::string& name, float* out, size_t cap, int64_t dims[4]);
+    std::string list_taps() const;
+    std::string last_error;
+    std::mutex mu;
+
+  private:
+    // weight staging
+    size_t stage(const float* p, size_t n);
+    const ConvW& add_conv(const WeightsFile& wf, const std::string& key, const std::string& tensor, int Cout, int Cin,
+                          int K, bool bias, int epi = EPI_STD);
+    const ConvW& add_conv_data(const std::string& key, const std::vector<float>& w, const std::vector<float>* bias,
+                               int Cout, int Cin, int K, int epi = EPI_STD);
+    void add_vec(const WeightsFile& wf, const std::string& name, std::initializer_list<int> dims);
+    const float* vec(const std::string& name) const;
+    const float* P(size_t off) const { return off == NO_OFF ? nullptr : dev_weights_ + off; }
+    const ConvW& cw(const std::string& key) const;
+
+    // launch helpers
+    void conv(const char* label, const ConvW& w, ConvArgs a);
+    void tap(const char* name, const float* dev, std::initializer_list<int64_t> dims);
+    void text_encoder(int B, int Tx);
+    void duration_predictor(int B, int Tx, const mi355vits_run_args& args);
+    void dds(const std::string& key, float* X, float* Y1, float* Y2, int B, int T);
+    void flow_and_decoder(int B, int Ty, const mi355vits_run_args& args);
+    void copy_out(uint32_t want, mi355vits_result* out);
+
+    mi355vits_config cfg_{};
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_start_ = nullptr, ev_end_ = nullptr;
+    bool timed_ = false;
+    bool force_generic_ = false;
+    Profiler prof_;
+
+    std::vector<float> host_stage_;
+    float* dev_weights_ = nullptr;
+    std::unordered_map<std::string, ConvW> convs_;
+    std::unordered_map<std::string, size_t> vecs_;
+    float ea_m_[2] = {0, 0}, ea_logs_[2] = {0, 0};
+    bool flow_reversed_out_ = false;
+
+    DeviceArena arena_a_, arena_b_, arena_taps_;
+    std::vector<Tap> taps_;
+    bool taps_on_ = false;
+    int B_ = 0, Tx_ = 0, Ty_ = 0;
+    long L_ = 0;
+    bool have_result_ = false, have_pcm_ = false;
+    // phase-A buffers (sized by B, Tx)
+    long long *d_ids_ = nullptr, *d_sid_ = nullptr;
+    int *d_len_ = nullptr, *d_wceil_ = nullptr, *d_cum_ = nullptr, *d_ylen_ = nullptr, *d_alen_ = nullptr,
+        *d_forced_ = nullptr;
+    float *d_x_ = nullptr, *d_x2_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_ffn_ = nullptr,
+          *d_stats_ = nullptr;
+    float *d_h_ = nullptr, *d_d0_ = nullptr, *d_d1_ = nullptr, *d_d2_ = nullptr, *d_theta_ = nullptr, *d_z2_ = nullptr,
+          *d_logw_ = nullptr, *d_noise_w_ = nullptr;
+    float *d_cond_dp_ = nullptr, *d_cond_dec_ = nullptr;
+    std::vector<float*> d_cond_flow_;
+    // phase-B buffers (sized by B, Ty)
+    float *d_z_ = nullptr, *d_fh_ = nullptr, *d_fu_ = nullptr, *d_fskip_ = nullptr, *d_noise_z_ = nullptr;
+    float *d_bufA_ = nullptr, *d_bufB_ = nullptr, *d_bufT_ = nullptr, *d_bufC_ = nullptr;
+    float* d_audio_ = nullptr;
+    int16_t* d_pcm_ = nullptr;
+    unsigned* d_peaks_ = nullptr;
+    int* d_slen_ = nullptr;  // [n_upsamples + 1][B] valid frames per decoder stage
+    std::vector<int> h_ylen_;
+};
+
+void free_result_impl(mi355vits_result* r);
+
+}  // namespace m355

@@ -1,0 +1,120 @@
+// kernels.h — launch wrappers of every HIP kernel on the path (definitions in kernels_*.cpp).
+// Activations are channels-first fp32 [B, C, T] (the reference graph's layout);
+// a tensor "view" is (pointer, batch stride, row stride) so channel halves need no copies.
+#pragma once
+#include "hipx.h"
+
+namespace m355 {
+
+struct Profiler;  // engine.h
+
+// ---------------------------------------------------------------- Conv1d
+enum ConvEpilogue { EPI_STD = 0, EPI_GATE = 1, EPI_RESSKIP = 2 };
+
+struct ConvArgs {
+    const float* x = nullptr; long x_bs = 0; int x_ld = 0;   // input  [B,Cin,T]
+    float* y = nullptr;       long y_bs = 0; int y_ld = 0;   // output [B,Cout,T] (GATE: [B,H,T]; RESSKIP: h, in place)
+    const float* w = nullptr;      // generic kernel: [Cout,Cin,K]; MFMA kernel: packed fragments (pack_conv_weights_mfma)
+    const float* bias = nullptr;   // [Cout] or null
+    const float* cond = nullptr; long cond_bs = 0;  // per-(b,co) additive term (speaker conditioning) or null
+    const float* res = nullptr; long res_bs = 0; int res_ld = 0;  // residual [B,Cout,T] or null
+    float* y2 = nullptr; long y2_bs = 0; int y2_ld = 0;           // RESSKIP: skip accumulator [B,H,T]
+    const int* in_len = nullptr;   // [B] valid length of the input (x * mask) or null
+    const int* out_len = nullptr;  // [B] valid length of the output (y * mask) or null
+    int B = 1, Cin = 0, Cout = 0, T = 0, K = 1, dil = 1, pad = 0;
+    float in_slope = 1.0f;   // leaky-relu slope applied to the input while staging (1 = identity)
+    int relu = 0;            // relu on the output
+    float out_scale = 1.0f;  // y = (...) * out_scale
+    int accumulate = 0;      // y += instead of y =
+    int res_sub = 0;         // v = res - v instead of res + v   (coupling: x1 = (x1 - mean) * mask)
+    int mask_before_res = 0; // apply the output mask to the conv result before the residual add (FFN: x + conv(..)*mask)
+    int skip_init = 0;       // RESSKIP: first WN layer writes skip instead of accumulating
+    int H = 0;               // GATE / RESSKIP: hidden channels
+    int epi = EPI_STD;
+};
+
+// Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).
+void launch_conv1d_generic(const ConvArgs& a, hipStream_t s);
+// fp32-MFMA implicit-GEMM Conv1d (v_mfma_f32_32x32x2_f32).  Needs Cin even and packed weights.
+void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s);
+bool conv1d_mfma_supported(int Cin, int Cout, int K, int dil);
+// Host-side weight repack for the MFMA kernel: [Cout,Cin,K] -> [ceil(Cout/32)][K][Cin/2][64].
+size_t mfma_packed_floats(int Cout, int Cin, int K);
+void pack_conv_weights_mfma(const float* w, int Cout, int Cin, int K, float* out);
+// epi = EPI_GATE packs rows as (c, H + c) tile pairs (H = Cout / 2); otherwise identical to the above.
+void pack_conv_weights_mfma_mode(const float* w, int Cout, int Cin, int K, int epi, float* out);
+
+// ---------------------------------------------------------------- ConvTranspose1d (K = 2*stride polyphase or general)
+struct ConvTArgs {
+    const float* x = nullptr; long x_bs = 0; int x_ld = 0;  // [B,Cin,Tin]
+    float* y = nullptr; long y_bs = 0; int y_ld = 0;        // [B,Cout,Tin*stride]
+    const float* w = nullptr;     // [Cin,Cout,K]
+    const float* bias = nullptr;  // [Cout]
+    const int* in_len = nullptr;  // [B] valid input frames per row (rows of a batch end at their own length)
+    int B = 1, Cin = 0, Cout = 0, Tin = 0, K = 0, stride = 0, pad = 0;
+    float in_slope = 1.0f;
+};
+void launch_conv_transpose1d(const ConvTArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- decoder tail
+// y = tanh(conv_post(lrelu_0.01(x * mask))) (Cout = 1, no bias) + per-utterance max|y| over valid samples;
+// mask = t < valid_len[b]: every row of a batch is synthesised as if it were alone (zero padding at its own end).
+void launch_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, int Cin, int K, int B, int L,
+                           const int* valid_len, float* audio, long audio_bs, unsigned* peak_bits, hipStream_t s);
+// audio_float_to_int16 per utterance (utils.py:237-244) from the peaks found above.
+void launch_pcm16(const float* audio, long audio_bs, const unsigned* peak_bits, const int* valid_len, int B, int L,
+                  int16_t* pcm, long pcm_bs, hipStream_t s);
+
+// ---------------------------------------------------------------- encoder pieces
+void launch_embed(const long long* ids, const int* len, const float* emb, int B, int T, int H, int num_symbols,
+                  float scale, float* y, hipStream_t s);
+// y = LN_c(x (+ res)) [* gelu] [* mask]; in place allowed (y == x).
+struct LNArgs {
+    const float* x = nullptr; const float* res = nullptr; float* y = nullptr;
+    const float* gamma = nullptr; const float* beta = nullptr;
+    const int* out_len = nullptr;
+    int B = 1, C = 0, T = 0;
+    int gelu = 0;
+    const float* add_to = nullptr;  // y = add_to + f(LN(x))   (DDS residual) or null
+    float eps = 1e-5f;
+};
+void launch_layernorm(const LNArgs& a, hipStream_t s);
+// relative-position multi-head attention on packed qkv [B, 3H, T] -> out [B, H, T]
+void launch_rel_attention(const float* qkv, const float* emb_rel_k, const float* emb_rel_v, const int* len,
+                          int B, int T, int H, int n_heads, int window, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------- stochastic duration predictor pieces
+// y = gelu(LN(dwconv_k,d(x * mask)))   (first half of a DDS layer, A.6)
+void launch_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias, const float* gamma,
+                               const float* beta, const int* len, int B, int C, int T, int K, int dil, float* y,
+                               hipStream_t s);
+// h[b,c,t] = w[c] * z[b,ch,t] + bias[c] + g[b,c,t]      (ConvFlow.pre on one channel + conditioning)
+void launch_convflow_pre(const float* z, int ch, const float* w, const float* bias, const float* g, int B, int C,
+                         int T, float* h, hipStream_t s);
+// z[b,1-ch] <- RQS^-1(z[b,1-ch]; theta[b,:,t]) inside the tail bound; then z *= mask     (A.7)
+void launch_spline_inverse(float* z, int ch_x0, const float* theta, const int* len, int B, int T, int nbins,
+                           float tail, float inv_sqrt_fc, hipStream_t s);
+// z init: z[b,c,t] = noise * noise_w (Philox or injected)
+void launch_sdp_noise(float* z, const float* injected, int B, int T, float noise_w, unsigned long long seed,
+                      unsigned long long utt_base, hipStream_t s);
+// EA^-1 on channel `ch` -> logw; durations: w = ceil(exp(logw)*mask*ls) (or forced); cum = inclusive scan;
+// ylen = max(1, sum)
+void launch_durations(const float* z, int ch, float ea_m, float ea_logs, const int* len, const int* forced, int B,
+                      int T, float length_scale, float* logw, int* w_ceil, int* cum, int* ylen, hipStream_t s);
+
+// ---------------------------------------------------------------- length regulator + prior sampling (K6, K7)
+void launch_expand_prior(const float* stats /*[B,2I,Tx]: m_p | logs_p*/, const int* cum, const int* ylen,
+                         const float* injected, int injected_frames, int B, int I, int Tx, int Ty,
+                         float noise_scale, unsigned long long seed, unsigned long long utt_base, float* z,
+                         hipStream_t s);
+
+// ---------------------------------------------------------------- speaker conditioning (A.11)
+// out[b, co] = W[co, :] . emb_g[sid[b], :] + bias[co]
+void launch_speaker_cond(const float* emb_g, const long long* sid, const float* w, const float* bias, int B,
+                         int gin, int Cout, float* out, hipStream_t s);
+
+// misc
+void launch_fill(float* p, float v, size_t n, hipStream_t s);
+void launch_mfma_selftest(float* out /*[32*32 + 16*16]*/, hipStream_t s);
+
+}  // namespace m355

@@ -1,0 +1,574 @@
+// kernels_conv.cpp — Conv1d / ConvTranspose1d / decoder-tail kernels for gfx950 (MI355X).
+//
+// Conv1d semantics:  y[co,t] = b[co] + sum_ci sum_k W[co,ci,k] * x[ci, t - pad + k*dil]
+// (zero outside [0,T)).  Two implementations share one epilogue:
+//   * k_conv1d_mfma   — implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32,
+//                       cdna_hip_programming.md §3): M = C_out, N = time, K = C_in x taps.  The input
+//                       tile (+halo) is staged once per C_in chunk into LDS with the input-side pointwise
+//                       op (mask, leaky-relu) fused; B fragments are conflict-free ds_read_b32 of 32
+//                       consecutive time samples per half-wave; A fragments come pre-packed in fragment
+//                       order from HBM/L2 (one coalesced 256 B load per k-step); all output-side pointwise
+//                       work (bias, speaker conditioning, relu, residual, WaveNet gate, res/skip update,
+//                       coupling subtract, masks, MRF mean) is fused into the epilogue.
+//   * k_conv1d_generic — plain VALU/LDS tiled kernel for any shape; reference for tests and A/B.
+#include "kernels.h"
+
+namespace m355 {
+
+// ------------------------------------------------------------------------------------------------
+// shared epilogues
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epi_std(const ConvArgs& a, int b, int co, int t, float v, int out_len) {
+    if (a.bias) v += a.bias[co];
+    if (a.cond) v += a.cond[(long)b * a.cond_bs + co];
+    if (a.relu) v = fmaxf(v, 0.0f);
+    if (a.mask_before_res && t >= out_len) v = 0.0f;
+    if (a.res) {
+        const float r = a.res[(long)b * a.res_bs + (long)co * a.res_ld + t];
+        v = a.res_sub ? r - v : r + v;
+    }
+    v *= a.out_scale;
+    if (!a.mask_before_res && t >= out_len) v = 0.0f;
+    float* yp = a.y + (long)b * a.y_bs + (long)co * a.y_ld + t;
+    if (a.accumulate) v += *yp;
+    *yp = v;
+}
+
+// WaveNet gate (A.9): u = tanh(a[:H] + cond) * sigmoid(a[H:] + cond)
+__device__ __forceinline__ void epi_gate(const ConvArgs& a, int b, int c, int t, float v0, float v1) {
+    if (a.bias) { v0 += a.bias[c]; v1 += a.bias[c + a.H]; }
+    if (a.cond) { v0 += a.cond[(long)b * a.cond_bs + c]; v1 += a.cond[(long)b * a.cond_bs + c + a.H]; }
+    const float u = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
+    a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = u;
+}
+
+// WaveNet res/skip update (A.9): h = (h + rs[:H]) * mask ; skip += rs[H:]  (last layer: skip += rs)
+__device__ __forceinline__ void epi_resskip(const ConvArgs& a, int b, int co, int t, float v, int out_len) {
+    if (a.bias) v += a.bias[co];
+    if (a.Cout == a.H || co >= a.H) {
+        const int c2 = (a.Cout == a.H) ? co : co - a.H;
+        float* sp = a.y2 + (long)b * a.y2_bs + (long)c2 * a.y2_ld + t;
+        *sp = a.skip_init ? v : *sp + v;
+    } else {
+        float* hp = a.y + (long)b * a.y_bs + (long)co * a.y_ld + t;
+        float h = *hp + v;
+        if (t >= out_len) h = 0.0f;
+        *hp = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic VALU kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int G_CO = 32, G_T = 64, G_CI = 8;
+
+__global__ __launch_bounds__(256) void k_conv1d_generic(ConvArgs a) {
+    DYN_SMEM(float, smem);
+    const int LD = G_T + (a.K - 1) * a.dil;
+    float* xs = smem;              // [G_CI][LD]
+    float* ws = smem + G_CI * LD;  // [G_CO][G_CI][K]
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * G_T;
+    const bool gate = (a.epi == EPI_GATE);
+    // output channels of this thread: STD/RESSKIP: co0 + 2*ty + i ; GATE: (c, c + H) with c = 16*blockIdx.y + ty
+    int co_i[2];
+    if (gate) {
+        const int c = blockIdx.y * 16 + ty;
+        co_i[0] = (c < a.H) ? c : -1;
+        co_i[1] = (c < a.H) ? c + a.H : -1;
+    } else {
+        for (int i = 0; i < 2; ++i) {
+            const int co = blockIdx.y * G_CO + 2 * ty + i;
+            co_i[i] = (co < a.Cout) ? co : -1;
+        }
+    }
+    const int in_len = a.in_len ? a.in_len[b] : a.T;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+    float acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += G_CI) {
+        for (int idx = tid; idx < G_CI * LD; idx += 256) {
+            const int ci = idx / LD, tt = idx - ci * LD;
+            const int c = c0 + ci, t = t0 - a.pad + tt;
+            float v = 0.0f;
+            if (c < a.Cin && t >= 0 && t < a.T && t < in_len) {
+                v = a.x[(long)b * a.x_bs + (long)c * a.x_ld + t];
+                v = v >= 0.0f ? v : v * a.in_slope;
+            }
+            xs[idx] = v;
+        }
+        // weights of the 32 rows this block needs: row r = 2*ty' + i  (ty' = 0..15)
+        for (int idx = tid; idx < G_CO * G_CI * a.K; idx += 256) {
+            const int r = idx / (G_CI * a.K);
+            const int rem = idx - r * (G_CI * a.K);
+            const int ci = rem / a.K, k = rem - ci * a.K;
+            const int tyy = r >> 1, i = r & 1;
+            int co;
+            if (gate) {
+                const int c = blockIdx.y * 16 + tyy;
+                co = (c < a.H) ? c + i * a.H : -1;
+            } else {
+                co = blockIdx.y * G_CO + r;
+                if (co >= a.Cout) co = -1;
+            }
+            float v = 0.0f;
+            if (co >= 0 && c0 + ci < a.Cin) v = a.w[((long)co * a.Cin + c0 + ci) * a.K + k];
+            ws[idx] = v;
+        }
+        __syncthreads();
+        for (int ci = 0; ci < G_CI; ++ci) {
+            for (int k = 0; k < a.K; ++k) {
+                const float w0 = ws[((2 * ty + 0) * G_CI + ci) * a.K + k];
+                const float w1 = ws[((2 * ty + 1) * G_CI + ci) * a.K + k];
+                const float* xp = xs + ci * LD + tx * 4 + k * a.dil;
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = xp[j];
+                    acc[0][j] = fmaf(w0, xv, acc[0][j]);
+                    acc[1][j] = fmaf(w1, xv, acc[1][j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < 4; ++j) {
+        const int t = t0 + tx * 4 + j;
+        if (t >= a.T) continue;
+        if (gate) {
+            if (co_i[0] >= 0) epi_gate(a, b, co_i[0], t, acc[0][j], acc[1][j]);
+        } else {
+            for (int i = 0; i < 2; ++i) {
+                if (co_i[i] < 0) continue;
+                if (a.epi == EPI_RESSKIP) epi_resskip(a, b, co_i[i], t, acc[i][j], out_len);
+                else epi_std(a, b, co_i[i], t, acc[i][j], out_len);
+            }
+        }
+    }
+}
+
+void launch_conv1d_generic(const ConvArgs& a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    const int LD = G_T + (a.K - 1) * a.dil;
+    const size_t shmem = sizeof(float) * ((size_t)G_CI * LD + (size_t)G_CO * G_CI * a.K);
+    const int ny = (a.epi == EPI_GATE) ? (a.H + 15) / 16 : (a.Cout + G_CO - 1) / G_CO;
+    dim3 grid((a.T + G_T - 1) / G_T, ny, a.B);
+    LAUNCH_KERNEL(k_conv1d_generic, grid, dim3(256), shmem, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32-MFMA implicit-GEMM kernel
+// ------------------------------------------------------------------------------------------------
+// Packed A operand: [n_tiles][K][Cin/2][64]; lane l of (tile, k, cp) holds W[row(tile, l&31)][2cp + (l>>5)][k]
+// — exactly the v_mfma_f32_32x32x2_f32 A fragment (A[i = l&31][k = l>>5]).
+// Tile -> output-channel map: STD/RESSKIP: co = 32*tile + r.  GATE: tiles come in pairs (2m, 2m+1) =
+// rows {c, H + c}, c = 32m + r, so one wave holds both gate operands of a channel in the same lane.
+static inline int tile_row_to_co(int epi, int tile, int r, int Cout, int H) {
+    if (epi == EPI_GATE) {
+        const int c = 32 * (tile >> 1) + r;
+        return c < H ? (tile & 1) * H + c : -1;
+    }
+    const int co = 32 * tile + r;
+    return co < Cout ? co : -1;
+}
+static inline int n_tiles_for(int epi, int Cout, int H) {
+    return epi == EPI_GATE ? 2 * ((H + 31) / 32) : (Cout + 31) / 32;
+}
+
+size_t mfma_packed_floats(int Cout, int Cin, int K) {
+    // GATE packing has the same tile count when H % 32 == 0; take the larger bound to be safe
+    const int nt_std = (Cout + 31) / 32;
+    const int nt_gate = 2 * ((Cout / 2 + 31) / 32);
+    const int nt = nt_std > nt_gate ? nt_std : nt_gate;
+    return (size_t)nt * K * (Cin / 2) * 64;
+}
+
+// epi selects the tile->channel map; for GATE, H = Cout / 2.
+void pack_conv_weights_mfma_mode(const float* w, int Cout, int Cin, int K, int epi, float* out) {
+    const int H = Cout / 2;
+    const int nt = n_tiles_for(epi, Cout, H);
+    const int cp_n = Cin / 2;
+    for (int tile = 0; tile < nt; ++tile)
+        for (int k = 0; k < K; ++k)
+            for (int cp = 0; cp < cp_n; ++cp)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = tile_row_to_co(epi, tile, l & 31, Cout, H);
+                    const int ci = 2 * cp + (l >> 5);
+                    out[(((size_t)tile * K + k) * cp_n + cp) * 64 + l] = co >= 0 ? w[((size_t)co * Cin + ci) * K + k] : 0.0f;
+                }
+}
+void pack_conv_weights_mfma(const float* w, int Cout, int Cin, int K, float* out) {
+    pack_conv_weights_mfma_mode(w, Cout, Cin, K, EPI_STD, out);
+}
+
+bool conv1d_mfma_supported(int Cin, int Cout, int K, int dil) {
+    (void)Cout; (void)K; (void)dil;
+    return Cin >= 2 && (Cin % 2) == 0;
+}
+
+template <int MT, int NT, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
+    DYN_SMEM(float, xs);  // [CI_C][LD]
+    constexpr int T_B = 32 * NT * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * T_B;
+    const int LD = T_B + (a.K - 1) * a.dil;
+    const int n_tiles = (EPI == EPI_GATE) ? 2 * ((a.H + 31) / 32) : (a.Cout + 31) / 32;
+    const int tile0 = (blockIdx.y * WM + wm) * MT;
+    const int cpairs = a.Cin >> 1;
+    const int in_len = a.in_len ? a.in_len[b] : a.T;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+    const float* xb = a.x + (long)b * a.x_bs;
+
+    f32x16 acc[MT][NT];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int brow = lane >> 5, bcol = lane & 31;
+    for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
+        // ---- stage x[c0:c0+CI_C, t0-pad : t0-pad+LD) with mask + leaky-relu fused (coalesced rows)
+        for (int ci = wid; ci < CI_C; ci += 4) {
+            const float* row = xb + (long)(c0 + ci) * a.x_ld;
+            float* dst = xs + ci * LD;
+            for (int tt = lane; tt < LD; tt += 64) {
+                const int t = t0 - a.pad + tt;
+                float v = 0.0f;
+                if (t >= 0 && t < a.T && t < in_len) {
+                    v = row[t];
+                    v = v >= 0.0f ? v : v * a.in_slope;
+                }
+                dst[tt] = v;
+            }
+        }
+        __syncthreads();
+        const int cp0 = c0 >> 1;
+        for (int k = 0; k < a.K; ++k) {
+            const float* xk = xs + brow * LD + k * a.dil + bcol + wn * NT * 32;
+            for (int cp = 0; cp < (CI_C >> 1); ++cp) {
+                float af[MT], bf[NT];
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) {
+                    const int tile = tile0 + i;
+                    af[i] = (tile < n_tiles) ? a.w[(((long)tile * a.K + k) * cpairs + cp0 + cp) * 64 + lane] : 0.0f;
+                }
+                const float* xr = xk + (2 * cp) * LD;
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) bf[j] = xr[j * 32];
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i)
+                    MI355_UNROLL
+                    for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j) {
+        const int t = t0 + (wn * NT + j) * 32 + bcol;
+        if (t >= a.T) continue;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * brow;
+            if (EPI == EPI_GATE) {
+                const int c = 32 * (tile0 >> 1) + row;
+                if (tile0 + 1 < n_tiles && c < a.H) epi_gate(a, b, c, t, acc[0][j][r], acc[MT - 1][j][r]);
+            } else {
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) {
+                    const int co = 32 * (tile0 + i) + row;
+                    if (co >= a.Cout) continue;
+                    if (EPI == EPI_RESSKIP) epi_resskip(a, b, co, t, acc[i][j][r], out_len);
+                    else epi_std(a, b, co, t, acc[i][j][r], out_len);
+                }
+            }
+        }
+    }
+}
+
+namespace {
+
+struct TileCfg { int MT, NT, WM, WN; };
+
+template <int MT, int NT, int WM, int WN, int EPI>
+void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
+    constexpr int T_B = 32 * NT * WN;
+    const int LD = T_B + (a.K - 1) * a.dil;
+    // C_in chunk: even divisor of Cin keeping the staged tile <= 48 KiB
+    int ci_c = a.Cin;
+    auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= 48 * 1024; };
+    if (!fits(ci_c)) {
+        ci_c = 0;
+        for (int c = 64; c >= 2; c -= 2)
+            if (a.Cin % c == 0 && fits(c)) { ci_c = c; break; }
+        if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
+    }
+    const size_t shmem = (size_t)ci_c * LD * sizeof(float);
+    dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
+    auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI>;
+    LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a, ci_c);
+}
+
+}  // namespace
+
+void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
+    const int n_tiles = n_tiles_for(a.epi, a.Cout, a.H);
+    // Tile choice: the largest workgroup tile that still leaves >= ~2 workgroups per CU, else smaller.
+    auto blocks = [&](int MT, int NT, int WM, int WN) {
+        const long tb = 32L * NT * WN;
+        return ((a.T + tb - 1) / tb) * ((n_tiles + MT * WM - 1) / (MT * WM)) * (long)a.B;
+    };
+    const long want = 512;
+    if (a.epi == EPI_GATE) {
+        if (blocks(2, 2, 2, 2) >= want) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, n_tiles, s);
+        else launch_cfg<2, 1, 2, 2, EPI_GATE>(a, n_tiles, s);
+        return;
+    }
+    if (a.epi == EPI_RESSKIP) {
+        if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        else if (n_tiles >= 2 && blocks(1, 2, 2, 2) >= want) launch_cfg<1, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        else launch_cfg<1, 1, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        return;
+    }
+    if (n_tiles == 1) {
+        if (blocks(1, 2, 1, 4) >= want) launch_cfg<1, 2, 1, 4, EPI_STD>(a, n_tiles, s);
+        else launch_cfg<1, 1, 1, 4, EPI_STD>(a, n_tiles, s);
+    } else if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) {
+        launch_cfg<2, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+    } else if (blocks(1, 2, 2, 2) >= want) {
+        launch_cfg<1, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+    } else {
+        launch_cfg<1, 1, 2, 2, EPI_STD>(a, n_tiles, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose1d: y[co,n] = b[co] + sum_ci sum_{k = r, r+s, ... < K} x[ci,(n+p-k)/s] * W[ci,co,k],
+// r = (n + p) mod s.  With K = 2s each output sees exactly two taps (polyphase); no scatter, no atomics.
+// ------------------------------------------------------------------------------------------------
+constexpr int CT_N = 64, CT_CO = 32, CT_CI = 16;
+
+__global__ __launch_bounds__(256) void k_conv_transpose1d(ConvTArgs a) {
+    DYN_SMEM(float, smem);
+    const int tid = threadIdx.x;
+    const int nl = tid & 63, cg = tid >> 6;  // 64 output samples x 4 groups of 8 channels
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * CT_N;
+    const int co0 = blockIdx.y * CT_CO;
+    const int Tout = a.Tin * a.stride;
+    // input positions touched by this tile: i in [i_lo, i_hi]
+    const int taps = (a.K + a.stride - 1) / a.stride;
+    const int i_hi = (n0 + CT_N - 1 + a.pad) / a.stride;
+    const int i_lo = (n0 + a.pad) / a.stride - (taps - 1);
+    const int NI = i_hi - i_lo + 1;
+    float* xs = smem;                 // [CT_CI][NI]
+    float* ws = smem + CT_CI * NI;    // [CT_CI][CT_CO][K]
+    const int n = n0 + nl;
+    const int r = (n + a.pad) % a.stride;
+    const int ibase = (n + a.pad) / a.stride;  // tap m uses input ibase - m with k = r + m*stride
+    const int in_len = a.in_len ? a.in_len[b] : a.Tin;
+    float acc[8];
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
+    for (int c0 = 0; c0 < a.Cin; c0 += CT_CI) {
+        for (int idx = tid; idx < CT_CI * NI; idx += 256) {
+            const int ci = idx / NI, ii = idx - ci * NI;
+            const int c = c0 + ci, i = i_lo + ii;
+            float v = 0.0f;
+            if (c < a.Cin && i >= 0 && i < a.Tin && i < in_len) {
+                v = a.x[(long)b * a.x_bs + (long)c * a.x_ld + i];
+                v = v >= 0.0f ? v : v * a.in_slope;
+            }
+            xs[idx] = v;
+        }
+        for (int idx = tid; idx < CT_CI * CT_CO * a.K; idx += 256) {
+            const int ci = idx / (CT_CO * a.K);
+            const int rem = idx - ci * (CT_CO * a.K);
+            const int co = rem / a.K, k = rem - co * a.K;
+            float v = 0.0f;
+            if (c0 + ci < a.Cin && co0 + co < a.Cout) v = a.w[((long)(c0 + ci) * a.Cout + co0 + co) * a.K + k];
+            ws[idx] = v;
+        }
+        __syncthreads();
+        for (int ci = 0; ci < CT_CI; ++ci) {
+            for (int m = 0; m < taps; ++m) {
+                const int k = r + m * a.stride;
+                if (k >= a.K) break;
+                const float xv = xs[ci * NI + (ibase - m - i_lo)];
+                const float* wp = ws + (ci * CT_CO + cg * 8) * a.K + k;
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(xv, wp[q * a.K], acc[q]);
+            }
+        }
+        __syncthreads();
+    }
+    if (n < Tout) {
+        for (int q = 0; q < 8; ++q) {
+            const int co = co0 + cg * 8 + q;
+            if (co < a.Cout) a.y[(long)b * a.y_bs + (long)co * a.y_ld + n] = acc[q] + (a.bias ? a.bias[co] : 0.0f);
+        }
+    }
+}
+
+void launch_conv_transpose1d(const ConvTArgs& a, hipStream_t s) {
+    if (a.Tin <= 0 || a.B <= 0) return;
+    const int Tout = a.Tin * a.stride;
+    const int taps = (a.K + a.stride - 1) / a.stride;
+    const int NI = CT_N / a.stride + taps + 2;  // upper bound of i_hi - i_lo + 1
+    const size_t shmem = sizeof(float) * ((size_t)CT_CI * NI + (size_t)CT_CI * CT_CO * a.K);
+    dim3 grid((Tout + CT_N - 1) / CT_N, (a.Cout + CT_CO - 1) / CT_CO, a.B);
+    LAUNCH_KERNEL(k_conv_transpose1d, grid, dim3(256), shmem, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_post (C_out = 1, no bias) + leaky-relu(0.01) on the input + tanh + per-utterance peak  (K12 + A2)
+// HBM-bound: reads the [C_in, L] activation once (3.4 FLOP/B), writes L floats.
+// ------------------------------------------------------------------------------------------------
+constexpr int CP_T = 1024;  // samples per workgroup (4 per thread)
+
+__global__ __launch_bounds__(256) void k_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, int Cin,
+                                                        int K, int L, const int* valid_len, float* audio,
+                                                        long audio_bs, unsigned* peak_bits) {
+    DYN_SMEM(float, smem);
+    const int halo = K - 1, pad = (K - 1) / 2;
+    const int LD = CP_T + halo;
+    constexpr int CIC = 8;
+    float* xs = smem;             // [CIC][LD]
+    float* ws = smem + CIC * LD;  // [Cin*K]
+    float* red = ws + Cin * K;    // [4]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * CP_T;
+    for (int i = tid; i < Cin * K; i += 256) ws[i] = w[i];
+    const int vl = valid_len ? valid_len[b] : L;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c0 = 0; c0 < Cin; c0 += CIC) {
+        __syncthreads();
+        for (int ci = wid; ci < CIC; ci += 4) {
+            const int c = c0 + ci;
+            const float* row = x + (long)b * x_bs + (long)c * x_ld;
+            for (int tt = lane; tt < LD; tt += 64) {
+                const int t = t0 - pad + tt;
+                float v = 0.0f;
+                if (c < Cin && t >= 0 && t < L && t < vl) {
+                    v = row[t];
+                    v = v >= 0.0f ? v : v * 0.01f;
+                }
+                xs[ci * LD + tt] = v;
+            }
+        }
+        __syncthreads();
+        for (int ci = 0; ci < CIC && c0 + ci < Cin; ++ci) {
+            for (int k = 0; k < K; ++k) {
+                const float wv = ws[(c0 + ci) * K + k];
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(wv, xs[ci * LD + tid + q * 256 + k], acc[q]);
+            }
+        }
+    }
+    float pk = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+        const int t = t0 + tid + q * 256;
+        if (t < L) {
+            const float y = tanhf(acc[q]);
+            audio[(long)b * audio_bs + t] = y;
+            if (t < vl) pk = fmaxf(pk, fabsf(y));
+        }
+    }
+    pk = wave_reduce_max(pk);
+    if (lane == 0) red[wid] = pk;
+    __syncthreads();
+    if (tid == 0) {
+        pk = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(peak_bits + b, __float_as_uint(pk));  // non-negative floats order like their bit patterns
+    }
+}
+
+void launch_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, int Cin, int K, int B, int L,
+                           const int* valid_len, float* audio, long audio_bs, unsigned* peak_bits, hipStream_t s) {
+    if (L <= 0 || B <= 0) return;
+    const size_t shmem = sizeof(float) * ((size_t)8 * (CP_T + K - 1) + (size_t)Cin * K + 4);
+    dim3 grid((L + CP_T - 1) / CP_T, B);
+    LAUNCH_KERNEL(k_conv_post_tanh, grid, dim3(256), shmem, s, x, x_bs, x_ld, w, Cin, K, L, valid_len, audio, audio_bs,
+                  peak_bits);
+}
+
+// audio_float_to_int16 (mimic3_tts/utils.py:237-244) per utterance: scale = 32767 / max(0.01, peak),
+// clip to +-32767, truncate toward zero.  Rows are zero beyond their valid length.
+__global__ __launch_bounds__(256) void k_pcm16(const float* audio, long audio_bs, const unsigned* peak_bits,
+                                               const int* valid_len, int L, int16_t* pcm, long pcm_bs) {
+    const int b = blockIdx.y;
+    const float peak = fmaxf(0.01f, __uint_as_float(peak_bits[b]));
+    const float scale = 32767.0f / peak;
+    const int vl = valid_len ? valid_len[b] : L;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < L; t += gridDim.x * 256) {
+        float v = 0.0f;
+        if (t < vl) {
+            v = audio[(long)b * audio_bs + t] * scale;
+            v = fminf(fmaxf(v, -32767.0f), 32767.0f);
+        }
+        pcm[(long)b * pcm_bs + t] = (int16_t)(int)v;
+    }
+}
+
+void launch_pcm16(const float* audio, long audio_bs, const unsigned* peak_bits, const int* valid_len, int B, int L,
+                  int16_t* pcm, long pcm_bs, hipStream_t s) {
+    if (L <= 0 || B <= 0) return;
+    int gx = (L + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    LAUNCH_KERNEL(k_pcm16, dim3(gx, B), dim3(256), 0, s, audio, audio_bs, peak_bits, valid_len, L, pcm, pcm_bs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA fragment-layout self test (asymmetric operands; cdna guide §3 "always A=I-check with asymmetric B")
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_mfma_selftest(float* out) {
+    const int lane = threadIdx.x & 63;
+    // 32x32x2: C[i][j] = sum_k A[i][k] * B[k][j], A[i][k] = i + 100k + 1, B[k][j] = 3j - 7k + 2
+    {
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+        const float av = (float)((lane & 31) + 100 * (lane >> 5) + 1);
+        const float bv = (float)(3 * (lane & 31) - 7 * (lane >> 5) + 2);
+        c = MFMA_32x32x2_F32(av, bv, c);
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[row * 32 + (lane & 31)] = c[r];
+        }
+    }
+    // 16x16x4
+    {
+        f32x4 c;
+        for (int r = 0; r < 4; ++r) c[r] = 0.0f;
+        const float av = (float)((lane & 15) + 100 * (lane >> 4) + 1);
+        const float bv = (float)(3 * (lane & 15) - 7 * (lane >> 4) + 2);
+        c = MFMA_16x16x4_F32(av, bv, c);
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            out[1024 + row * 16 + (lane & 15)] = c[r];
+        }
+    }
+}
+void launch_mfma_selftest(float* out, hipStream_t s) { LAUNCH_KERNEL(k_mfma_selftest, dim3(1), dim3(64), 0, s, out); }
+
+__global__ __launch_bounds__(256) void k_fill(float* p, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+void launch_fill(float* p, float v, size_t n, hipStream_t s) {
+    if (!n) return;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    LAUNCH_KERNEL(k_fill, dim3((unsigned)g), dim3(256), 0, s, p, v, n);
+}
+
+}  // namespace m355

@@ -1,0 +1,459 @@
+// kernels_misc.cpp — the small kernels of the path: embedding, channel LayerNorm, relative-position
+// attention, the duration predictor's depthwise/spline pieces, length regulator + prior sampling,
+// speaker conditioning.  All HBM/latency-bound; one pass over their tensors, pointwise work fused.
+#include "kernels.h"
+
+namespace m355 {
+
+// ------------------------------------------------------------------------------------------------
+// counter-based Gaussian noise: Philox4x32-10 keyed by the seed, counter =
+// (time index, channel, global utterance index, tensor id) -> the draw for an element depends neither on
+// padding, batch composition nor on which GPU the utterance landed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned long long utt, unsigned tensor,
+                                               unsigned c, unsigned t) {
+    unsigned r[4];
+    philox4x32_10(t, c, (unsigned)utt, tensor ^ (unsigned)(utt >> 32) * 0x9E3779B9u, (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+    const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: x[b,c,t] = Emb[ids[b,t]][c] * sqrt(H) * mask
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed(const long long* ids, const int* len, const float* emb, int T, int H,
+                                               int num_symbols, float scale, float* y) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cg = threadIdx.x >> 6;
+    if (t >= T) return;
+    const bool valid = t < len[b];
+    long long id = ids[(long)b * T + t];
+    if (id < 0 || id >= num_symbols) id = 0;  // host validates; belt and braces
+    for (int c = cg; c < H; c += 4) y[((long)b * H + c) * T + t] = valid ? emb[id * H + c] * scale : 0.0f;
+}
+void launch_embed(const long long* ids, const int* len, const float* emb, int B, int T, int H, int num_symbols,
+                  float scale, float* y, hipStream_t s) {
+    LAUNCH_KERNEL(k_embed, dim3((T + 63) / 64, B), dim3(256), 0, s, ids, len, emb, T, H, num_symbols, scale, y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// channel LayerNorm (A.3) over [B,C,T], optional residual input, GELU, additive output, mask.
+// Workgroup = 64 time columns x 4 channel groups; every thread owns one column slice, so all global
+// accesses are coalesced along time; three cached sweeps (mean, biased variance, write).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float block4_sum(float v, float* red, int tl, int cg) {
+    __syncthreads();
+    red[cg * 64 + tl] = v;
+    __syncthreads();
+    return red[tl] + red[64 + tl] + red[128 + tl] + red[192 + tl];
+}
+
+__global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
+    DYN_SMEM(float, red);
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const bool live = t < a.T;
+    const long base = (long)b * a.C * a.T + (live ? t : 0);
+    float sum = 0.0f;
+    if (live)
+        for (int c = cg; c < a.C; c += 4) {
+            float v = a.x[base + (long)c * a.T];
+            if (a.res) v += a.res[base + (long)c * a.T];
+            sum += v;
+        }
+    const float mean = block4_sum(sum, red, tl, cg) / (float)a.C;
+    float sq = 0.0f;
+    if (live)
+        for (int c = cg; c < a.C; c += 4) {
+            float v = a.x[base + (long)c * a.T];
+            if (a.res) v += a.res[base + (long)c * a.T];
+            v -= mean;
+            sq += v * v;
+        }
+    const float var = block4_sum(sq, red, tl, cg) / (float)a.C;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    __syncthreads();  // in-place use: all reads of x above are done before anyone writes y
+    if (!live) return;
+    const bool masked = a.out_len && t >= a.out_len[b];
+    for (int c = cg; c < a.C; c += 4) {
+        float v = a.x[base + (long)c * a.T];
+        if (a.res) v += a.res[base + (long)c * a.T];
+        v = (v - mean) * rstd * a.gamma[c] + a.beta[c];
+        if (a.gelu) v = gelu_erf(v);
+        if (a.add_to) v += a.add_to[base + (long)c * a.T];
+        if (masked) v = 0.0f;
+        a.y[base + (long)c * a.T] = v;
+    }
+}
+void launch_layernorm(const LNArgs& a, hipStream_t s) {
+    if (a.T <= 0) return;
+    LAUNCH_KERNEL(k_layernorm, dim3((a.T + 63) / 64, a.B), dim3(256), 256 * sizeof(float), s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// first half of a DDS layer (A.6): y = gelu(LN_c(depthwise_conv_{K,dil}(x * mask)))
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dwconv_at(const float* xrow, const float* w, float bias, int t, int T, int len, int K,
+                                           int dil) {
+    float acc = bias;
+    const int pad = (K * dil - dil) / 2;
+    for (int k = 0; k < K; ++k) {
+        const int tt = t - pad + k * dil;
+        if (tt >= 0 && tt < T && tt < len) acc = fmaf(w[k], xrow[tt], acc);
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void k_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias,
+                                                            const float* gamma, const float* beta, const int* len,
+                                                            int C, int T, int K, int dil, float* y) {
+    DYN_SMEM(float, red);
+    const int b = blockIdx.y;
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const bool live = t < T;
+    const int L = len[b];
+    const float* xb = x + (long)b * C * T;
+    float sum = 0.0f;
+    if (live)
+        for (int c = cg; c < C; c += 4) sum += dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil);
+    const float mean = block4_sum(sum, red, tl, cg) / (float)C;
+    float sq = 0.0f;
+    if (live)
+        for (int c = cg; c < C; c += 4) {
+            const float v = dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil) - mean;
+            sq += v * v;
+        }
+    const float var = block4_sum(sq, red, tl, cg) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (!live) return;
+    for (int c = cg; c < C; c += 4) {
+        float v = dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil);
+        v = (v - mean) * rstd * gamma[c] + beta[c];
+        y[((long)b * C + c) * T + t] = gelu_erf(v);
+    }
+}
+void launch_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias, const float* gamma,
+                               const float* beta, const int* len, int B, int C, int T, int K, int dil, float* y,
+                               hipStream_t s) {
+    LAUNCH_KERNEL(k_dds_dwconv_ln_gelu, dim3((T + 63) / 64, B), dim3(256), 256 * sizeof(float), s, x, w, bias, gamma,
+                  beta, len, C, T, K, dil, y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// relative-position multi-head attention (A.4).  One wave per query row; scores and probabilities of the
+// row live in LDS; window terms E_k / E_v enter as 2W+1 extra logits / values.
+//   s[i,j] = (q_i/sqrt(d)) . k_j + [|j-i|<=W] (q_i/sqrt(d)) . E_k[j-i+W];  masked -> -1e4;  softmax_j
+//   o_i    = sum_j p[i,j] v_j + sum_{|j-i|<=W} p[i,j] E_v[j-i+W]
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_ROWS = 16;  // query rows per workgroup (4 per wave)
+
+__global__ __launch_bounds__(256) void k_rel_attention(const float* qkv, const float* ek, const float* ev,
+                                                       const int* len, int T, int H, int nh, int W, float* out) {
+    DYN_SMEM(float, smem);
+    const int d = H / nh;
+    const int nrel = 2 * W + 1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int per_wave = d + T + nrel;
+    float* qs = smem + wid * per_wave;  // [d]
+    float* p = qs + d;                  // [T]
+    float* rl = p + T;                  // [2W+1]
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int L = len[b];
+    const float scale = 1.0f / sqrtf((float)d);
+    const float* qb = qkv + ((long)b * 3 * H + h * d) * T;
+    const float* kb = qb + (long)H * T;
+    const float* vb = qb + (long)2 * H * T;
+    for (int n = 0; n < ATT_ROWS / 4; ++n) {
+        const int i_raw = blockIdx.x * ATT_ROWS + n * 4 + wid;
+        const bool row_live = i_raw < T;
+        const int i = row_live ? i_raw : T - 1;
+        for (int c = lane; c < d; c += 64) qs[c] = qb[(long)c * T + i] * scale;
+        __syncthreads();
+        for (int r = 0; r < nrel; ++r) {
+            float part = 0.0f;
+            for (int c = lane; c < d; c += 64) part = fmaf(qs[c], ek[r * d + c], part);
+            part = wave_reduce_sum(part);
+            if (lane == 0) rl[r] = part;
+        }
+        __syncthreads();
+        float mx = -3.0e38f;
+        for (int j0 = 0; j0 < T; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < T) {
+                float sc = 0.0f;
+                for (int c = 0; c < d; ++c) sc = fmaf(qs[c], kb[(long)c * T + j], sc);
+                const int rel = j - i;
+                if (rel >= -W && rel <= W) sc += rl[rel + W];
+                if (j >= L || i >= L) sc = -1e4f;
+                p[j] = sc;
+                mx = fmaxf(mx, sc);
+            }
+        }
+        mx = wave_reduce_max(mx);
+        float sum = 0.0f;
+        for (int j0 = 0; j0 < T; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < T) {
+                const float e = expf(p[j] - mx);
+                p[j] = e;
+                sum += e;
+            }
+        }
+        sum = wave_reduce_sum(sum);
+        __syncthreads();
+        const float inv = 1.0f / sum;
+        for (int c = lane; c < d; c += 64) {
+            const float* vr = vb + (long)c * T;
+            float o = 0.0f;
+            for (int j = 0; j < T; ++j) o = fmaf(p[j], vr[j], o);
+            for (int r = 0; r < nrel; ++r) {
+                const int j = i + r - W;
+                if (j >= 0 && j < T) o = fmaf(p[j], ev[r * d + c], o);
+            }
+            if (row_live) out[((long)b * H + h * d + c) * T + i] = o * inv;
+        }
+        __syncthreads();
+    }
+}
+void launch_rel_attention(const float* qkv, const float* emb_rel_k, const float* emb_rel_v, const int* len, int B,
+                          int T, int H, int n_heads, int window, float* out, hipStream_t s) {
+    const int d = H / n_heads;
+    const size_t shmem = sizeof(float) * 4 * (size_t)(d + T + 2 * window + 1);
+    if (shmem > 64 * 1024) throw std::runtime_error("rel_attention: phoneme sequence too long for the LDS row buffer");
+    LAUNCH_KERNEL(k_rel_attention, dim3((T + ATT_ROWS - 1) / ATT_ROWS, n_heads, B), dim3(256), shmem, s, qkv, emb_rel_k,
+                  emb_rel_v, len, T, H, n_heads, window, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stochastic duration predictor pieces (A.7)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_convflow_pre(const float* z, int ch, const float* w, const float* bias,
+                                                      const float* g, int C, int T, float* h) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cg = threadIdx.x >> 6;
+    if (t >= T) return;
+    const float zv = z[((long)b * 2 + ch) * T + t];
+    for (int c = cg; c < C; c += 4) {
+        const long o = ((long)b * C + c) * T + t;
+        h[o] = fmaf(w[c], zv, bias[c]) + g[o];
+    }
+}
+void launch_convflow_pre(const float* z, int ch, const float* w, const float* bias, const float* g, int B, int C,
+                         int T, float* h, hipStream_t s) {
+    LAUNCH_KERNEL(k_convflow_pre, dim3((T + 63) / 64, B), dim3(256), 0, s, z, ch, w, bias, g, C, T, h);
+}
+
+constexpr int NB_MAX = 16;
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// One thread per (b,t): rational-quadratic spline inverse with linear tails (HF modeling_vits.py:93-302).
+__global__ __launch_bounds__(64) void k_spline_inverse(float* z, int ch_x0, const float* theta, const int* len, int T,
+                                                       int nb, float tb, float inv_sqrt_fc) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= T) return;
+    const int ch_x1 = 1 - ch_x0;
+    float* z0 = z + ((long)b * 2 + ch_x0) * T + t;
+    float* z1 = z + ((long)b * 2 + ch_x1) * T + t;
+    const bool valid = t < len[b];
+    const float x1 = *z1;
+    float outv = x1;
+    if (x1 >= -tb && x1 <= tb) {
+        const float* th = theta + (long)b * (3 * nb - 1) * T + t;
+        const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+        float cw[NB_MAX + 1], chh[NB_MAX + 1], dv[NB_MAX + 1];
+        // widths
+        {
+            float u[NB_MAX], mx = -3.0e38f, sum = 0.0f;
+            for (int i = 0; i < nb; ++i) { u[i] = th[(long)i * T] * inv_sqrt_fc; mx = fmaxf(mx, u[i]); }
+            for (int i = 0; i < nb; ++i) { u[i] = expf(u[i] - mx); sum += u[i]; }
+            float cum = 0.0f;
+            cw[0] = -tb;
+            for (int i = 0; i < nb; ++i) {
+                cum += min_w + (1.0f - min_w * nb) * (u[i] / sum);
+                cw[i + 1] = 2.0f * tb * cum - tb;
+            }
+            cw[nb] = tb;
+        }
+        // heights
+        {
+            float u[NB_MAX], mx = -3.0e38f, sum = 0.0f;
+            for (int i = 0; i < nb; ++i) { u[i] = th[(long)(nb + i) * T] * inv_sqrt_fc; mx = fmaxf(mx, u[i]); }
+            for (int i = 0; i < nb; ++i) { u[i] = expf(u[i] - mx); sum += u[i]; }
+            float cum = 0.0f;
+            chh[0] = -tb;
+            for (int i = 0; i < nb; ++i) {
+                cum += min_h + (1.0f - min_h * nb) * (u[i] / sum);
+                chh[i + 1] = 2.0f * tb * cum - tb;
+            }
+            chh[nb] = tb;
+        }
+        // derivatives: interior from theta, both ends = min_d + softplus(log(exp(1 - min_d) - 1))
+        {
+            const float cst = logf(expf(1.0f - min_d) - 1.0f);
+            dv[0] = min_d + softplus_f(cst);
+            dv[nb] = dv[0];
+            for (int i = 1; i < nb; ++i) dv[i] = min_d + softplus_f(th[(long)(2 * nb + i - 1) * T]);
+        }
+        int bin = -1;
+        for (int i = 0; i <= nb; ++i) {
+            const float loc = (i == nb) ? chh[i] + 1e-6f : chh[i];
+            bin += (x1 >= loc) ? 1 : 0;
+        }
+        bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
+        const float in_cw = cw[bin], in_w = cw[bin + 1] - cw[bin];
+        const float in_ch = chh[bin], in_h = chh[bin + 1] - chh[bin];
+        const float delta = in_h / in_w;
+        const float d0 = dv[bin], d1 = dv[bin + 1];
+        const float t1 = d0 + d1 - 2.0f * delta;
+        const float u = x1 - in_ch;
+        const float t3 = u * t1;
+        const float qa = in_h * (delta - d0) + t3;
+        const float qb = in_h * d0 - t3;
+        const float qc = -delta * u;
+        const float disc = qb * qb - 4.0f * qa * qc;
+        const float root = (2.0f * qc) / (-qb - sqrtf(disc));
+        outv = root * in_w + in_cw;
+    }
+    *z1 = valid ? outv : 0.0f;
+    if (!valid) *z0 = 0.0f;
+}
+void launch_spline_inverse(float* z, int ch_x0, const float* theta, const int* len, int B, int T, int nbins,
+                           float tail, float inv_sqrt_fc, hipStream_t s) {
+    if (nbins > NB_MAX) throw std::runtime_error("spline: too many bins");
+    LAUNCH_KERNEL(k_spline_inverse, dim3((T + 63) / 64, B), dim3(64), 0, s, z, ch_x0, theta, len, T, nbins, tail,
+                  inv_sqrt_fc);
+}
+
+__global__ __launch_bounds__(64) void k_sdp_noise(float* z, const float* injected, int T, float noise_w,
+                                                  unsigned long long seed, unsigned long long utt_base) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= T) return;
+    for (int c = 0; c < 2; ++c) {
+        const long o = ((long)b * 2 + c) * T + t;
+        float n = 0.0f;
+        if (noise_w != 0.0f) n = injected ? injected[o] : philox_normal(seed, utt_base + b, 0u, (unsigned)c, (unsigned)t);
+        z[o] = n * noise_w;
+    }
+}
+void launch_sdp_noise(float* z, const float* injected, int B, int T, float noise_w, unsigned long long seed,
+                      unsigned long long utt_base, hipStream_t s) {
+    LAUNCH_KERNEL(k_sdp_noise, dim3((T + 63) / 64, B), dim3(64), 0, s, z, injected, T, noise_w, seed, utt_base);
+}
+
+// EA^-1 (HF:703) on the logical channel 0, then K6: w = ceil(exp(logw) * mask * length_scale), inclusive scan.
+__global__ __launch_bounds__(256) void k_durations(const float* z, int ch, float ea_m, float ea_logs, const int* len,
+                                                   const int* forced, int T, float length_scale, float* logw,
+                                                   int* w_ceil, int* cum, int* ylen) {
+    const int b = blockIdx.x;
+    const int L = len[b];
+    const float es = expf(-ea_logs);
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float m = t < L ? 1.0f : 0.0f;
+        const float lw = (z[((long)b * 2 + ch) * T + t] - ea_m) * es * m;
+        logw[(long)b * T + t] = lw;
+        float w = expf(lw) * m * length_scale;
+        int wc = (int)ceilf(w);
+        if (forced) wc = t < L ? forced[(long)b * T + t] : 0;
+        w_ceil[(long)b * T + t] = wc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int t = 0; t < T; ++t) {
+            acc += w_ceil[(long)b * T + t];
+            cum[(long)b * T + t] = acc;
+        }
+        ylen[b] = acc < 1 ? 1 : acc;
+    }
+}
+void launch_durations(const float* z, int ch, float ea_m, float ea_logs, const int* len, const int* forced, int B,
+                      int T, float length_scale, float* logw, int* w_ceil, int* cum, int* ylen, hipStream_t s) {
+    LAUNCH_KERNEL(k_durations, dim3(B), dim3(256), 0, s, z, ch, ea_m, ea_logs, len, forced, T, length_scale, logw,
+                  w_ceil, cum, ylen);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 + K7: frame t takes phoneme j(t) = #{j : cum_j <= t} (binary search instead of the reference's dense
+// [Ty x Tx] path matmul);  z_p = m_p[j] + N(0,1) * exp(logs_p[j]) * noise_scale, zero beyond the row's length.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand_prior(const float* stats, const int* cum, const int* ylen,
+                                                      const float* injected, int injected_frames, int I, int Tx,
+                                                      int Ty, float noise_scale, unsigned long long seed,
+                                                      unsigned long long utt_base, float* z) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cg = threadIdx.x >> 6;
+    if (t >= Ty) return;
+    const int* cb = cum + (long)b * Tx;
+    int lo = 0, hi = Tx;  // first j with cum[j] > t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cb[mid] <= t) lo = mid + 1; else hi = mid;
+    }
+    const int j = lo;
+    const bool valid = t < ylen[b] && j < Tx;
+    for (int c = cg; c < I; c += 4) {
+        float v = 0.0f;
+        if (valid) {
+            const float m = stats[((long)b * 2 * I + c) * Tx + j];
+            v = m;
+            if (noise_scale != 0.0f) {
+                const float ls = stats[((long)b * 2 * I + I + c) * Tx + j];
+                const float n = injected ? injected[((long)b * I + c) * injected_frames + t]
+                                         : philox_normal(seed, utt_base + b, 1u, (unsigned)c, (unsigned)t);
+                v = m + n * expf(ls) * noise_scale;
+            }
+        }
+        z[((long)b * I + c) * Ty + t] = v;
+    }
+}
+void launch_expand_prior(const float* stats, const int* cum, const int* ylen, const float* injected,
+                         int injected_frames, int B, int I, int Tx, int Ty, float noise_scale, unsigned long long seed,
+                         unsigned long long utt_base, float* z, hipStream_t s) {
+    LAUNCH_KERNEL(k_expand_prior, dim3((Ty + 63) / 64, B), dim3(256), 0, s, stats, cum, ylen, injected, injected_frames,
+                  I, Tx, Ty, noise_scale, seed, utt_base, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A.11: per-utterance conditioning vectors  out[b,co] = W[co,:] . emb_g[sid[b],:] + bias[co]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_speaker_cond(const float* emb_g, const long long* sid, const float* w,
+                                                      const float* bias, int gin, int Cout, float* out) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int co_raw = blockIdx.x * 4 + wid;
+    const int co = co_raw < Cout ? co_raw : Cout - 1;
+    const float* g = emb_g + (long)sid[b] * gin;
+    float acc = 0.0f;
+    for (int i = lane; i < gin; i += 64) acc = fmaf(w[(long)co * gin + i], g[i], acc);
+    acc = wave_reduce_sum(acc);
+    if (lane == 0 && co_raw < Cout) out[(long)b * Cout + co] = acc + (bias ? bias[co] : 0.0f);
+}
+void launch_speaker_cond(const float* emb_g, const long long* sid, const float* w, const float* bias, int B, int gin,
+                         int Cout, float* out, hipStream_t s) {
+    LAUNCH_KERNEL(k_speaker_cond, dim3((Cout + 3) / 4, B), dim3(256), 0, s, emb_g, sid, w, bias, gin, Cout, out);
+}
+
+}  // namespace m355

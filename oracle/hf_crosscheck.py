@@ -186,7 +186,8 @@ def hf_resblock1_config(base: VitsConfig) -> VitsConfig:
 def compare(cfg: VitsConfig, seed: int, ids: np.ndarray, lengths: np.ndarray, sid=None, tag=""):
     weights = W.synthetic_weights(cfg, seed=seed, frames_per_id=3.0)
     oracle = VitsOracle(cfg, weights)
-    res = oracle.infer(ids, lengths, [0.0, 1.0, 0.0], sid=None if sid is None else np.full(len(lengths), sid))
+    res = oracle.infer(ids, lengths, [0.0, 1.0, 0.0], sid=None if sid is None else np.full(len(lengths), sid),
+                       batch_semantics="upstream")
     model = build_hf(cfg, weights)
     am = (np.arange(ids.shape[1])[None, :] < lengths[:, None]).astype(np.int64)
     with torch.no_grad():

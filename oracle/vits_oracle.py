@@ -325,6 +325,7 @@ class VitsOracle:
         noise_w: Optional[np.ndarray] = None,
         noise_z: Optional[np.ndarray] = None,
         forced_durations: Optional[np.ndarray] = None,
+        batch_semantics: str = "per_row",
     ) -> Dict[str, np.ndarray]:
         """Restates ``onnx_model.run(None, {"input","input_lengths","scales"[,"sid"]})``
         (feed built at ``voice.py:180-218``; scales = [noise_scale, length_scale, noise_w]).
@@ -333,6 +334,11 @@ class VitsOracle:
         (required when the corresponding scale is non-zero; the reference's RNG stream is
         onnxruntime-internal, so parity uses injected noise or zero scales).
         ``forced_durations`` int [B,Tx] overrides ceil(exp(logw)*length_scale) (bench mode F).
+        ``batch_semantics``: the reference only ever feeds B = 1 (``voice.py:180``).  Upstream's decoder is
+        unmasked, so in a padded batch the tail of a shorter row would see its neighbours' padding;
+        ``"per_row"`` (default) decodes every row over its own frames only, i.e. a batch equals B separate
+        B = 1 calls — the contract of the drop-in.  ``"upstream"`` keeps the unmasked batch
+        decode (used to cross-check against HF ``VitsModel``).
         Returns every intermediate the parity tests compare.
         """
         cfg = self.cfg
@@ -376,7 +382,23 @@ class VitsOracle:
             nz = torch.zeros_like(m_pe)
         z_p = m_pe + nz * torch.exp(logs_pe) * torch.tensor(ns, dtype=self.dtype)  # K7 (HF:1373)
         z = self.flow_reverse(z_p, y_mask, g)
-        audio, stages = self.decoder(z * y_mask, g, return_stages=True)  # [B,1,L]
+        zm = z * y_mask
+        if batch_semantics == "upstream" or B == 1:
+            audio, stages = self.decoder(zm, g, return_stages=True)  # [B,1,L]
+        elif batch_semantics == "per_row":
+            audio = torch.zeros(B, 1, Ty * cfg.upsample_factor, dtype=self.dtype)
+            stages = {}
+            for b in range(B):
+                nb = int(y_len[b])
+                ab, sb = self.decoder(zm[b:b + 1, :, :nb], None if g is None else g[b:b + 1], return_stages=True)
+                audio[b, :, : ab.shape[-1]] = ab[0]
+                for k, v in sb.items():
+                    if k not in stages:
+                        f = v.shape[-1] // nb
+                        stages[k] = torch.zeros(B, v.shape[1], Ty * f, dtype=self.dtype)
+                    stages[k][b, :, : v.shape[-1]] = v[0]
+        else:
+            raise ValueError(batch_semantics)
         out = {
             "x": x, "m_p": m_p, "logs_p": logs_p, "logw": logw, "w_ceil": w_ceil, "y_lengths": y_len,
             "z_p": z_p, "z": z * y_mask, "audio": audio,

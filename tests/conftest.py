@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """CPU model of the kernels (tests/emu): same sources as the product, compiled with g++ -DMI355_EMU.
+    Test infrastructure only — checks kernel/host logic without a GPU."""
+    from mimic3_amd import build
+    from mimic3_amd._native import NativeLibrary
+
+    return NativeLibrary(build.build_emu())
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product library on the real device; fails loudly if it is missing."""
+    from mimic3_amd._native import default_library
+
+    return default_library()

@@ -1,0 +1,182 @@
+"""Kernel + host logic of mimic3_amd/csrc checked on the CPU model (tests/emu) against the oracle.
+These are NOT the parity tests proper (those run on the MI355X: test_gpu_parity.py); they make sure the
+sources the GPU build compiles index, tile, synchronise and orchestrate correctly."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mimic3_amd import weights as W
+from mimic3_amd._native import Engine, NativeError
+from mimic3_amd.config import VitsConfig
+from tests.util import check_parity, rel_rms
+
+
+def test_mfma_fragment_layout_model(emu_lib):
+    assert emu_lib.test_mfma_layout() == 0.0
+
+
+CONV_CASES = [
+    # B, Cin, Cout, T, K, dil
+    (1, 2, 3, 5, 1, 1),
+    (2, 16, 32, 70, 3, 1),
+    (1, 32, 32, 300, 7, 12),
+    (1, 6, 70, 129, 5, 2),
+    (2, 64, 29, 33, 1, 1),
+    (1, 96, 96, 64, 5, 1),
+]
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d_kernels(emu_lib, impl, case):
+    B, Cin, Cout, T, K, dil = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, Cout, T)).astype(np.float32)
+    in_len = np.array([T] + [max(1, T - 3)] * (B - 1), np.int32)
+    out_len = in_len.copy()
+    y = emu_lib.test_conv1d(x, w, bias, res, dilation=dil, impl=impl, in_len=in_len, out_len=out_len, in_slope=0.1,
+                            out_scale=0.5)
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).float()[:, None, :]
+    xt = F.leaky_relu(torch.from_numpy(x) * tm, 0.1)
+    ref = F.conv1d(xt, torch.from_numpy(w), torch.from_numpy(bias), dilation=dil, padding=(K * dil - dil) // 2)
+    ref = ((ref + torch.from_numpy(res)) * 0.5 * tm).numpy()
+    assert np.abs(y - ref).max() < 2e-5, np.abs(y - ref).max()
+
+
+def test_conv1d_accumulate_and_ressub(emu_lib):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 8, 40)).astype(np.float32)
+    w = rng.standard_normal((8, 8, 3)).astype(np.float32) * 0.2
+    res = rng.standard_normal((1, 8, 40)).astype(np.float32)
+    y0 = rng.standard_normal((1, 8, 40)).astype(np.float32)
+    for impl in (0, 1):
+        y = emu_lib.test_conv1d(x, w, None, res, impl=impl, res_sub=True, accumulate_into=y0)
+        ref = y0 + (res - F.conv1d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy())
+        assert np.abs(y - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", [(1, 8, 4, 10, 16, 8), (2, 32, 16, 37, 8, 4), (1, 6, 3, 5, 4, 2), (1, 4, 2, 9, 3, 1)])
+def test_conv_transpose1d(emu_lib, case):
+    B, Cin, Cout, Tin, K, s = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
+    w = rng.standard_normal((Cin, Cout, K)).astype(np.float32) * 0.3
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = emu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x), 0.1), torch.from_numpy(w), torch.from_numpy(b), stride=s,
+                             padding=(K - s) // 2).numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 1e-5
+
+
+def test_engine_matches_oracle_tiny_ragged(emu_lib):
+    check_parity(emu_lib, VitsConfig.tiny(), B=3, Tx=11, seed=1)
+
+
+def test_engine_matches_oracle_multispeaker(emu_lib):
+    check_parity(emu_lib, VitsConfig.tiny(n_speakers=4), B=2, Tx=8, seed=2)
+
+
+def test_engine_matches_oracle_resblock1(emu_lib):
+    check_parity(emu_lib, VitsConfig.tiny(resblock="1"), B=2, Tx=7, seed=3)
+
+
+def test_engine_matches_oracle_injected_noise(emu_lib):
+    check_parity(emu_lib, VitsConfig.tiny(), B=2, Tx=10, seed=4, noise=True)
+
+
+def test_engine_forced_durations_and_length_scale(emu_lib):
+    cfg = VitsConfig.tiny()
+    forced = np.full((2, 6), 3, np.int32)
+    out, _ = check_parity(emu_lib, cfg, B=2, Tx=6, seed=5, forced=forced, ragged=False)
+    assert list(out["lengths"]) == [6 * 3 * cfg.hop_length] * 2
+    check_parity(emu_lib, cfg, B=1, Tx=6, seed=6, scales=(0.0, 1.7, 0.0))
+
+
+def test_odd_flow_depth_folds_final_flip(emu_lib):
+    cfg = VitsConfig.tiny()
+    cfg.flow_n_flows = 3
+    # taps of z are in physical (flipped) order for odd depth: compare audio only
+    check_parity(emu_lib, cfg, B=1, Tx=6, seed=8, taps=False)
+
+
+def test_batched_equals_unbatched(emu_lib):
+    cfg = VitsConfig.tiny()
+    w = W.synthetic_weights(cfg, seed=9)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    rng = np.random.default_rng(9)
+    ids = rng.integers(1, cfg.num_symbols, size=(3, 8)).astype(np.int64)
+    lengths = np.array([8, 5, 3], np.int64)
+    for b in range(3):
+        ids[b, lengths[b]:] = 0
+    full = eng.run(ids, lengths, [0, 1, 0], want_pcm16=True)
+    for b in range(3):
+        one = eng.run(ids[b:b + 1, :lengths[b]], lengths[b:b + 1], [0, 1, 0], want_pcm16=True)
+        L = int(one["lengths"][0])
+        assert L == int(full["lengths"][b])
+        assert np.array_equal(one["audio"][0, :L], full["audio"][b, :L])
+        assert np.array_equal(one["pcm"][0, :L], full["pcm"][b, :L])
+    eng.close()
+
+
+def test_philox_noise_is_split_invariant_and_plausible(emu_lib):
+    cfg = VitsConfig.tiny()
+    w = W.synthetic_weights(cfg, seed=10)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    rng = np.random.default_rng(10)
+    ids = rng.integers(1, cfg.num_symbols, size=(4, 8)).astype(np.int64)
+    lengths = np.full(4, 8, np.int64)
+    sc = [0.667, 1.0, 0.8]
+    full = eng.run(ids, lengths, sc, seed=42, utterance_base=100)
+    again = eng.run(ids, lengths, sc, seed=42, utterance_base=100)
+    assert np.array_equal(full["audio"], again["audio"])
+    half = eng.run(ids[2:], lengths[2:], sc, seed=42, utterance_base=102)
+    for b in range(2):
+        L = int(half["lengths"][b])
+        assert L == int(full["lengths"][2 + b])
+        assert np.array_equal(half["audio"][b, :L], full["audio"][2 + b, :L])
+    other = eng.run(ids, lengths, sc, seed=43, utterance_base=100)
+    assert not np.array_equal(other["audio"][:, :64], full["audio"][:, :64])
+    eng.close()
+
+
+def test_errors_are_reported_not_fatal(emu_lib):
+    cfg = VitsConfig.tiny(n_speakers=3)
+    eng = Engine(W.pack(cfg, W.synthetic_weights(cfg, seed=11)), library=emu_lib)
+    ids = np.ones((1, 4), np.int64)
+    with pytest.raises(NativeError, match="sid"):
+        eng.run(ids, [4], [0, 1, 0])
+    with pytest.raises(NativeError, match="phoneme id"):
+        eng.run(ids * 10_000, [4], [0, 1, 0], sid=[0])
+    with pytest.raises(NativeError, match="speaker id"):
+        eng.run(ids, [4], [0, 1, 0], sid=[7])
+    with pytest.raises(NativeError, match="input_lengths"):
+        eng.run(ids, [9], [0, 1, 0], sid=[0])
+    with pytest.raises(NativeError, match="length_scale"):
+        eng.run(ids, [4], [0, 0.0, 0], sid=[0])
+    ok = eng.run(ids, [4], [0, 1, 0], sid=[0])  # the handle is still usable
+    assert ok["audio"].shape[0] == 1
+    with pytest.raises(NativeError):
+        Engine(b"not a container", library=emu_lib)
+    blob = bytearray(W.pack(cfg, W.synthetic_weights(cfg, seed=11)))
+    with pytest.raises(NativeError, match="truncated"):
+        Engine(bytes(blob[: len(blob) // 2]), library=emu_lib)
+    eng.close()
+
+
+def test_empty_row_in_batch(emu_lib):
+    """input_lengths = 0 for a row: one silent frame (y_length clamps to 1), other rows unaffected."""
+    cfg = VitsConfig.tiny()
+    w = W.synthetic_weights(cfg, seed=12)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    ids = np.array([[3, 4, 5, 6], [0, 0, 0, 0]], np.int64)
+    out = eng.run(ids, [4, 0], [0, 1, 0])
+    assert int(out["lengths"][1]) == cfg.hop_length
+    solo = eng.run(ids[:1], [4], [0, 1, 0])
+    L = int(solo["lengths"][0])
+    assert np.array_equal(solo["audio"][0, :L], out["audio"][0, :L])
+    eng.close()

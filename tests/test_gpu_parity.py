@@ -1,0 +1,137 @@
+"""Parity tests proper: the HIP path on a real MI355X, through the C ABI, against the oracle on identical
+seeded inputs, against the committed golden vectors, and through size-independent properties at the
+BASELINE.json sizes.  Tolerances are the ones stated in tests/util.py (fp32: rel. RMS <= 1e-4,
+max abs <= 1e-3, durations exactly equal, int16 bit-exact on the engine's own float output)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mimic3_amd import weights as W
+from mimic3_amd._native import Engine
+from mimic3_amd.config import VitsConfig
+from oracle.vits_oracle import VitsOracle, audio_float_to_int16
+from tests.util import REL_RMS_TOL, check_parity, rel_rms
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_native_library_is_the_hip_build(gpu_lib):
+    assert "gfx950" in gpu_lib.version()
+
+
+def test_mfma_fragment_layout_on_device(gpu_lib):
+    assert gpu_lib.test_mfma_layout() < 1e-3
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("case", [(2, 16, 32, 70, 3, 1), (1, 32, 32, 1000, 7, 12), (1, 6, 70, 129, 5, 2),
+                                  (2, 64, 29, 33, 1, 1), (1, 192, 384, 500, 5, 1), (1, 768, 192, 130, 3, 1),
+                                  (3, 128, 128, 2000, 7, 3)])
+def test_conv1d_kernels(gpu_lib, impl, case):
+    B, Cin, Cout, T, K, dil = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, Cout, T)).astype(np.float32)
+    in_len = np.array([T] + [max(1, T - 3)] * (B - 1), np.int32)
+    y = gpu_lib.test_conv1d(x, w, bias, res, dilation=dil, impl=impl, in_len=in_len, out_len=in_len, in_slope=0.1,
+                            out_scale=0.5)
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).double()[:, None, :]
+    xt = F.leaky_relu(torch.from_numpy(x).double() * tm, 0.1)
+    ref = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil, padding=(K * dil - dil) // 2)
+    ref = ((ref + torch.from_numpy(res).double()) * 0.5 * tm).numpy()
+    assert np.abs(y - ref).max() < 5e-5, np.abs(y - ref).max()
+
+
+@pytest.mark.parametrize("case", [(1, 256, 128, 100, 16, 8), (2, 128, 64, 333, 16, 8), (1, 64, 32, 1000, 8, 4), (1, 6, 3, 5, 4, 2)])
+def test_conv_transpose1d(gpu_lib, case):
+    B, Cin, Cout, Tin, K, s = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(2 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = gpu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(),
+                             torch.from_numpy(b).double(), stride=s, padding=(K - s) // 2).numpy()
+    assert np.abs(y - ref).max() < 5e-5
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "tiny_ms", "tiny_rb1"])
+def test_tiny_graphs_match_oracle(gpu_lib, cfgname):
+    cfg = {"tiny": VitsConfig.tiny(), "tiny_ms": VitsConfig.tiny(n_speakers=4), "tiny_rb1": VitsConfig.tiny(resblock="1")}[cfgname]
+    check_parity(gpu_lib, cfg, B=3, Tx=11, seed=1)
+    check_parity(gpu_lib, cfg, B=2, Tx=10, seed=4, noise=True)
+
+
+def test_apope_low_b1_matches_oracle(gpu_lib):
+    """configs[1] shape class: en_UK/apope_low graph, B = 1, natural durations, deterministic scales."""
+    check_parity(gpu_lib, VitsConfig.apope_low(), B=1, Tx=40, seed=21, frames_per_id=3.0)
+
+
+def test_apope_low_b1_injected_noise_matches_oracle(gpu_lib):
+    check_parity(gpu_lib, VitsConfig.apope_low(), B=1, Tx=24, seed=22, frames_per_id=3.0, noise=True)
+
+
+def test_vctk_low_ragged_batch_matches_oracle(gpu_lib):
+    """configs[2] shape class: multi-speaker graph (109 speakers, gin 512), ragged batch."""
+    check_parity(gpu_lib, VitsConfig.vctk_low(), B=3, Tx=20, seed=23, frames_per_id=2.5)
+
+
+def test_committed_golden_vector(gpu_lib):
+    """Engine vs the oracle output frozen in tests/golden (made by oracle/make_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, "oracle_apope_low_b1.npz"))
+    cfg = VitsConfig.from_json(str(g["config_json"]))
+    w = W.synthetic_weights(cfg, seed=int(g["seed"]), frames_per_id=float(g["frames_per_id"]))
+    assert abs(float(sum(float(np.abs(v).sum()) for v in w.values())) - float(g["weight_checksum"])) < 1e-3 * float(g["weight_checksum"])
+    eng = Engine(W.pack(cfg, w))
+    out = eng.run(g["ids"], g["lengths"], [0, 1, 0], want_pcm16=True)
+    assert np.array_equal(out["lengths"], g["audio_lengths"])
+    L = int(out["lengths"][0])
+    assert rel_rms(out["audio"][0, :L], g["audio"][0, :L]) < REL_RMS_TOL
+    d = np.abs(out["pcm"][0, :L].astype(np.int32) - g["pcm"][0, :L].astype(np.int32))
+    assert (d > 0).mean() <= 0.10 and d.max() <= 16
+    eng.close()
+
+
+def test_full_size_properties_b8_forced(gpu_lib):
+    """BASELINE.json sizes (Tx = 128, forced 6 frames/id -> 768 frames, 196,608 samples per row) through
+    properties that do not need the oracle: batch invariance (bitwise), determinism, per-row pcm16 ==
+    audio_float_to_int16(float row), Philox noise independent of the batch split."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    eng = Engine(W.pack(cfg, w))
+    B, Tx = 8, 128
+    ids = np.stack([np.random.default_rng(1234 + b).integers(1, 50, Tx) for b in range(B)]).astype(np.int64)
+    lengths = np.full(B, Tx, np.int64)
+    forced = np.full((B, Tx), 6, np.int32)
+    sc = [0.667, 1.0, 0.8]
+    full = eng.run(ids, lengths, sc, forced_durations=forced, seed=7, utterance_base=0, want_pcm16=True)
+    assert list(full["lengths"]) == [768 * 256] * B
+    assert np.isfinite(full["audio"]).all() and np.abs(full["audio"]).max() <= 1.0
+    again = eng.run(ids, lengths, sc, forced_durations=forced, seed=7, utterance_base=0, want_pcm16=True)
+    assert np.array_equal(full["audio"], again["audio"])
+    part = eng.run(ids[5:7], lengths[5:7], sc, forced_durations=forced[5:7], seed=7, utterance_base=5, want_pcm16=True)
+    assert np.array_equal(part["audio"], full["audio"][5:7])
+    for b in range(B):
+        assert np.array_equal(full["pcm"][b], audio_float_to_int16(full["audio"][b]))
+        assert np.abs(full["pcm"][b]).max() == 32767
+    eng.close()
+
+
+def test_golden_shape_utterance(gpu_lib):
+    """Shape of the reference's golden utterance (tests/apope_sample_*.wav: 991 frames = 253,696 samples)."""
+    cfg = VitsConfig.apope_low()
+    eng = Engine(W.pack(cfg, W.synthetic_weights(cfg, seed=1234)))
+    Tx = 180
+    ids = np.random.default_rng(99).integers(1, 50, (1, Tx)).astype(np.int64)
+    forced = np.full((1, Tx), 5, np.int32)
+    forced[0, :91] = 6  # 91*6 + 89*5 = 991 frames
+    out = eng.run(ids, [Tx], [0, 1, 0], forced_durations=forced, want_pcm16=True)
+    assert int(out["lengths"][0]) == 253696
+    assert np.abs(out["pcm"]).max() == 32767
+    eng.close()

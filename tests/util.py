@@ -1,0 +1,85 @@
+"""Shared helpers of the parity tests (the oracle is the checker, never the thing under test)."""
+import numpy as np
+
+from mimic3_amd import weights as W
+from mimic3_amd._native import Engine
+from mimic3_amd.config import VitsConfig
+from oracle.vits_oracle import VitsOracle, audio_float_to_int16
+
+# Tolerances: the reference's own goldens differ across platforms by
+# rel. RMS 2e-5..8e-5 and <= 12 LSB; its acceptance test allows 10 % of int16 samples to differ.
+REL_RMS_TOL = 1e-4
+MAX_ABS_TOL = 1e-3
+INT16_DIFF_FRACTION_TOL = 0.10
+INT16_MAX_LSB = 16
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(1e-30, np.sqrt(np.mean(b ** 2))))
+
+
+def make_inputs(cfg: VitsConfig, B: int, Tx: int, seed: int = 0, ragged: bool = True):
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1, cfg.num_symbols, size=(B, Tx)).astype(np.int64)
+    lengths = np.full(B, Tx, np.int64)
+    if ragged and B > 1:
+        lengths[1:] = rng.integers(max(1, Tx // 2), Tx + 1, size=B - 1)
+        for b in range(B):
+            ids[b, lengths[b]:] = 0
+    sid = rng.integers(0, cfg.n_speakers, size=B).astype(np.int64) if cfg.is_multispeaker else None
+    return ids, lengths, sid
+
+
+def check_parity(lib, cfg: VitsConfig, B=2, Tx=9, seed=0, scales=(0.0, 1.0, 0.0), noise=False, forced=None,
+                 frames_per_id=2.5, taps=True, ragged=True, weights=None):
+    """Run engine and oracle on identical inputs; assert durations equal and waveforms within tolerance.
+    Returns (engine output dict, oracle dict)."""
+    w = weights if weights is not None else W.synthetic_weights(cfg, seed=seed + 100, frames_per_id=frames_per_id)
+    eng = Engine(W.pack(cfg, w), library=lib)
+    ids, lengths, sid = make_inputs(cfg, B, Tx, seed, ragged)
+    rng = np.random.default_rng(seed + 7)
+    kw = {}
+    if noise:
+        scales = (0.667, scales[1], 0.8)
+        kw["noise_w"] = rng.standard_normal((B, 2, Tx)).astype(np.float32)
+    ora = VitsOracle(cfg, w)
+    o1 = ora.infer(ids, lengths, scales, sid=sid, noise_w=kw.get("noise_w"),
+                   noise_z=None if not noise else np.zeros((B, cfg.inter_channels, 1), np.float32) , forced_durations=forced) \
+        if not noise else None
+    if noise:
+        # the frame count is needed to size noise_z: a first oracle pass with the duration noise only
+        pre = ora.infer(ids, lengths, (0.0, scales[1], scales[2]), sid=sid, noise_w=kw["noise_w"], forced_durations=forced)
+        Ty = int(pre["y_lengths"].max())
+        kw["noise_z"] = rng.standard_normal((B, cfg.inter_channels, Ty)).astype(np.float32)
+        o1 = ora.infer(ids, lengths, scales, sid=sid, noise_w=kw["noise_w"], noise_z=kw["noise_z"], forced_durations=forced)
+    out = eng.run(ids, lengths, scales, sid, forced_durations=forced, want_pcm16=True, debug_taps=taps, **kw)
+    assert np.array_equal(out["lengths"], o1["audio_lengths"]), (out["lengths"], o1["audio_lengths"])
+    if taps:
+        assert np.array_equal(eng.tap("w_ceil"), o1["w_ceil"]), "durations (ceil) differ"
+        I = cfg.inter_channels
+        st = eng.tap("stats")
+        for name, got, ref in (("x", eng.tap("x"), o1["x"]), ("m_p", st[:, :I], o1["m_p"]), ("logs_p", st[:, I:], o1["logs_p"]),
+                               ("z_p", eng.tap("z_p"), o1["z_p"]), ("z", eng.tap("z"), o1["z"])):
+            assert got.shape == ref.shape, (name, got.shape, ref.shape)
+            if name in ("z_p", "z"):
+                # padded frames: upstream leaves the (unmasked) prior noise there, the engine writes zeros;
+                # they never reach a valid frame (every consumer masks), so compare valid frames only
+                ym = (np.arange(got.shape[2])[None, :] < o1["y_lengths"][:, None])[:, None, :]
+                got, ref = got * ym, ref * ym
+            assert rel_rms(got, ref) < REL_RMS_TOL, (name, rel_rms(got, ref))
+    for b in range(B):
+        L = int(out["lengths"][b])
+        a, r = out["audio"][b, :L], o1["audio"][b, 0, :L]
+        assert rel_rms(a, r) < REL_RMS_TOL, (b, rel_rms(a, r))
+        assert np.abs(a - r).max() < MAX_ABS_TOL, (b, np.abs(a - r).max())
+        # A2: int16 conversion is bit-exact on the engine's own float output ...
+        assert np.array_equal(out["pcm"][b, :L], audio_float_to_int16(a)), "pcm16 differs from audio_float_to_int16"
+        # ... and within the reference's acceptance criterion against the oracle's waveform
+        ref16 = audio_float_to_int16(r)
+        d = np.abs(out["pcm"][b, :L].astype(np.int32) - ref16.astype(np.int32))
+        assert (d > 0).mean() <= INT16_DIFF_FRACTION_TOL and d.max() <= INT16_MAX_LSB, ((d > 0).mean(), d.max())
+        assert np.all(out["pcm"][b, L:] == 0)
+    eng.close()
+    return out, o1
