@@ -208,7 +208,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.vits_oracle import VitsOracle, audio_float_to_int16
 
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))  # beyond ~32 threads the small ops only get slower
         ora = VitsOracle(cfg, weights)
         nb = 1
         ids_c, len_c = ids[:nb], lengths[:nb]

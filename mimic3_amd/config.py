@@ -132,6 +132,16 @@ class VitsConfig:
             hop_length=8,
         )
 
+    @staticmethod
+    def tiny_wide(n_speakers: int = 1) -> "VitsConfig":
+        """Tiny encoder/flow with the *real* decoder widths of the last two stages (64 -> 32 channels, ResBlock2
+        k = 3/5/7, dilations (1,2)/(2,6)/(3,12)) so that the fused multi-receptive-field kernel is exercised."""
+        c = VitsConfig.tiny(n_speakers=n_speakers)
+        c.upsample_initial_channel = 128
+        c.resblock_kernel_sizes = (3, 5, 7)
+        c.resblock_dilation_sizes = ((1, 2), (2, 6), (3, 12))
+        return c
+
     # ------------------------------------------------------------------ (de)serialisation
     @staticmethod
     def from_json(text_or_dict) -> "VitsConfig":

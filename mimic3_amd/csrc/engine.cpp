@@ -285,6 +285,8 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
     prof_.stream = stream_;
     const char* fg = getenv("MI355VITS_FORCE_GENERIC");
     force_generic_ = fg && fg[0] == '1';
+    const char* nf = getenv("MI355VITS_NO_FUSED_MRF");
+    no_fused_mrf_ = nf && nf[0] == '1';
 
     const mi355vits_config& c = cfg_;
     const int H = c.hidden_channels, F = c.filter_channels, I = c.inter_channels, half = I / 2;
@@ -405,6 +407,15 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
     for (int i = 0; i < c.n_upsamples; ++i) {
         add_vec(wf, S("dec.ups.%d.weight", i), {ch, ch / 2, c.upsample_kernel_sizes[i]});
         add_vec(wf, S("dec.ups.%d.bias", i), {ch / 2});
+        {
+            // the transposed conv as `rate` polyphase stride-1 filters on the matrix cores (kernels.h: shuf_*)
+            const int uk = c.upsample_kernel_sizes[i], ur = c.upsample_rates[i], taps = convt_taps(uk, ur);
+            const HostTensor& w = wf.get(S("dec.ups.%d.weight", i), {ch, ch / 2, uk});
+            const HostTensor& b = wf.get(S("dec.ups.%d.bias", i), {ch / 2});
+            std::vector<float> wv((size_t)ur * (ch / 2) * ch * taps), bv((size_t)ur * (ch / 2));
+            convt_to_polyphase(w.data, b.data, ch, ch / 2, uk, ur, wv.data(), bv.data());
+            add_conv_data(S("dec.ups.%d.poly", i), wv, &bv, ur * (ch / 2), ch, taps);
+        }
         ch /= 2;
         for (int j = 0; j < c.n_resblock_kernels; ++j) {
             const int n = i * c.n_resblock_kernels + j;
@@ -452,7 +463,7 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     a.Cout = w.Cout;
     a.K = w.K;
     a.bias = P(w.bias);
-    a.pad = (w.K * a.dil - a.dil) / 2;
+    if (a.pad < 0) a.pad = (w.K * a.dil - a.dil) / 2;
     if ((a.epi == EPI_GATE) != (w.epi == EPI_GATE)) throw EngineError(MI355VITS_ERR_INTERNAL, "conv epilogue / packing mismatch");
     const double flops = 2.0 * a.B * (double)a.T * w.Cout * w.Cin * w.K;
     double ch_io = (double)w.Cin + (a.epi == EPI_GATE ? a.H : w.Cout);
@@ -747,14 +758,24 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
     const int nk = c.n_resblock_kernels;
     for (int i = 0; i < c.n_upsamples; ++i) {
         const int r = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
-        ConvTArgs u;
-        u.x = d_bufC_; u.x_bs = (long)ch * T; u.x_ld = (int)T;
-        u.y = d_bufA_; u.y_bs = (long)(ch / 2) * T * r; u.y_ld = (int)(T * r);
-        u.w = vec(S("dec.ups.%d.weight", i)); u.bias = vec(S("dec.ups.%d.bias", i));
-        u.B = B; u.Cin = ch; u.Cout = ch / 2; u.Tin = (int)T; u.K = k; u.stride = r; u.pad = (k - r) / 2;
-        u.in_slope = 0.1f;
-        u.in_len = d_slen_ + (long)i * B;
-        {
+        const ConvW& up = cw(S("dec.ups.%d.poly", i));
+        if (!force_generic_ && up.packed != NO_OFF) {
+            ConvArgs u;
+            u.x = d_bufC_; u.x_bs = (long)ch * T; u.x_ld = (int)T;
+            u.y = d_bufA_; u.y_bs = (long)(ch / 2) * T * r; u.y_ld = (int)(T * r);
+            u.in_slope = 0.1f; u.in_len = d_slen_ + (long)i * B;
+            u.pad = up.K - 1; u.Tin = (int)T;
+            u.shuf_s = r; u.shuf_p = (k - r) / 2; u.shuf_cout = ch / 2; u.shuf_T = (int)(T * r);
+            u.B = B; u.T = (int)T + up.K - 1;
+            conv("dec.upsample", up, u);
+        } else {
+            ConvTArgs u;
+            u.x = d_bufC_; u.x_bs = (long)ch * T; u.x_ld = (int)T;
+            u.y = d_bufA_; u.y_bs = (long)(ch / 2) * T * r; u.y_ld = (int)(T * r);
+            u.w = vec(S("dec.ups.%d.weight", i)); u.bias = vec(S("dec.ups.%d.bias", i));
+            u.B = B; u.Cin = ch; u.Cout = ch / 2; u.Tin = (int)T; u.K = k; u.stride = r; u.pad = (k - r) / 2;
+            u.in_slope = 0.1f;
+            u.in_len = d_slen_ + (long)i * B;
             const int taps = (k + r - 1) / r;
             ProfScope ps(prof_, "dec.upsample", 2.0 * B * (double)T * r * ch * (ch / 2) * taps,
                          4.0 * B * ((double)ch * T + (double)(ch / 2) * T * r));
@@ -765,6 +786,39 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         const long sbs = (long)ch * T;
         const int* slen = d_slen_ + (long)(i + 1) * B;  // rows end at their own length (batched == unbatched)
         tap(S("dec.ups.%d", i).c_str(), d_bufA_, {B, ch, T});
+        bool fused = false;
+        if (!force_generic_ && !no_fused_mrf_ && c.resblock == 2 && nk <= MRF_MAX_RB) {
+            MrfArgs m;
+            bool two = true;
+            for (int j = 0; j < nk; ++j) two = two && c.resblock_n_dilations[j] == 2;
+            if (two) {
+                for (int j = 0; j < nk; ++j) {
+                    m.k[j] = c.resblock_kernel_sizes[j];
+                    m.d1[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 0];
+                    m.d2[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 1];
+                }
+                if (mrf_fused_supported(ch, nk, m.k, m.d1, m.d2)) {
+                    double flops = 0;
+                    for (int j = 0; j < nk; ++j) {
+                        for (int q = 0; q < 2; ++q) {
+                            const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
+                            m.w[j][q] = P(w.packed);
+                            m.bias[j][q] = P(w.bias);
+                        }
+                        flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];
+                    }
+                    m.nrb = nk;
+                    m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
+                    m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
+                    m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
+                    ProfScope ps(prof_, i == 1 ? "dec.mrf_fused.s1" : (i == 2 ? "dec.mrf_fused.s2" : "dec.mrf_fused"), flops,
+                                 8.0 * B * (double)T * ch);
+                    launch_mrf_fused(m, stream_);
+                    fused = true;
+                }
+            }
+        }
+        if (!fused)
         for (int j = 0; j < nk; ++j) {
             const int n = i * nk + j;
             const int nd = c.resblock_n_dilations[j];

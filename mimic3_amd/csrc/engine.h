@@ -137,6 +137,7 @@ class Engine {
     hipEvent_t ev_start_ = nullptr, ev_end_ = nullptr;
     bool timed_ = false;
     bool force_generic_ = false;
+    bool no_fused_mrf_ = false;  // MI355VITS_NO_FUSED_MRF=1: conv-by-conv resblocks (A/B + fallback)
     Profiler prof_;
 
     std::vector<float> host_stage_;

@@ -21,7 +21,9 @@ struct ConvArgs {
     float* y2 = nullptr; long y2_bs = 0; int y2_ld = 0;           // RESSKIP: skip accumulator [B,H,T]
     const int* in_len = nullptr;   // [B] valid length of the input (x * mask) or null
     const int* out_len = nullptr;  // [B] valid length of the output (y * mask) or null
-    int B = 1, Cin = 0, Cout = 0, T = 0, K = 1, dil = 1, pad = 0;
+    int B = 1, Cin = 0, Cout = 0, T = 0, K = 1, dil = 1;
+    int pad = -1;            // left zero padding; -1 = "same" ((K*dil - dil) / 2), filled in by Engine::conv
+    int Tin = -1;            // input extent when it differs from the number of output positions T (-1: = T)
     float in_slope = 1.0f;   // leaky-relu slope applied to the input while staging (1 = identity)
     int relu = 0;            // relu on the output
     float out_scale = 1.0f;  // y = (...) * out_scale
@@ -31,6 +33,9 @@ struct ConvArgs {
     int skip_init = 0;       // RESSKIP: first WN layer writes skip instead of accumulating
     int H = 0;               // GATE / RESSKIP: hidden channels
     int epi = EPI_STD;
+    // ConvTranspose1d run as a stride-1 conv over `stride` polyphase filters: output channel
+    // co' = r * shuf_cout + co of position i lands at y[co][i * shuf_s + r - shuf_p]  (0 <= n < shuf_T)
+    int shuf_s = 0, shuf_p = 0, shuf_cout = 0, shuf_T = 0;
 };
 
 // Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).
@@ -55,6 +60,30 @@ struct ConvTArgs {
     float in_slope = 1.0f;
 };
 void launch_conv_transpose1d(const ConvTArgs& a, hipStream_t s);
+// Polyphase repack: ConvTranspose1d weight [Cin,Cout,K] (+bias [Cout]) -> Conv1d weight
+// [stride*Cout, Cin, taps] (+bias [stride*Cout]) with taps = ceil(K/stride); see ConvArgs::shuf_*.
+int convt_taps(int K, int stride);
+void convt_to_polyphase(const float* w, const float* bias, int Cin, int Cout, int K, int stride, float* w_out,
+                        float* bias_out);
+
+// ---------------------------------------------------------------- fused multi-receptive-field stage (K11)
+// y = (1/n) * sum_j ResBlock2_j(x),  ResBlock2(k,(d1,d2)): x1 = x + conv_{k,d1}(lrelu(x)); x2 = x1 + conv_{k,d2}(lrelu(x1)).
+// One workgroup keeps the x tile (+halo) and the x1 tile in LDS, runs all 2n convolutions on the fp32 matrix
+// cores and writes y once: HBM traffic = read x + write y (vs ~7 tensor passes per resblock conv-by-conv).
+constexpr int MRF_MAX_RB = 4;
+struct MrfArgs {
+    const float* x = nullptr; long x_bs = 0; int x_ld = 0;
+    float* y = nullptr; long y_bs = 0; int y_ld = 0;
+    const float* w[MRF_MAX_RB][2] = {};     // MFMA-packed [C/32][K][C/2][64]
+    const float* bias[MRF_MAX_RB][2] = {};
+    int k[MRF_MAX_RB] = {}, d1[MRF_MAX_RB] = {}, d2[MRF_MAX_RB] = {};
+    int nrb = 0;
+    const int* len = nullptr;  // [B] rows end at their own length
+    int B = 1, C = 0, T = 0;
+    int R = 0, ldx = 0, ld1 = 0;  // filled by the launcher
+};
+bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
+void launch_mrf_fused(MrfArgs a, hipStream_t s);
 
 // ---------------------------------------------------------------- decoder tail
 // y = tanh(conv_post(lrelu_0.01(x * mask))) (Cout = 1, no bias) + per-utterance max|y| over valid samples;

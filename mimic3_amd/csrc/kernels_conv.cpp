@@ -20,6 +20,12 @@ namespace m355 {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void epi_std(const ConvArgs& a, int b, int co, int t, float v, int out_len) {
     if (a.bias) v += a.bias[co];
+    if (a.shuf_s) {  // polyphase ConvTranspose1d: scatter phase r of position t to n = t*s + r - p
+        const int r = co / a.shuf_cout, c = co - r * a.shuf_cout;
+        const int n = t * a.shuf_s + r - a.shuf_p;
+        if (n >= 0 && n < a.shuf_T) a.y[(long)b * a.y_bs + (long)c * a.y_ld + n] = v;
+        return;
+    }
     if (a.cond) v += a.cond[(long)b * a.cond_bs + co];
     if (a.relu) v = fmaxf(v, 0.0f);
     if (a.mask_before_res && t >= out_len) v = 0.0f;
@@ -84,7 +90,8 @@ __global__ __launch_bounds__(256) void k_conv1d_generic(ConvArgs a) {
             co_i[i] = (co < a.Cout) ? co : -1;
         }
     }
-    const int in_len = a.in_len ? a.in_len[b] : a.T;
+    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
+    const int in_len = a.in_len ? a.in_len[b] : Tin;
     const int out_len = a.out_len ? a.out_len[b] : a.T;
     float acc[2][4];
     for (int i = 0; i < 2; ++i)
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void k_conv1d_generic(ConvArgs a) {
             const int ci = idx / LD, tt = idx - ci * LD;
             const int c = c0 + ci, t = t0 - a.pad + tt;
             float v = 0.0f;
-            if (c < a.Cin && t >= 0 && t < a.T && t < in_len) {
+            if (c < a.Cin && t >= 0 && t < Tin && t < in_len) {
                 v = a.x[(long)b * a.x_bs + (long)c * a.x_ld + t];
                 v = v >= 0.0f ? v : v * a.in_slope;
             }
@@ -222,7 +229,8 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     const int n_tiles = (EPI == EPI_GATE) ? 2 * ((a.H + 31) / 32) : (a.Cout + 31) / 32;
     const int tile0 = (blockIdx.y * WM + wm) * MT;
     const int cpairs = a.Cin >> 1;
-    const int in_len = a.in_len ? a.in_len[b] : a.T;
+    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
+    const int in_len = a.in_len ? a.in_len[b] : Tin;
     const int out_len = a.out_len ? a.out_len[b] : a.T;
     const float* xb = a.x + (long)b * a.x_bs;
 
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
             for (int tt = lane; tt < LD; tt += 64) {
                 const int t = t0 - a.pad + tt;
                 float v = 0.0f;
-                if (t >= 0 && t < a.T && t < in_len) {
+                if (t >= 0 && t < Tin && t < in_len) {
                     v = row[t];
                     v = v >= 0.0f ? v : v * a.in_slope;
                 }
@@ -251,24 +259,42 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
             }
         }
         __syncthreads();
+        // K-loop over (tap, channel pair) with the next step's fragments already in flight (register double
+        // buffer): the 64-cycle MFMAs of step s cover the L2/LDS latency of step s+1.
         const int cp0 = c0 >> 1;
-        for (int k = 0; k < a.K; ++k) {
-            const float* xk = xs + brow * LD + k * a.dil + bcol + wn * NT * 32;
-            for (int cp = 0; cp < (CI_C >> 1); ++cp) {
-                float af[MT], bf[NT];
+        const int cpn = CI_C >> 1;
+        const int steps = a.K * cpn;
+        const float* xw = xs + brow * LD + bcol + wn * NT * 32;
+        float af_n[MT], bf_n[NT];
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i) {
+            const int tile = tile0 + i;
+            af_n[i] = (tile < n_tiles) ? a.w[(((long)tile * a.K) * cpairs + cp0) * 64 + lane] : 0.0f;
+        }
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j) bf_n[j] = xw[j * 32];
+        int k = 0, cp = 0;
+        for (int s = 0; s < steps; ++s) {
+            float af[MT], bf[NT];
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) af[i] = af_n[i];
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) bf[j] = bf_n[j];
+            if (++cp == cpn) { cp = 0; ++k; }
+            if (s + 1 < steps) {
                 MI355_UNROLL
                 for (int i = 0; i < MT; ++i) {
                     const int tile = tile0 + i;
-                    af[i] = (tile < n_tiles) ? a.w[(((long)tile * a.K + k) * cpairs + cp0 + cp) * 64 + lane] : 0.0f;
+                    af_n[i] = (tile < n_tiles) ? a.w[(((long)tile * a.K + k) * cpairs + cp0 + cp) * 64 + lane] : 0.0f;
                 }
-                const float* xr = xk + (2 * cp) * LD;
+                const float* xr = xw + (2 * cp) * LD + k * a.dil;
                 MI355_UNROLL
-                for (int j = 0; j < NT; ++j) bf[j] = xr[j * 32];
-                MI355_UNROLL
-                for (int i = 0; i < MT; ++i)
-                    MI355_UNROLL
-                    for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) bf_n[j] = xr[j * 32];
             }
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -305,15 +331,14 @@ template <int MT, int NT, int WM, int WN, int EPI>
 void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
     const int LD = T_B + (a.K - 1) * a.dil;
-    // C_in chunk: even divisor of Cin keeping the staged tile <= 48 KiB
-    int ci_c = a.Cin;
-    auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= 48 * 1024; };
-    if (!fits(ci_c)) {
-        ci_c = 0;
-        for (int c = 64; c >= 2; c -= 2)
-            if (a.Cin % c == 0 && fits(c)) { ci_c = c; break; }
-        if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
-    }
+    // C_in chunk: fixed by C_in alone (largest even divisor <= 32) so that the summation order — and with it
+    // every output bit — does not depend on the tile shape chosen for a batch size; only a receptive field too
+    // large for LDS shrinks it further.
+    auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= 60 * 1024; };
+    int ci_c = 0;
+    for (int c = 32; c >= 2; c -= 2)
+        if (a.Cin % c == 0 && fits(c)) { ci_c = c; break; }
+    if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
     const size_t shmem = (size_t)ci_c * LD * sizeof(float);
     dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
     auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI>;
@@ -429,6 +454,24 @@ void launch_conv_transpose1d(const ConvTArgs& a, hipStream_t s) {
     const size_t shmem = sizeof(float) * ((size_t)CT_CI * NI + (size_t)CT_CI * CT_CO * a.K);
     dim3 grid((Tout + CT_N - 1) / CT_N, (a.Cout + CT_CO - 1) / CT_CO, a.B);
     LAUNCH_KERNEL(k_conv_transpose1d, grid, dim3(256), shmem, s, a);
+}
+
+// Polyphase view of ConvTranspose1d (A.2): output n = i*s + r - p, r in [0,s) takes taps k = r + m*s (m = 0..taps-1)
+// of inputs x[i - m].  As a stride-1 Conv1d over positions i with `taps` taps and left padding taps-1:
+//   y'[r*Cout + co][i] = sum_ci sum_j W'[r*Cout + co][ci][j] * x[ci][i - (taps-1) + j],  W'[..][j] = W[ci][co][r + (taps-1-j)*s]
+int convt_taps(int K, int stride) { return (K + stride - 1) / stride; }
+void convt_to_polyphase(const float* w, const float* bias, int Cin, int Cout, int K, int stride, float* w_out,
+                        float* bias_out) {
+    const int taps = convt_taps(K, stride);
+    for (int r = 0; r < stride; ++r)
+        for (int co = 0; co < Cout; ++co) {
+            if (bias_out) bias_out[r * Cout + co] = bias ? bias[co] : 0.0f;
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int j = 0; j < taps; ++j) {
+                    const int k = r + (taps - 1 - j) * stride;
+                    w_out[(((size_t)r * Cout + co) * Cin + ci) * taps + j] = k < K ? w[((size_t)ci * Cout + co) * K + k] : 0.0f;
+                }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,241 @@
+// kernels_mrf.cpp — one HiFi-GAN multi-receptive-field stage as ONE kernel.
+//
+//   y = (1/n) * sum_j RB_j(x),   RB_j: x1 = x + conv_{k_j,d1_j}(lrelu_0.1(x));  x2 = x1 + conv_{k_j,d2_j}(lrelu_0.1(x1))
+//
+// Conv-by-conv this stage moves ~7 activation tensors per resblock through HBM and its k=3 convs sit at
+// 24 FLOP/B — HBM-bound on MI355X (ridge 19.7 FLOP/B fp32).  Here a workgroup owns a [C, T_B] output tile:
+//   * x[C, T_B + 2R] (R = largest receptive radius of the n resblocks) is staged ONCE into LDS, raw; leaky-relu is
+//     applied when a B fragment is read (max(v, 0.1 v): 2 VALU per 64-cycle MFMA);
+//   * conv1 of a resblock runs on the fp32 matrix cores over T_B + 2*r2 columns and leaves x1 (masked to the row's
+//     own length) in a second LDS tile; conv2 consumes it and accumulates x2 into per-lane registers that persist
+//     across the n resblocks;
+//   * A fragments stream from L2/L1 in fragment order (same packing as k_conv1d_mfma) with a one-step register
+//     prefetch; B fragments are conflict-free ds_read_b32 (32 consecutive columns per half-wave);
+//   * y is written once.  HBM traffic = read x + write y = 8*C bytes per sample (layer-at-a-time: ~50*C).
+// Wave layout: WM waves over the C/32 output-channel tiles x WT waves over time; 4 waves, one per SIMD; LDS ~155 KiB
+// (one workgroup per CU).  Columns are processed in 32-wide MFMA tiles; conv1's ceil((T_B+2*r2)/32) tiles are dealt
+// round-robin to the WT time waves.
+#include "kernels.h"
+
+namespace m355 {
+
+template <int WM, int WT, int NT2, int NT1MAX>
+__global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
+    static_assert(WM * WT == 4, "4 waves per workgroup");
+    constexpr int C = 32 * WM;
+    constexpr int T_B = 32 * NT2 * WT;
+    constexpr int CP = C / 2;
+    DYN_SMEM(float, smem);
+    const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
+    float* X = smem;             // [C][LDX]  raw x, zero outside the row
+    float* X1 = smem + C * LDX;  // [C][LD1]  x1 of the current resblock, zero outside the row
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WT, wt = wid % WT;
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * T_B;
+    int len = a.len ? a.len[b] : a.T;
+    if (len > a.T) len = a.T;
+
+    {
+        const float* xb = a.x + (long)b * a.x_bs;
+        for (int c = wid; c < C; c += 4) {
+            const float* row = xb + (long)c * a.x_ld;
+            float* dst = X + c * LDX;
+            for (int cx = lane; cx < LDX; cx += 64) {
+                const int t = t0 - R + cx;
+                dst[cx] = (t >= 0 && t < len) ? row[t] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 out[NT2];
+    MI355_UNROLL
+    for (int i = 0; i < NT2; ++i)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) out[i][r] = 0.0f;
+
+    for (int j = 0; j < a.nrb; ++j) {
+        const int K = a.k[j], d1 = a.d1[j], d2 = a.d2[j];
+        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
+        const int n1 = (T_B + 2 * r2 + 31) / 32;  // conv1 column tiles: extended column e <-> t = t0 - r2 + e
+        // ------------------------------------------------------------ conv1: x1 = x + conv(lrelu(x)) -> LDS
+        {
+            f32x16 acc[NT1MAX];
+            MI355_UNROLL
+            for (int i = 0; i < NT1MAX; ++i)
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
+            const int steps = K * CP;
+            const float* xw = X + brow * LDX + (R - r2 - r1) + bcol;
+            // register double buffer: fragments of step s+1 are in flight while the MFMAs of step s issue
+            float a_nxt = wp[0];
+            float b_nxt[NT1MAX];
+            MI355_UNROLL
+            for (int i = 0; i < NT1MAX; ++i) {
+                const int q = wt + WT * i;
+                b_nxt[i] = (q < n1) ? xw[q * 32] : 0.0f;
+            }
+            int k = 0, cp = 0;
+            for (int s = 0; s < steps; ++s) {
+                const float av = a_nxt;
+                float bv[NT1MAX];
+                MI355_UNROLL
+                for (int i = 0; i < NT1MAX; ++i) bv[i] = b_nxt[i];
+                if (++cp == CP) { cp = 0; ++k; }
+                if (s + 1 < steps) {
+                    a_nxt = wp[(long)(s + 1) * 64];
+                    const float* xr = xw + (2 * cp) * LDX + k * d1;
+                    MI355_UNROLL
+                    for (int i = 0; i < NT1MAX; ++i) {
+                        const int q = wt + WT * i;
+                        if (q < n1) b_nxt[i] = xr[q * 32];
+                    }
+                }
+                MI355_UNROLL
+                for (int i = 0; i < NT1MAX; ++i) {
+                    const int q = wt + WT * i;
+                    if (q < n1) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
+                }
+            }
+            const float* bias = a.bias[j][0];
+            MI355_UNROLL
+            for (int i = 0; i < NT1MAX; ++i) {
+                const int q = wt + WT * i;
+                if (q < n1) {
+                    const int e = q * 32 + bcol;
+                    const int t = t0 - r2 + e;
+                    const bool live = t >= 0 && t < len;
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                        const float v = X[co * LDX + (R - r2) + e] + acc[i][r] + bias[co];
+                        X1[co * LD1 + e] = live ? v : 0.0f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ conv2: out += x1 + conv(lrelu(x1))
+        {
+            f32x16 acc[NT2];
+            MI355_UNROLL
+            for (int i = 0; i < NT2; ++i)
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            const float* wp = a.w[j][1] + (long)wm * K * CP * 64 + lane;
+            const int steps = K * CP;
+            const float* xw = X1 + brow * LD1 + bcol + wt * NT2 * 32;
+            float a_nxt = wp[0];
+            float b_nxt[NT2];
+            MI355_UNROLL
+            for (int i = 0; i < NT2; ++i) b_nxt[i] = xw[i * 32];
+            int k = 0, cp = 0;
+            for (int s = 0; s < steps; ++s) {
+                const float av = a_nxt;
+                float bv[NT2];
+                MI355_UNROLL
+                for (int i = 0; i < NT2; ++i) bv[i] = b_nxt[i];
+                if (++cp == CP) { cp = 0; ++k; }
+                if (s + 1 < steps) {
+                    a_nxt = wp[(long)(s + 1) * 64];
+                    const float* xr = xw + (2 * cp) * LD1 + k * d2;
+                    MI355_UNROLL
+                    for (int i = 0; i < NT2; ++i) b_nxt[i] = xr[i * 32];
+                }
+                MI355_UNROLL
+                for (int i = 0; i < NT2; ++i) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
+            }
+            const float* bias = a.bias[j][1];
+            MI355_UNROLL
+            for (int i = 0; i < NT2; ++i) {
+                const int c0 = (wt * NT2 + i) * 32 + bcol;
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                    out[i][r] += X1[co * LD1 + c0 + r2] + acc[i][r] + bias[co];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const float n = (float)a.nrb;
+    MI355_UNROLL
+    for (int i = 0; i < NT2; ++i) {
+        const int t = t0 + (wt * NT2 + i) * 32 + bcol;
+        if (t < a.T) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = out[i][r] / n;
+            }
+        }
+    }
+}
+
+namespace {
+// geometry per channel count: (WM, WT, NT2, NT1MAX)
+//   C = 32: 1 x 4 waves, T_B = 512;  C = 64: 2 x 2 waves, T_B = 192
+struct Geo { int C, T_B, WT, NT1MAX; };
+inline bool geometry(int C, Geo* g) {
+    if (C == 32) { *g = {32, 512, 4, 5}; return true; }
+    if (C == 64) { *g = {64, 192, 2, 5}; return true; }
+    return false;
+}
+constexpr size_t LDS_LIMIT = 160 * 1024;
+}  // namespace
+
+bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
+    Geo g;
+    if (!geometry(C, &g) || nrb < 1 || nrb > MRF_MAX_RB) return false;
+    int R = 0, r2max = 0;
+    for (int j = 0; j < nrb; ++j) {
+        if (k[j] < 1 || (k[j] % 2) == 0 || d1[j] < 1 || d2[j] < 1) return false;
+        const int r1 = (k[j] - 1) / 2 * d1[j], r2 = (k[j] - 1) / 2 * d2[j];
+        R = R > r1 + r2 ? R : r1 + r2;
+        r2max = r2max > r2 ? r2max : r2;
+        const int n1 = (g.T_B + 2 * r2 + 31) / 32;
+        if ((n1 + g.WT - 1) / g.WT > g.NT1MAX) return false;
+    }
+    const size_t ldx = (size_t)g.T_B + 2 * R + 32;
+    const size_t ld1 = (size_t)((g.T_B + 2 * r2max + 31) / 32) * 32;
+    return (size_t)C * (ldx + ld1) * sizeof(float) <= LDS_LIMIT;
+}
+
+void launch_mrf_fused(MrfArgs a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    Geo g;
+    if (!geometry(a.C, &g) || !mrf_fused_supported(a.C, a.nrb, a.k, a.d1, a.d2))
+        throw std::runtime_error("mrf_fused: unsupported stage shape");
+    int R = 0, r2max = 0;
+    for (int j = 0; j < a.nrb; ++j) {
+        const int r1 = (a.k[j] - 1) / 2 * a.d1[j], r2 = (a.k[j] - 1) / 2 * a.d2[j];
+        R = R > r1 + r2 ? R : r1 + r2;
+        r2max = r2max > r2 ? r2max : r2;
+    }
+    a.R = R;
+    a.ldx = g.T_B + 2 * R + 32;  // +32: conv1's last (rounded-up) column tile stays inside its row
+    a.ld1 = ((g.T_B + 2 * r2max + 31) / 32) * 32;
+    const size_t shmem = (size_t)a.C * (a.ldx + a.ld1) * sizeof(float);
+    dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
+    if (a.C == 32) {
+        auto kfn = k_mrf_fused<1, 4, 4, 5>;
+#ifndef MI355_EMU
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT), true);
+        (void)once;
+#endif
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+    } else {
+        auto kfn = k_mrf_fused<2, 2, 3, 5>;
+#ifndef MI355_EMU
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT), true);
+        (void)once;
+#endif
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+    }
+}
+
+}  // namespace m355

@@ -97,6 +97,37 @@ def test_engine_forced_durations_and_length_scale(emu_lib):
     check_parity(emu_lib, cfg, B=1, Tx=6, seed=6, scales=(0.0, 1.7, 0.0))
 
 
+def test_fused_mrf_stage_kernel(emu_lib):
+    """Decoder stages of 64 and 32 channels go through k_mrf_fused (all resblocks of a stage in one kernel);
+    compare the stage taps and the waveform with the oracle, ragged batch, and with the conv-by-conv path."""
+    import os
+
+    cfg = VitsConfig.tiny_wide()
+    w = W.synthetic_weights(cfg, seed=31, frames_per_id=2.0)
+    out, ora = check_parity(emu_lib, cfg, B=2, Tx=7, seed=31, weights=w)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    from tests.util import make_inputs
+    ids, lengths, _ = make_inputs(cfg, 2, 7, 31)
+    eng.run(ids, lengths, [0, 1, 0], debug_taps=True)
+    for name in ("dec.ups.0", "dec.mrf.0", "dec.ups.1", "dec.mrf.1"):
+        got, ref = eng.tap(name), ora[name]
+        f = got.shape[2] // int(ora["y_lengths"].max())
+        m = (np.arange(got.shape[2])[None, :] < (ora["y_lengths"] * f)[:, None])[:, None, :]
+        assert rel_rms(got * m, ref * m) < 1e-5, (name, rel_rms(got * m, ref * m))
+    fused_audio = eng.run(ids, lengths, [0, 1, 0])["audio"]
+    eng.close()
+    os.environ["MI355VITS_NO_FUSED_MRF"] = "1"
+    try:
+        eng2 = Engine(W.pack(cfg, w), library=emu_lib)
+        plain_audio = eng2.run(ids, lengths, [0, 1, 0])["audio"]
+        eng2.close()
+    finally:
+        del os.environ["MI355VITS_NO_FUSED_MRF"]
+    for b in range(2):
+        L = int(out["lengths"][b])
+        assert rel_rms(fused_audio[b, :L], plain_audio[b, :L]) < 1e-5
+
+
 def test_odd_flow_depth_folds_final_flip(emu_lib):
     cfg = VitsConfig.tiny()
     cfg.flow_n_flows = 3
