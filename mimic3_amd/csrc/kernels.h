@@ -36,6 +36,7 @@ struct ConvArgs {
     // ConvTranspose1d run as a stride-1 conv over `stride` polyphase filters: output channel
     // co' = r * shuf_cout + co of position i lands at y[co][i * shuf_s + r - shuf_p]  (0 <= n < shuf_T)
     int shuf_s = 0, shuf_p = 0, shuf_cout = 0, shuf_T = 0;
+    int vec = 0;  // set by the launcher: input rows are 16-byte aligned -> 16-byte staging loads
 };
 
 // Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).
@@ -80,7 +81,7 @@ struct MrfArgs {
     int nrb = 0;
     const int* len = nullptr;  // [B] rows end at their own length
     int B = 1, C = 0, T = 0;
-    int R = 0, ldx = 0, ld1 = 0;  // filled by the launcher
+    int R = 0, ldx = 0, ld1 = 0, vec = 0;  // filled by the launcher (R = staging halo, rounded up to 4)
 };
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);

@@ -225,7 +225,11 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     const int wm = wid / WN, wn = wid % WN;
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * T_B;
-    const int LD = T_B + (a.K - 1) * a.dil;
+    // staged window starts at ts = floor4(t0 - pad) so that rows can move as aligned 16-byte vectors
+    const int tlo = t0 - a.pad;
+    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
+    const int toff = tlo - ts;  // 0..3
+    const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
     const int n_tiles = (EPI == EPI_GATE) ? 2 * ((a.H + 31) / 32) : (a.Cout + 31) / 32;
     const int tile0 = (blockIdx.y * WM + wm) * MT;
     const int cpairs = a.Cin >> 1;
@@ -244,27 +248,15 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
 
     const int brow = lane >> 5, bcol = lane & 31;
     for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
-        // ---- stage x[c0:c0+CI_C, t0-pad : t0-pad+LD) with mask + leaky-relu fused (coalesced rows)
-        for (int ci = wid; ci < CI_C; ci += 4) {
-            const float* row = xb + (long)(c0 + ci) * a.x_ld;
-            float* dst = xs + ci * LD;
-            for (int tt = lane; tt < LD; tt += 64) {
-                const int t = t0 - a.pad + tt;
-                float v = 0.0f;
-                if (t >= 0 && t < Tin && t < in_len) {
-                    v = row[t];
-                    v = v >= 0.0f ? v : v * a.in_slope;
-                }
-                dst[tt] = v;
-            }
-        }
+        // ---- stage x[c0:c0+CI_C, ts : ts+LD) with mask + leaky-relu fused
+        stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
         __syncthreads();
         // K-loop over (tap, channel pair) with the next step's fragments already in flight (register double
         // buffer): the 64-cycle MFMAs of step s cover the L2/LDS latency of step s+1.
         const int cp0 = c0 >> 1;
         const int cpn = CI_C >> 1;
         const int steps = a.K * cpn;
-        const float* xw = xs + brow * LD + bcol + wn * NT * 32;
+        const float* xw = xs + brow * LD + bcol + wn * NT * 32 + toff;
         float af_n[MT], bf_n[NT];
         MI355_UNROLL
         for (int i = 0; i < MT; ++i) {
@@ -330,7 +322,7 @@ struct TileCfg { int MT, NT, WM, WN; };
 template <int MT, int NT, int WM, int WN, int EPI>
 void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
-    const int LD = T_B + (a.K - 1) * a.dil;
+    const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
     // C_in chunk: fixed by C_in alone (largest even divisor <= 32) so that the summation order — and with it
     // every output bit — does not depend on the tile shape chosen for a batch size; only a receptive field too
     // large for LDS shrinks it further.
@@ -342,7 +334,9 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     const size_t shmem = (size_t)ci_c * LD * sizeof(float);
     dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
     auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI>;
-    LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a, ci_c);
+    ConvArgs av = a;
+    av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
+    LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
 }
 
 }  // namespace

@@ -37,17 +37,7 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
     int len = a.len ? a.len[b] : a.T;
     if (len > a.T) len = a.T;
 
-    {
-        const float* xb = a.x + (long)b * a.x_bs;
-        for (int c = wid; c < C; c += 4) {
-            const float* row = xb + (long)c * a.x_ld;
-            float* dst = X + c * LDX;
-            for (int cx = lane; cx < LDX; cx += 64) {
-                const int t = t0 - R + cx;
-                dst[cx] = (t >= 0 && t < len) ? row[t] : 0.0f;
-            }
-        }
-    }
+    stage_tile_256(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
     __syncthreads();
 
     f32x16 out[NT2];
@@ -70,8 +60,10 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
             const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
             const int steps = K * CP;
             const float* xw = X + brow * LDX + (R - r2 - r1) + bcol;
-            // register double buffer: fragments of step s+1 are in flight while the MFMAs of step s issue
-            float a_nxt = wp[0];
+            // A fragments: 4-deep register ring (L2 latency at one wave per SIMD); B fragments: one step ahead (LDS)
+            float a_ring[4];
+            MI355_UNROLL
+            for (int u = 0; u < 4; ++u) a_ring[u] = wp[(long)u * 64];
             float b_nxt[NT1MAX];
             MI355_UNROLL
             for (int i = 0; i < NT1MAX; ++i) {
@@ -79,25 +71,30 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
                 b_nxt[i] = (q < n1) ? xw[q * 32] : 0.0f;
             }
             int k = 0, cp = 0;
-            for (int s = 0; s < steps; ++s) {
-                const float av = a_nxt;
-                float bv[NT1MAX];
+            for (int s0 = 0; s0 < steps; s0 += 4) {
                 MI355_UNROLL
-                for (int i = 0; i < NT1MAX; ++i) bv[i] = b_nxt[i];
-                if (++cp == CP) { cp = 0; ++k; }
-                if (s + 1 < steps) {
-                    a_nxt = wp[(long)(s + 1) * 64];
-                    const float* xr = xw + (2 * cp) * LDX + k * d1;
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + u;
+                    const float av = a_ring[u];
+                    const int sn = s + 4 < steps ? s + 4 : steps - 1;
+                    a_ring[u] = wp[(long)sn * 64];
+                    float bv[NT1MAX];
+                    MI355_UNROLL
+                    for (int i = 0; i < NT1MAX; ++i) bv[i] = b_nxt[i];
+                    if (++cp == CP) { cp = 0; ++k; }
+                    if (s + 1 < steps) {
+                        const float* xr = xw + (2 * cp) * LDX + k * d1;
+                        MI355_UNROLL
+                        for (int i = 0; i < NT1MAX; ++i) {
+                            const int q = wt + WT * i;
+                            if (q < n1) b_nxt[i] = xr[q * 32];
+                        }
+                    }
                     MI355_UNROLL
                     for (int i = 0; i < NT1MAX; ++i) {
                         const int q = wt + WT * i;
-                        if (q < n1) b_nxt[i] = xr[q * 32];
+                        if (q < n1) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
                     }
-                }
-                MI355_UNROLL
-                for (int i = 0; i < NT1MAX; ++i) {
-                    const int q = wt + WT * i;
-                    if (q < n1) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
                 }
             }
             const float* bias = a.bias[j][0];
@@ -128,25 +125,32 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
             const float* wp = a.w[j][1] + (long)wm * K * CP * 64 + lane;
             const int steps = K * CP;
             const float* xw = X1 + brow * LD1 + bcol + wt * NT2 * 32;
-            float a_nxt = wp[0];
+            float a_ring[4];
+            MI355_UNROLL
+            for (int u = 0; u < 4; ++u) a_ring[u] = wp[(long)u * 64];
             float b_nxt[NT2];
             MI355_UNROLL
             for (int i = 0; i < NT2; ++i) b_nxt[i] = xw[i * 32];
             int k = 0, cp = 0;
-            for (int s = 0; s < steps; ++s) {
-                const float av = a_nxt;
-                float bv[NT2];
+            for (int s0 = 0; s0 < steps; s0 += 4) {
                 MI355_UNROLL
-                for (int i = 0; i < NT2; ++i) bv[i] = b_nxt[i];
-                if (++cp == CP) { cp = 0; ++k; }
-                if (s + 1 < steps) {
-                    a_nxt = wp[(long)(s + 1) * 64];
-                    const float* xr = xw + (2 * cp) * LD1 + k * d2;
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + u;
+                    const float av = a_ring[u];
+                    const int sn = s + 4 < steps ? s + 4 : steps - 1;
+                    a_ring[u] = wp[(long)sn * 64];
+                    float bv[NT2];
                     MI355_UNROLL
-                    for (int i = 0; i < NT2; ++i) b_nxt[i] = xr[i * 32];
+                    for (int i = 0; i < NT2; ++i) bv[i] = b_nxt[i];
+                    if (++cp == CP) { cp = 0; ++k; }
+                    if (s + 1 < steps) {
+                        const float* xr = xw + (2 * cp) * LD1 + k * d2;
+                        MI355_UNROLL
+                        for (int i = 0; i < NT2; ++i) b_nxt[i] = xr[i * 32];
+                    }
+                    MI355_UNROLL
+                    for (int i = 0; i < NT2; ++i) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
                 }
-                MI355_UNROLL
-                for (int i = 0; i < NT2; ++i) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
             }
             const float* bias = a.bias[j][1];
             MI355_UNROLL
@@ -200,7 +204,8 @@ bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int*
         const int n1 = (g.T_B + 2 * r2 + 31) / 32;
         if ((n1 + g.WT - 1) / g.WT > g.NT1MAX) return false;
     }
-    const size_t ldx = (size_t)g.T_B + 2 * R + 32;
+    const int Rp = (R + 3) & ~3;
+    const size_t ldx = (size_t)g.T_B + 2 * Rp + 32;
     const size_t ld1 = (size_t)((g.T_B + 2 * r2max + 31) / 32) * 32;
     return (size_t)C * (ldx + ld1) * sizeof(float) <= LDS_LIMIT;
 }
@@ -216,8 +221,9 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
         R = R > r1 + r2 ? R : r1 + r2;
         r2max = r2max > r2 ? r2max : r2;
     }
-    a.R = R;
-    a.ldx = g.T_B + 2 * R + 32;  // +32: conv1's last (rounded-up) column tile stays inside its row
+    a.R = (R + 3) & ~3;               // staging halo rounded up to 4: the tile starts on a 16-byte boundary
+    a.ldx = g.T_B + 2 * a.R + 32;     // +32: conv1's last (rounded-up) column tile stays inside its row
+    a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     a.ld1 = ((g.T_B + 2 * r2max + 31) / 32) * 32;
     const size_t shmem = (size_t)a.C * (a.ldx + a.ld1) * sizeof(float);
     dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);

@@ -119,7 +119,7 @@ def test_full_size_properties_b8_forced(gpu_lib):
     assert np.array_equal(part["audio"], full["audio"][5:7])
     for b in range(B):
         assert np.array_equal(full["pcm"][b], audio_float_to_int16(full["audio"][b]))
-        assert np.abs(full["pcm"][b]).max() == 32767
+        assert np.abs(full["pcm"][b]).max() >= 32766  # peak * (32767 / peak) may round just below 32767 in fp32
     eng.close()
 
 
@@ -133,5 +133,5 @@ def test_golden_shape_utterance(gpu_lib):
     forced[0, :91] = 6  # 91*6 + 89*5 = 991 frames
     out = eng.run(ids, [Tx], [0, 1, 0], forced_durations=forced, want_pcm16=True)
     assert int(out["lengths"][0]) == 253696
-    assert np.abs(out["pcm"]).max() == 32767
+    assert np.abs(out["pcm"]).max() >= 32766
     eng.close()
