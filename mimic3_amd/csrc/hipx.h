@@ -16,6 +16,7 @@ typedef hipemu_f32x4 f32x4;
     hipemu::launch((kernel), (grid), (block), (size_t)(shmem), __VA_ARGS__)
 #define DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu::tl_worker->dyn_smem)
 #define MI355_UNROLL
+#define WAVE_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,6 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char _dyn_smem_raw[]; \
     type* name = reinterpret_cast<type*>(_dyn_smem_raw)
 #define MI355_UNROLL _Pragma("unroll")
+// value known to be identical in all lanes of a wave: move it to an SGPR so branches on it are scalar
+#define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 #include <cstdint>
@@ -67,7 +70,7 @@ __device__ __forceinline__ float lrelu_f(float v, float slope) { return v >= 0.0
 
 __device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
                                                float slope, float* __restrict__ dst, int vec) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = WAVE_UNIFORM(threadIdx.x >> 6);
     constexpr int RU = 8;
     if (vec) {
         const int ld4 = LD >> 2;

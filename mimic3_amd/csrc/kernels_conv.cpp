@@ -215,13 +215,85 @@ bool conv1d_mfma_supported(int Cin, int Cout, int K, int dil) {
     return Cin >= 2 && (Cin % 2) == 0;
 }
 
+// One C_in chunk of the implicit GEMM for a wave: MT x NT accumulator tiles, K taps x cpn channel pairs.
+// wp[i]: packed A fragments of tile i at (k = 0, first pair of the chunk), lane offset included; record (k, cp)
+// sits (k * cpairs + cp) * 64 floats further.  When the step count is a multiple of 8 the A fragments run through an
+// 8-register ring four steps ahead (no drain at the loop edge); B fragments (LDS) are fetched one step ahead.
+template <int MT, int NT>
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* const (&wp)[MT], const float* __restrict__ xw,
+                                           int LD, int K, int cpn, int cpairs, int dil) {
+    const int steps = K * cpn;
+    float bf_n[NT];
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j) bf_n[j] = xw[j * 32];
+    int k = 0, cp = 0;
+    if ((steps & 7) == 0) {
+        float ring[MT][8];
+        int kp = 0, cpp = 0;  // position of the prefetch stream
+        MI355_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) ring[i][u] = wp[i][(kp * cpairs + cpp) * 64];
+            if (++cpp == cpn) { cpp = 0; ++kp; }
+        }
+        for (int s0 = 0; s0 < steps; s0 += 8) {
+            MI355_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + u;
+                float af[MT], bf[NT];
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) af[i] = ring[i][u];
+                const int off = (kp < K ? kp * cpairs + cpp : (K - 1) * cpairs + cpn - 1) * 64;  // tail: harmless re-read
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) ring[i][(u + 4) & 7] = wp[i][off];
+                if (++cpp == cpn) { cpp = 0; ++kp; }
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) bf[j] = bf_n[j];
+                if (++cp == cpn) { cp = 0; ++k; }
+                if (s + 1 < steps) {
+                    const float* xr = xw + (2 * cp) * LD + k * dil;
+                    MI355_UNROLL
+                    for (int j = 0; j < NT; ++j) bf_n[j] = xr[j * 32];
+                }
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i)
+                    MI355_UNROLL
+                    for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
+            }
+        }
+    } else {
+        float af_n[MT];
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i) af_n[i] = wp[i][0];
+        for (int s = 0; s < steps; ++s) {
+            float af[MT], bf[NT];
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) af[i] = af_n[i];
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) bf[j] = bf_n[j];
+            if (++cp == cpn) { cp = 0; ++k; }
+            if (s + 1 < steps) {
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) af_n[i] = wp[i][(k * cpairs + cp) * 64];
+                const float* xr = xw + (2 * cp) * LD + k * dil;
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) bf_n[j] = xr[j * 32];
+            }
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
+        }
+    }
+}
+
 template <int MT, int NT, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
     DYN_SMEM(float, xs);  // [CI_C][LD]
     constexpr int T_B = 32 * NT * WN;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * T_B;
@@ -251,42 +323,15 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
         // ---- stage x[c0:c0+CI_C, ts : ts+LD) with mask + leaky-relu fused
         stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
         __syncthreads();
-        // K-loop over (tap, channel pair) with the next step's fragments already in flight (register double
-        // buffer): the 64-cycle MFMAs of step s cover the L2/LDS latency of step s+1.
-        const int cp0 = c0 >> 1;
-        const int cpn = CI_C >> 1;
-        const int steps = a.K * cpn;
-        const float* xw = xs + brow * LD + bcol + wn * NT * 32 + toff;
-        float af_n[MT], bf_n[NT];
-        MI355_UNROLL
-        for (int i = 0; i < MT; ++i) {
-            const int tile = tile0 + i;
-            af_n[i] = (tile < n_tiles) ? a.w[(((long)tile * a.K) * cpairs + cp0) * 64 + lane] : 0.0f;
-        }
-        MI355_UNROLL
-        for (int j = 0; j < NT; ++j) bf_n[j] = xw[j * 32];
-        int k = 0, cp = 0;
-        for (int s = 0; s < steps; ++s) {
-            float af[MT], bf[NT];
+        {
+            const float* wp[MT];
             MI355_UNROLL
-            for (int i = 0; i < MT; ++i) af[i] = af_n[i];
-            MI355_UNROLL
-            for (int j = 0; j < NT; ++j) bf[j] = bf_n[j];
-            if (++cp == cpn) { cp = 0; ++k; }
-            if (s + 1 < steps) {
-                MI355_UNROLL
-                for (int i = 0; i < MT; ++i) {
-                    const int tile = tile0 + i;
-                    af_n[i] = (tile < n_tiles) ? a.w[(((long)tile * a.K + k) * cpairs + cp0 + cp) * 64 + lane] : 0.0f;
-                }
-                const float* xr = xw + (2 * cp) * LD + k * a.dil;
-                MI355_UNROLL
-                for (int j = 0; j < NT; ++j) bf_n[j] = xr[j * 32];
+            for (int i = 0; i < MT; ++i) {
+                int tile = tile0 + i;
+                if (tile >= n_tiles) tile = n_tiles - 1;  // out-of-range tile: recompute the last one, discarded below
+                wp[i] = a.w + ((long)tile * a.K * cpairs + (c0 >> 1)) * 64 + lane;
             }
-            MI355_UNROLL
-            for (int i = 0; i < MT; ++i)
-                MI355_UNROLL
-                for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
+            mfma_chunk<MT, NT>(acc, wp, xs + brow * LD + bcol + wn * NT * 32 + toff, LD, a.K, CI_C >> 1, cpairs, a.dil);
         }
         __syncthreads();
     }

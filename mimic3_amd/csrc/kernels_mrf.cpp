@@ -19,9 +19,73 @@
 
 namespace m355 {
 
+// One wave's share of a conv on the matrix cores: NTL column tiles (32 columns each, `tstride` floats apart in the
+// LDS tile), all of the wave's 32 output channels, K taps x CP channel pairs.  A fragments: 8-register ring, four
+// steps ahead (L2 latency at one wave per SIMD, no register copies at the loop edge); B fragments: one step ahead.
+template <int NTL, int CP>
+__device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NTL], const float* __restrict__ wp, const float* __restrict__ xw,
+                                                int tstride, int LD, int K, int dil) {
+    const int steps = K * CP;  // multiple of 8 (CP >= 16)
+    float a_ring[8];
+    MI355_UNROLL
+    for (int u = 0; u < 4; ++u) a_ring[u] = wp[(long)u * 64];
+    float b_nxt[NTL];
+    MI355_UNROLL
+    for (int i = 0; i < NTL; ++i) b_nxt[i] = xw[i * tstride];
+    int k = 0, cp = 0;
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+        MI355_UNROLL
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + u;
+            const float av = a_ring[u];
+            const int sn = s + 4 < steps ? s + 4 : steps - 1;
+            a_ring[(u + 4) & 7] = wp[(long)sn * 64];
+            float bv[NTL];
+            MI355_UNROLL
+            for (int i = 0; i < NTL; ++i) bv[i] = b_nxt[i];
+            if (++cp == CP) { cp = 0; ++k; }
+            if (s + 1 < steps) {
+                const float* xr = xw + (2 * cp) * LD + k * dil;
+                MI355_UNROLL
+                for (int i = 0; i < NTL; ++i) b_nxt[i] = xr[i * tstride];
+            }
+            MI355_UNROLL
+            for (int i = 0; i < NTL; ++i) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
+        }
+    }
+}
+
+// conv1 of a resblock for a wave that owns NTL column tiles q = wt + WT*i of the extended range:
+// x1 = x + conv(lrelu(x)) + bias, zero outside the row, written to the X1 tile.
+template <int NTL, int CP, int WT>
+__device__ __forceinline__ void mrf_conv1(const float* __restrict__ wp, const float* __restrict__ bias, const float* X,
+                                          float* X1, int LDX, int LD1, int R, int r1, int r2, int K, int d1, int wm,
+                                          int wt, int brow, int bcol, int t0, int len) {
+    f32x16 acc[NTL];
+    MI355_UNROLL
+    for (int i = 0; i < NTL; ++i)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const float* xw = X + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
+    mfma_conv_tiles<NTL, CP>(acc, wp, xw, WT * 32, LDX, K, d1);
+    MI355_UNROLL
+    for (int i = 0; i < NTL; ++i) {
+        const int e = (wt + WT * i) * 32 + bcol;
+        const int t = t0 - r2 + e;
+        const bool live = t >= 0 && t < len;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            const float v = X[co * LDX + (R - r2) + e] + acc[i][r] + bias[co];
+            X1[co * LD1 + e] = live ? v : 0.0f;
+        }
+    }
+}
+
 template <int WM, int WT, int NT2, int NT1MAX>
 __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 4, "4 waves per workgroup");
+    static_assert(NT1MAX <= 5, "dispatch below covers up to 5 conv1 tiles per wave");
     constexpr int C = 32 * WM;
     constexpr int T_B = 32 * NT2 * WT;
     constexpr int CP = C / 2;
@@ -29,7 +93,7 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
     const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
     float* X = smem;             // [C][LDX]  raw x, zero outside the row
     float* X1 = smem + C * LDX;  // [C][LD1]  x1 of the current resblock, zero outside the row
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
     const int wm = wid / WT, wt = wid % WT;
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.y;
@@ -52,67 +116,16 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
         const int n1 = (T_B + 2 * r2 + 31) / 32;  // conv1 column tiles: extended column e <-> t = t0 - r2 + e
         // ------------------------------------------------------------ conv1: x1 = x + conv(lrelu(x)) -> LDS
         {
-            f32x16 acc[NT1MAX];
-            MI355_UNROLL
-            for (int i = 0; i < NT1MAX; ++i)
-                MI355_UNROLL
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
             const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
-            const int steps = K * CP;
-            const float* xw = X + brow * LDX + (R - r2 - r1) + bcol;
-            // A fragments: 4-deep register ring (L2 latency at one wave per SIMD); B fragments: one step ahead (LDS)
-            float a_ring[4];
-            MI355_UNROLL
-            for (int u = 0; u < 4; ++u) a_ring[u] = wp[(long)u * 64];
-            float b_nxt[NT1MAX];
-            MI355_UNROLL
-            for (int i = 0; i < NT1MAX; ++i) {
-                const int q = wt + WT * i;
-                b_nxt[i] = (q < n1) ? xw[q * 32] : 0.0f;
-            }
-            int k = 0, cp = 0;
-            for (int s0 = 0; s0 < steps; s0 += 4) {
-                MI355_UNROLL
-                for (int u = 0; u < 4; ++u) {
-                    const int s = s0 + u;
-                    const float av = a_ring[u];
-                    const int sn = s + 4 < steps ? s + 4 : steps - 1;
-                    a_ring[u] = wp[(long)sn * 64];
-                    float bv[NT1MAX];
-                    MI355_UNROLL
-                    for (int i = 0; i < NT1MAX; ++i) bv[i] = b_nxt[i];
-                    if (++cp == CP) { cp = 0; ++k; }
-                    if (s + 1 < steps) {
-                        const float* xr = xw + (2 * cp) * LDX + k * d1;
-                        MI355_UNROLL
-                        for (int i = 0; i < NT1MAX; ++i) {
-                            const int q = wt + WT * i;
-                            if (q < n1) b_nxt[i] = xr[q * 32];
-                        }
-                    }
-                    MI355_UNROLL
-                    for (int i = 0; i < NT1MAX; ++i) {
-                        const int q = wt + WT * i;
-                        if (q < n1) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
-                    }
-                }
-            }
             const float* bias = a.bias[j][0];
-            MI355_UNROLL
-            for (int i = 0; i < NT1MAX; ++i) {
-                const int q = wt + WT * i;
-                if (q < n1) {
-                    const int e = q * 32 + bcol;
-                    const int t = t0 - r2 + e;
-                    const bool live = t >= 0 && t < len;
-                    MI355_UNROLL
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                        const float v = X[co * LDX + (R - r2) + e] + acc[i][r] + bias[co];
-                        X1[co * LD1 + e] = live ? v : 0.0f;
-                    }
-                }
-            }
+            const int nt1 = (n1 - wt + WT - 1) / WT;  // tiles of this wave (wave-uniform): static-count code paths
+#define MRF_CONV1(N) mrf_conv1<N, CP, WT>(wp, bias, X, X1, LDX, LD1, R, r1, r2, K, d1, wm, wt, brow, bcol, t0, len)
+            if (nt1 >= 5) { if (NT1MAX >= 5) MRF_CONV1((NT1MAX >= 5 ? 5 : 1)); }
+            else if (nt1 == 4) MRF_CONV1(4);
+            else if (nt1 == 3) MRF_CONV1(3);
+            else if (nt1 == 2) MRF_CONV1(2);
+            else if (nt1 == 1) MRF_CONV1(1);
+#undef MRF_CONV1
         }
         __syncthreads();
         // ------------------------------------------------------------ conv2: out += x1 + conv(lrelu(x1))
@@ -123,35 +136,8 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
             const float* wp = a.w[j][1] + (long)wm * K * CP * 64 + lane;
-            const int steps = K * CP;
             const float* xw = X1 + brow * LD1 + bcol + wt * NT2 * 32;
-            float a_ring[4];
-            MI355_UNROLL
-            for (int u = 0; u < 4; ++u) a_ring[u] = wp[(long)u * 64];
-            float b_nxt[NT2];
-            MI355_UNROLL
-            for (int i = 0; i < NT2; ++i) b_nxt[i] = xw[i * 32];
-            int k = 0, cp = 0;
-            for (int s0 = 0; s0 < steps; s0 += 4) {
-                MI355_UNROLL
-                for (int u = 0; u < 4; ++u) {
-                    const int s = s0 + u;
-                    const float av = a_ring[u];
-                    const int sn = s + 4 < steps ? s + 4 : steps - 1;
-                    a_ring[u] = wp[(long)sn * 64];
-                    float bv[NT2];
-                    MI355_UNROLL
-                    for (int i = 0; i < NT2; ++i) bv[i] = b_nxt[i];
-                    if (++cp == CP) { cp = 0; ++k; }
-                    if (s + 1 < steps) {
-                        const float* xr = xw + (2 * cp) * LD1 + k * d2;
-                        MI355_UNROLL
-                        for (int i = 0; i < NT2; ++i) b_nxt[i] = xr[i * 32];
-                    }
-                    MI355_UNROLL
-                    for (int i = 0; i < NT2; ++i) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
-                }
-            }
+            mfma_conv_tiles<NT2, CP>(acc, wp, xw, 32, LD1, K, d2);
             const float* bias = a.bias[j][1];
             MI355_UNROLL
             for (int i = 0; i < NT2; ++i) {
