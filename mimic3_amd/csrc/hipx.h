@@ -60,7 +60,7 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cooperative global -> LDS staging of a [rows][LD] activation tile (256 threads = 4 waves).
+// Cooperative global -> LDS staging of a [rows][LD] activation tile by the NW waves of a workgroup.
 //   dst[r*LD + c] = f(x[r*x_ld + ts + c])  for ts + c in [0, tend), else 0;   f = leaky-relu(slope) (1 = identity)
 // Waves take rows round-robin; a wave issues the loads of up to 8 rows before the first LDS write, so a tile
 // costs a handful of memory round trips even with one wave per SIMD.  With `vec` (rows 16-byte aligned, ts and
@@ -68,20 +68,21 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v >= 0.0f ? v : v * slope; }
 
-__device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
-                                               float slope, float* __restrict__ dst, int vec) {
+template <int NW>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
+                                           float slope, float* __restrict__ dst, int vec) {
     const int lane = threadIdx.x & 63, wid = WAVE_UNIFORM(threadIdx.x >> 6);
-    constexpr int RU = 8;
+    constexpr int RU = 32 / NW;  // 8 rows in flight per wave with 4 waves, 4 with 8 waves
     if (vec) {
         const int ld4 = LD >> 2;
         for (int c4 = lane; c4 < ld4; c4 += 64) {
             const int t = ts + 4 * c4;
             const bool inner = t >= 0 && t + 3 < tend;
-            for (int r0 = wid; r0 < rows; r0 += 4 * RU) {
+            for (int r0 = wid; r0 < rows; r0 += NW * RU) {
                 float4 v[RU];
                 MI355_UNROLL
                 for (int u = 0; u < RU; ++u) {
-                    const int r = r0 + 4 * u;
+                    const int r = r0 + NW * u;
                     v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     if (r < rows) {
                         const float* row = xb + (long)r * x_ld;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, lon
                 }
                 MI355_UNROLL
                 for (int u = 0; u < RU; ++u) {
-                    const int r = r0 + 4 * u;
+                    const int r = r0 + NW * u;
                     if (r < rows) {
                         float4 o = v[u];
                         o.x = lrelu_f(o.x, slope); o.y = lrelu_f(o.y, slope); o.z = lrelu_f(o.z, slope); o.w = lrelu_f(o.w, slope);
@@ -110,19 +111,24 @@ __device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, lon
         for (int c = lane; c < LD; c += 64) {
             const int t = ts + c;
             const bool ok = t >= 0 && t < tend;
-            for (int r0 = wid; r0 < rows; r0 += 4 * RU) {
+            for (int r0 = wid; r0 < rows; r0 += NW * RU) {
                 float v[RU];
                 MI355_UNROLL
                 for (int u = 0; u < RU; ++u) {
-                    const int r = r0 + 4 * u;
+                    const int r = r0 + NW * u;
                     v[u] = (ok && r < rows) ? xb[(long)r * x_ld + t] : 0.0f;
                 }
                 MI355_UNROLL
                 for (int u = 0; u < RU; ++u) {
-                    const int r = r0 + 4 * u;
+                    const int r = r0 + NW * u;
                     if (r < rows) dst[(long)r * LD + c] = lrelu_f(v[u], slope);
                 }
             }
         }
     }
+}
+
+__device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
+                                               float slope, float* __restrict__ dst, int vec) {
+    stage_tile<4>(xb, x_ld, rows, LD, ts, tend, slope, dst, vec);
 }

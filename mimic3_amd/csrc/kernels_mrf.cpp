@@ -20,11 +20,13 @@
 namespace m355 {
 
 // One wave's share of a conv on the matrix cores: NTL column tiles (32 columns each, `tstride` floats apart in the
-// LDS tile), all of the wave's 32 output channels, K taps x CP channel pairs.  A fragments: 8-register ring, four
-// steps ahead (L2 latency at one wave per SIMD, no register copies at the loop edge); B fragments: one step ahead.
-template <int NTL, int CP>
-__device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NTL], const float* __restrict__ wp, const float* __restrict__ xw,
+// LDS tile), all of the wave's 32 output channels, K taps x CP channel pairs, accumulated INTO acc (callers preload
+// bias / residual there).  A fragments: 8-register ring, four steps ahead (L2 latency, no register copies at the loop
+// edge); B fragments: one step ahead; leaky-relu applied as the fragment is consumed.
+template <int NTL, int NA, int CP>
+__device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float* __restrict__ wp, const float* __restrict__ xw,
                                                 int tstride, int LD, int K, int dil) {
+    static_assert(NTL <= NA, "tile count");
     const int steps = K * CP;  // multiple of 8 (CP >= 16)
     float a_ring[8];
     MI355_UNROLL
@@ -56,18 +58,27 @@ __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NTL], const float*
 }
 
 // conv1 of a resblock for a wave that owns NTL column tiles q = wt + WT*i of the extended range:
-// x1 = x + conv(lrelu(x)) + bias, zero outside the row, written to the X1 tile.
+// x1 = x + bias + conv(lrelu(x)), zero outside the row, written to the X1 tile.  The residual and the bias are
+// loaded into the accumulators up front, so the epilogue is a masked LDS store.
 template <int NTL, int CP, int WT>
 __device__ __forceinline__ void mrf_conv1(const float* __restrict__ wp, const float* __restrict__ bias, const float* X,
                                           float* X1, int LDX, int LD1, int R, int r1, int r2, int K, int d1, int wm,
                                           int wt, int brow, int bcol, int t0, int len) {
     f32x16 acc[NTL];
+    float bs[16];
     MI355_UNROLL
-    for (int i = 0; i < NTL; ++i)
+    for (int r = 0; r < 16; ++r) bs[r] = bias[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow];
+    MI355_UNROLL
+    for (int i = 0; i < NTL; ++i) {
+        const int e = (wt + WT * i) * 32 + bcol;
         MI355_UNROLL
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            acc[i][r] = X[co * LDX + (R - r2) + e] + bs[r];
+        }
+    }
     const float* xw = X + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
-    mfma_conv_tiles<NTL, CP>(acc, wp, xw, WT * 32, LDX, K, d1);
+    mfma_conv_tiles<NTL, NTL, CP>(acc, wp, xw, WT * 32, LDX, K, d1);
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
         const int e = (wt + WT * i) * 32 + bcol;
@@ -76,87 +87,94 @@ __device__ __forceinline__ void mrf_conv1(const float* __restrict__ wp, const fl
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            const float v = X[co * LDX + (R - r2) + e] + acc[i][r] + bias[co];
-            X1[co * LD1 + e] = live ? v : 0.0f;
+            X1[co * LD1 + e] = live ? acc[i][r] : 0.0f;
         }
     }
 }
 
-template <int WM, int WT, int NT2, int NT1MAX>
-__global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
-    static_assert(WM * WT == 4, "4 waves per workgroup");
-    static_assert(NT1MAX <= 5, "dispatch below covers up to 5 conv1 tiles per wave");
+// conv2 for a wave that owns NTL output tiles p = wt + WT*i:  out += x1 + bias + conv(lrelu(x1)), accumulated
+// straight into the wave's persistent output registers (no epilogue).
+template <int NTL, int NA, int CP, int WT>
+__device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __restrict__ wp, const float* __restrict__ bias,
+                                          const float* X1, int LD1, int r2, int K, int d2, int wm, int wt, int brow, int bcol) {
+    float bs[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) bs[r] = bias[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow];
+    MI355_UNROLL
+    for (int i = 0; i < NTL; ++i) {
+        const int c0 = (wt + WT * i) * 32 + bcol;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            out[i][r] += X1[co * LD1 + c0 + r2] + bs[r];
+        }
+    }
+    const float* xw = X1 + brow * LD1 + bcol + wt * 32;
+    mfma_conv_tiles<NTL, NA, CP>(out, wp, xw, WT * 32, LD1, K, d2);
+}
+
+// WM x WT = 8 waves (two per SIMD: one wave's LDS epilogue / barrier wait overlaps its partner's MFMA stream).
+// Output tile T_B = 32 * N2 columns; column tiles of both convs are dealt round-robin to the WT time waves.
+template <int WM, int WT, int N2, int NT1MAX, int NT2MAX>
+__global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
+    static_assert(WM * WT == 8, "8 waves per workgroup");
+    static_assert(NT1MAX <= 3 && NT2MAX <= 2, "static dispatch below");
     constexpr int C = 32 * WM;
-    constexpr int T_B = 32 * NT2 * WT;
+    constexpr int T_B = 32 * N2;
     constexpr int CP = C / 2;
     DYN_SMEM(float, smem);
     const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
     float* X = smem;             // [C][LDX]  raw x, zero outside the row
     float* X1 = smem + C * LDX;  // [C][LD1]  x1 of the current resblock, zero outside the row
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
-    const int wm = wid / WT, wt = wid % WT;
+    // waves w and w+4 share a SIMD: give them complementary tile counts (wt < WT/2 gets the extra tile)
+    const int wm = (WM == 1) ? 0 : ((wid >> 1) & 1);
+    const int wt = (WM == 1) ? wid : ((wid >> 2) * 2 + (wid & 1));
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * T_B;
     int len = a.len ? a.len[b] : a.T;
     if (len > a.T) len = a.T;
 
-    stage_tile_256(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
+    stage_tile<8>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
     __syncthreads();
 
-    f32x16 out[NT2];
+    f32x16 out[NT2MAX];
     MI355_UNROLL
-    for (int i = 0; i < NT2; ++i)
+    for (int i = 0; i < NT2MAX; ++i)
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) out[i][r] = 0.0f;
+    const int nt2 = (N2 - wt + WT - 1) / WT;  // output tiles of this wave (wave-uniform)
 
     for (int j = 0; j < a.nrb; ++j) {
         const int K = a.k[j], d1 = a.d1[j], d2 = a.d2[j];
         const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
         const int n1 = (T_B + 2 * r2 + 31) / 32;  // conv1 column tiles: extended column e <-> t = t0 - r2 + e
-        // ------------------------------------------------------------ conv1: x1 = x + conv(lrelu(x)) -> LDS
         {
             const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
             const float* bias = a.bias[j][0];
-            const int nt1 = (n1 - wt + WT - 1) / WT;  // tiles of this wave (wave-uniform): static-count code paths
+            const int nt1 = n1 > wt ? (n1 - wt + WT - 1) / WT : 0;
 #define MRF_CONV1(N) mrf_conv1<N, CP, WT>(wp, bias, X, X1, LDX, LD1, R, r1, r2, K, d1, wm, wt, brow, bcol, t0, len)
-            if (nt1 >= 5) { if (NT1MAX >= 5) MRF_CONV1((NT1MAX >= 5 ? 5 : 1)); }
-            else if (nt1 == 4) MRF_CONV1(4);
-            else if (nt1 == 3) MRF_CONV1(3);
-            else if (nt1 == 2) MRF_CONV1(2);
+            if (nt1 >= 3) { if (NT1MAX >= 3) MRF_CONV1((NT1MAX >= 3 ? 3 : 1)); }
+            else if (nt1 == 2) { if (NT1MAX >= 2) MRF_CONV1((NT1MAX >= 2 ? 2 : 1)); }
             else if (nt1 == 1) MRF_CONV1(1);
 #undef MRF_CONV1
         }
         __syncthreads();
-        // ------------------------------------------------------------ conv2: out += x1 + conv(lrelu(x1))
         {
-            f32x16 acc[NT2];
-            MI355_UNROLL
-            for (int i = 0; i < NT2; ++i)
-                MI355_UNROLL
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
             const float* wp = a.w[j][1] + (long)wm * K * CP * 64 + lane;
-            const float* xw = X1 + brow * LD1 + bcol + wt * NT2 * 32;
-            mfma_conv_tiles<NT2, CP>(acc, wp, xw, 32, LD1, K, d2);
             const float* bias = a.bias[j][1];
-            MI355_UNROLL
-            for (int i = 0; i < NT2; ++i) {
-                const int c0 = (wt * NT2 + i) * 32 + bcol;
-                MI355_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                    out[i][r] += X1[co * LD1 + c0 + r2] + acc[i][r] + bias[co];
-                }
-            }
+            if (nt2 >= 2) { if (NT2MAX >= 2) mrf_conv2<(NT2MAX >= 2 ? 2 : 1), NT2MAX, CP, WT>(out, wp, bias, X1, LD1, r2, K, d2, wm, wt, brow, bcol); }
+            else if (nt2 == 1) mrf_conv2<1, NT2MAX, CP, WT>(out, wp, bias, X1, LD1, r2, K, d2, wm, wt, brow, bcol);
         }
         __syncthreads();
     }
 
     const float n = (float)a.nrb;
     MI355_UNROLL
-    for (int i = 0; i < NT2; ++i) {
-        const int t = t0 + (wt * NT2 + i) * 32 + bcol;
-        if (t < a.T) {
+    for (int i = 0; i < NT2MAX; ++i) {
+        const int t = t0 + (wt + WT * i) * 32 + bcol;
+        if (i < nt2 && t < a.T) {
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
@@ -167,12 +185,11 @@ __global__ __launch_bounds__(256) void k_mrf_fused(MrfArgs a) {
 }
 
 namespace {
-// geometry per channel count: (WM, WT, NT2, NT1MAX)
-//   C = 32: 1 x 4 waves, T_B = 512;  C = 64: 2 x 2 waves, T_B = 192
+// geometry per channel count:  C = 32: 1 x 8 waves, T_B = 512 (16 tiles, 2 per wave);  C = 64: 2 x 4 waves, T_B = 192
 struct Geo { int C, T_B, WT, NT1MAX; };
 inline bool geometry(int C, Geo* g) {
-    if (C == 32) { *g = {32, 512, 4, 5}; return true; }
-    if (C == 64) { *g = {64, 192, 2, 5}; return true; }
+    if (C == 32) { *g = {32, 512, 8, 3}; return true; }
+    if (C == 64) { *g = {64, 192, 4, 3}; return true; }
     return false;
 }
 constexpr size_t LDS_LIMIT = 160 * 1024;
@@ -209,24 +226,24 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     }
     a.R = (R + 3) & ~3;               // staging halo rounded up to 4: the tile starts on a 16-byte boundary
     a.ldx = g.T_B + 2 * a.R + 32;     // +32: conv1's last (rounded-up) column tile stays inside its row
-    a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     a.ld1 = ((g.T_B + 2 * r2max + 31) / 32) * 32;
+    a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     const size_t shmem = (size_t)a.C * (a.ldx + a.ld1) * sizeof(float);
     dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
     if (a.C == 32) {
-        auto kfn = k_mrf_fused<1, 4, 4, 5>;
+        auto kfn = k_mrf_fused<1, 8, 16, 3, 2>;
 #ifndef MI355_EMU
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT), true);
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         (void)once;
 #endif
-        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+        LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     } else {
-        auto kfn = k_mrf_fused<2, 2, 3, 5>;
+        auto kfn = k_mrf_fused<2, 4, 6, 3, 2>;
 #ifndef MI355_EMU
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT), true);
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         (void)once;
 #endif
-        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+        LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     }
 }
 
