@@ -545,8 +545,12 @@ void Engine::text_encoder(int B, int Tx) {
         {
             const double fl = 4.0 * B * (double)Tx * Tx * H;
             ProfScope ps(prof_, "enc.attention", fl, 4.0 * B * 4 * H * Tx);
-            launch_rel_attention(d_qkv_, vec(a + ".emb_rel_k"), vec(a + ".emb_rel_v"), d_len_, B, Tx, H, c.n_heads,
-                                 c.window_size, d_att_, stream_);
+            if (!force_generic_ && rel_attention_mfma_supported(Tx, H, c.n_heads, c.window_size))
+                launch_rel_attention_mfma(d_qkv_, vec(a + ".emb_rel_k"), vec(a + ".emb_rel_v"), d_len_, B, Tx, H, c.n_heads,
+                                          c.window_size, d_att_, stream_);
+            else
+                launch_rel_attention(d_qkv_, vec(a + ".emb_rel_k"), vec(a + ".emb_rel_v"), d_len_, B, Tx, H, c.n_heads,
+                                     c.window_size, d_att_, stream_);
         }
         ConvArgs o;
         o.x = d_att_; o.x_bs = xbs; o.x_ld = Tx;

@@ -112,6 +112,10 @@ void launch_layernorm(const LNArgs& a, hipStream_t s);
 // relative-position multi-head attention on packed qkv [B, 3H, T] -> out [B, H, T]
 void launch_rel_attention(const float* qkv, const float* emb_rel_k, const float* emb_rel_v, const int* len,
                           int B, int T, int H, int n_heads, int window, float* out, hipStream_t s);
+// same contract on the fp32 matrix cores (one wave per 32 query rows; T <= 512, window <= 15), see kernels_attn.cpp
+bool rel_attention_mfma_supported(int T, int H, int n_heads, int window);
+void launch_rel_attention_mfma(const float* qkv, const float* emb_rel_k, const float* emb_rel_v, const int* len,
+                               int B, int T, int H, int n_heads, int window, float* out, hipStream_t s);
 
 // ---------------------------------------------------------------- stochastic duration predictor pieces
 // y = gelu(LN(dwconv_k,d(x * mask)))   (first half of a DDS layer, A.6)

@@ -1,0 +1,161 @@
+// kernels_attn.cpp — relative-position multi-head attention on the fp32 matrix cores.
+//
+//   s[i,j] = (q_i/sqrt(d)) . k_j + [|j-i|<=W] (q_i/sqrt(d)) . E_k[j-i+W];  masked -> -1e4;  p = softmax_j s
+//   o_i    = sum_j p[i,j] v_j + sum_{|j-i|<=W} p[i,j] E_v[j-i+W]
+//
+// One wave owns 32 query rows of one (batch, head) and computes the TRANSPOSED score tile S^T[j][i] = K Q^T with
+// v_mfma_f32_32x32x2_f32: in the C/D layout a lane then holds one query column i = lane&31 and 16 key rows per key
+// tile, so the softmax statistics are in-lane reductions plus one cross-half shuffle, and P^T is directly the B
+// operand of the second product O^T[c][i] = V P^T — the probabilities never leave registers (the MFMA k index is
+// permuted to "the rows this lane half already holds": k-step (g,m) uses key row 8g+m for lanes 0-31 and 8g+4+m for
+// lanes 32-63; V is read with the same permutation).  Both operands of K Q^T are read straight from the [C,T]
+// activation layout: 32 consecutive time samples per half-wave (128-byte segments).  The window terms are two tiny
+// extra products: (q E_k^T) as a 32-row padded MFMA whose result goes through a 1 KiB LDS table, and E_v^T p_rel with
+// the near-diagonal probabilities gathered in the same table.
+#include "kernels.h"
+
+namespace m355 {
+
+template <int NKT>  // key tiles of 32 held in registers: T <= 32 * NKT
+__global__ __launch_bounds__(64) void k_rel_attention_mfma(const float* __restrict__ qkv, const float* __restrict__ ek,
+                                                           const float* __restrict__ ev, const int* __restrict__ len,
+                                                           int T, int H, int nh, int W, float* __restrict__ out) {
+    DYN_SMEM(float, tab);  // [32][32]: rows 0..2W hold the window table (first rel-k logits, later rel probabilities)
+    const int lane = threadIdx.x & 63;
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int d = H / nh, nrel = 2 * W + 1;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int i0 = blockIdx.x * 32;
+    const int i = i0 + bcol;  // this lane's query
+    const int L = len[b];
+    const float scale = 1.0f / sqrtf((float)d);
+    const float* qb = qkv + ((long)b * 3 * H + h * d) * T;
+    const float* kb = qb + (long)H * T;
+    const float* vb = qb + (long)2 * H * T;
+    const bool iq = i < T;
+
+    // ---- S^T = K Q^T (+ rel-k logits as a 32-row padded product with E_k)
+    f32x16 st[NKT];
+    f32x16 rl;
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) rl[r] = 0.0f;
+    MI355_UNROLL
+    for (int t = 0; t < NKT; ++t)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) st[t][r] = 0.0f;
+    for (int cp = 0; cp < d / 2; ++cp) {
+        const int c = 2 * cp + brow;
+        const float qv = iq ? qb[(long)c * T + i] * scale : 0.0f;         // B[k=c][col=i]
+        const float ekv = bcol < nrel ? ek[bcol * d + c] : 0.0f;          // A[row=r][k=c]
+        rl = MFMA_32x32x2_F32(ekv, qv, rl);
+        MI355_UNROLL
+        for (int t = 0; t < NKT; ++t) {
+            const int j = t * 32 + bcol;
+            const float kv = j < T ? kb[(long)c * T + j] : 0.0f;          // A[row=j][k=c]
+            st[t] = MFMA_32x32x2_F32(kv, qv, st[t]);
+        }
+    }
+    // rel-k logits -> LDS table [r][i]
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * brow;
+        tab[row * 32 + bcol] = rl[r];
+    }
+    __syncthreads();
+
+    // ---- window bias, masks, softmax statistics (per query column, i.e. per lane pair)
+    float mx = -3.0e38f;
+    MI355_UNROLL
+    for (int t = 0; t < NKT; ++t) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            float sc = st[t][r];
+            const int rel = j - i;
+            if (rel >= -W && rel <= W) sc += tab[(rel + W) * 32 + bcol];
+            if (j >= L || i >= L) sc = -1e4f;
+            if (j >= T) sc = -3.0e38f;  // beyond the tensor: not part of the softmax at all
+            st[t][r] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    __syncthreads();  // everyone has read the logits table; it is reused for the rel probabilities
+    for (int r = brow; r < 32; r += 2) tab[r * 32 + bcol] = 0.0f;
+    __syncthreads();
+    float sum = 0.0f;
+    MI355_UNROLL
+    for (int t = 0; t < NKT; ++t) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            const float e = j < T ? expf(st[t][r] - mx) : 0.0f;
+            st[t][r] = e;
+            sum += e;
+            const int rel = j - i;
+            if (j < T && rel >= -W && rel <= W) tab[(rel + W) * 32 + bcol] = e;
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+
+    // ---- O^T[c][i] = sum_j V[c][j] P^T[j][i] + sum_r E_v[r][c] p_rel[r][i]
+    for (int c0 = 0; c0 < d; c0 += 32) {
+        f32x16 o;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+        const int cr = c0 + bcol;  // A row of this lane
+        const bool cv = cr < d;
+        const float* vr = vb + (long)(cv ? cr : 0) * T;
+        MI355_UNROLL
+        for (int t = 0; t < NKT; ++t) {
+            MI355_UNROLL
+            for (int g = 0; g < 4; ++g) {
+                MI355_UNROLL
+                for (int m = 0; m < 4; ++m) {
+                    const int j = t * 32 + 8 * g + 4 * brow + m;  // the key row this lane half holds in register 4g+m
+                    const float vv = (cv && j < T) ? vr[j] : 0.0f;
+                    o = MFMA_32x32x2_F32(vv, st[t][4 * g + m], o);
+                }
+            }
+        }
+        for (int s = 0; s < (nrel + 1) / 2; ++s) {
+            const int r = 2 * s + brow;
+            const float evv = (cv && r < nrel) ? ev[r * d + cr] : 0.0f;
+            const float pv = r < nrel ? tab[r * 32 + bcol] : 0.0f;
+            o = MFMA_32x32x2_F32(evv, pv, o);
+        }
+        if (iq) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                if (c < d) out[((long)b * H + h * d + c) * T + i] = o[r] * inv;
+            }
+        }
+    }
+}
+
+bool rel_attention_mfma_supported(int T, int H, int n_heads, int window) {
+    const int d = H / n_heads;
+    return T >= 1 && T <= 512 && (d % 2) == 0 && window >= 0 && 2 * window + 1 <= 32;
+}
+
+void launch_rel_attention_mfma(const float* qkv, const float* emb_rel_k, const float* emb_rel_v, const int* len, int B,
+                               int T, int H, int n_heads, int window, float* out, hipStream_t s) {
+    if (!rel_attention_mfma_supported(T, H, n_heads, window)) throw std::runtime_error("rel_attention_mfma: unsupported shape");
+    dim3 grid((T + 31) / 32, n_heads, B);
+    const size_t shmem = 32 * 32 * sizeof(float);
+    if (T <= 128) {
+        auto k = k_rel_attention_mfma<4>;
+        LAUNCH_KERNEL(k, grid, dim3(64), shmem, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+    } else if (T <= 256) {
+        auto k = k_rel_attention_mfma<8>;
+        LAUNCH_KERNEL(k, grid, dim3(64), shmem, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+    } else {
+        auto k = k_rel_attention_mfma<16>;
+        LAUNCH_KERNEL(k, grid, dim3(64), shmem, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+    }
+}
+
+}  // namespace m355

@@ -128,6 +128,36 @@ def test_fused_mrf_stage_kernel(emu_lib):
         assert rel_rms(fused_audio[b, :L], plain_audio[b, :L]) < 1e-5
 
 
+@pytest.mark.parametrize("B,Tx", [(2, 70), (1, 150)])
+def test_attention_across_key_and_query_tiles(emu_lib, B, Tx):
+    """Phoneme sequences longer than one 32-wide MFMA tile (and than 128: 8 key tiles in registers)."""
+    check_parity(emu_lib, VitsConfig.tiny(), B=B, Tx=Tx, seed=40 + Tx, frames_per_id=1.2)
+
+
+def test_generic_kernels_agree_with_mfma_path(emu_lib):
+    """MI355VITS_FORCE_GENERIC=1 routes every conv / attention through the plain VALU kernels."""
+    import os
+
+    cfg = VitsConfig.tiny()
+    w = W.synthetic_weights(cfg, seed=77)
+    from tests.util import make_inputs
+    ids, lengths, _ = make_inputs(cfg, 2, 40, 77)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    a = eng.run(ids, lengths, [0, 1, 0])
+    eng.close()
+    os.environ["MI355VITS_FORCE_GENERIC"] = "1"
+    try:
+        eng2 = Engine(W.pack(cfg, w), library=emu_lib)
+        b = eng2.run(ids, lengths, [0, 1, 0])
+        eng2.close()
+    finally:
+        del os.environ["MI355VITS_FORCE_GENERIC"]
+    assert np.array_equal(a["lengths"], b["lengths"])
+    for r in range(2):
+        L = int(a["lengths"][r])
+        assert rel_rms(a["audio"][r, :L], b["audio"][r, :L]) < 1e-5
+
+
 def test_odd_flow_depth_folds_final_flip(emu_lib):
     cfg = VitsConfig.tiny()
     cfg.flow_n_flows = 3
