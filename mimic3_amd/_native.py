@@ -168,14 +168,14 @@ class NativeLibrary:
             raise NativeError(rc, self.create_error())
         return y
 
-    def test_conv_transpose1d(self, x, w, bias, stride, in_slope=1.0, device=0) -> np.ndarray:
+    def test_conv_transpose1d(self, x, w, bias, stride, in_slope=1.0, device=0, impl=0) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32)
         w = np.ascontiguousarray(w, np.float32)
         B, Cin, Tin = x.shape
         _, Cout, K = w.shape
         b = None if bias is None else np.ascontiguousarray(bias, np.float32)
         y = np.zeros((B, Cout, Tin * stride), np.float32)
-        rc = self.lib.mi355vits_test_conv_transpose1d(device, 0, B, Cin, Cout, Tin, K, stride, _fptr(x), _fptr(w),
+        rc = self.lib.mi355vits_test_conv_transpose1d(device, impl, B, Cin, Cout, Tin, K, stride, _fptr(x), _fptr(w),
                                                       _fptr(b), in_slope, _fptr(y))
         if rc != 0:
             raise NativeError(rc, self.create_error())

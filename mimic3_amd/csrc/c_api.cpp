@@ -222,23 +222,45 @@ int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t) {
 
 int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Cout, int Tin, int K, int stride,
                                     const float* x, const float* w, const float* bias, float in_slope, float* y) {
-    (void)impl;
     return guarded(nullptr, [&] {
         if (!x || !w || !y) throw EngineError(MI355VITS_ERR_INVALID, "null argument");
         HIP_CHECK(hipSetDevice(device));
         const size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tin * stride, nw = (size_t)Cin * Cout * K;
         DevBuf dx(nx * 4), dy(ny * 4), dw(nw * 4), db(Cout * 4);
         HIP_CHECK(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(dw.p, w, nw * 4, hipMemcpyHostToDevice));
-        ConvTArgs a;
-        a.x = dx.as<float>(); a.x_bs = (long)Cin * Tin; a.x_ld = Tin;
-        a.y = dy.as<float>(); a.y_bs = (long)Cout * Tin * stride; a.y_ld = Tin * stride;
-        a.w = dw.as<float>();
-        if (bias) { HIP_CHECK(hipMemcpy(db.p, bias, Cout * 4, hipMemcpyHostToDevice)); a.bias = db.as<float>(); }
-        a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.K = K; a.stride = stride; a.pad = (K - stride) / 2;
-        a.in_slope = in_slope;
-        launch_conv_transpose1d(a, nullptr);
-        HIP_CHECK(hipDeviceSynchronize());
+        if (impl == 1) {
+            // polyphase filters on the MFMA conv kernel (the path Engine uses)
+            const int taps = convt_taps(K, stride);
+            std::vector<float> wv((size_t)stride * Cout * Cin * taps), bv((size_t)stride * Cout);
+            convt_to_polyphase(w, bias, Cin, Cout, K, stride, wv.data(), bv.data());
+            if (!conv1d_mfma_supported(Cin, stride * Cout, taps, 1)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the MFMA kernel");
+            std::vector<float> pk(mfma_packed_floats(stride * Cout, Cin, taps));
+            pack_conv_weights_mfma(wv.data(), stride * Cout, Cin, taps, pk.data());
+            DevBuf dp(pk.size() * 4), dbias(bv.size() * 4);
+            HIP_CHECK(hipMemcpy(dp.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dbias.p, bv.data(), bv.size() * 4, hipMemcpyHostToDevice));
+            ConvArgs u;
+            u.x = dx.as<float>(); u.x_bs = (long)Cin * Tin; u.x_ld = Tin;
+            u.y = dy.as<float>(); u.y_bs = (long)Cout * Tin * stride; u.y_ld = Tin * stride;
+            u.w = dp.as<float>(); u.bias = dbias.as<float>();
+            u.Cin = Cin; u.Cout = stride * Cout; u.K = taps; u.dil = 1;
+            u.in_slope = in_slope; u.pad = taps - 1; u.Tin = Tin;
+            u.shuf_s = stride; u.shuf_p = (K - stride) / 2; u.shuf_cout = Cout; u.shuf_T = Tin * stride;
+            u.B = B; u.T = Tin + taps - 1;
+            launch_conv1d_mfma(u, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        } else {
+            HIP_CHECK(hipMemcpy(dw.p, w, nw * 4, hipMemcpyHostToDevice));
+            ConvTArgs a;
+            a.x = dx.as<float>(); a.x_bs = (long)Cin * Tin; a.x_ld = Tin;
+            a.y = dy.as<float>(); a.y_bs = (long)Cout * Tin * stride; a.y_ld = Tin * stride;
+            a.w = dw.as<float>();
+            if (bias) { HIP_CHECK(hipMemcpy(db.p, bias, Cout * 4, hipMemcpyHostToDevice)); a.bias = db.as<float>(); }
+            a.B = B; a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.K = K; a.stride = stride; a.pad = (K - stride) / 2;
+            a.in_slope = in_slope;
+            launch_conv_transpose1d(a, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost));
     });

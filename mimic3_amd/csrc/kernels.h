@@ -36,7 +36,8 @@ struct ConvArgs {
     // ConvTranspose1d run as a stride-1 conv over `stride` polyphase filters: output channel
     // co' = r * shuf_cout + co of position i lands at y[co][i * shuf_s + r - shuf_p]  (0 <= n < shuf_T)
     int shuf_s = 0, shuf_p = 0, shuf_cout = 0, shuf_T = 0;
-    int vec = 0;  // set by the launcher: input rows are 16-byte aligned -> 16-byte staging loads
+    int vec = 0;   // set by the launcher: input rows are 16-byte aligned -> 16-byte staging loads
+    int yvec = 0;  // set by the launcher: output rows are 16-byte aligned -> vector stores (polyphase epilogue)
 };
 
 // Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).

@@ -20,8 +20,8 @@ namespace m355 {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void epi_std(const ConvArgs& a, int b, int co, int t, float v, int out_len) {
     if (a.bias) v += a.bias[co];
-    if (a.shuf_s) {  // polyphase ConvTranspose1d: scatter phase r of position t to n = t*s + r - p
-        const int r = co / a.shuf_cout, c = co - r * a.shuf_cout;
+    if (a.shuf_s) {  // polyphase ConvTranspose1d (co' = c*s + r): phase r of position t lands at n = t*s + r - p
+        const int c = co / a.shuf_s, r = co - c * a.shuf_s;
         const int n = t * a.shuf_s + r - a.shuf_p;
         if (n >= 0 && n < a.shuf_T) a.y[(long)b * a.y_bs + (long)c * a.y_ld + n] = v;
         return;
@@ -337,6 +337,40 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (EPI == EPI_STD && a.shuf_s && (a.shuf_s & 3) == 0) {
+        // polyphase ConvTranspose1d, output channels ordered co' = c*s + r: the 4 consecutive rows a lane holds per
+        // register group are 4 consecutive phases of one channel = 4 consecutive output samples -> 16-byte stores
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j) {
+            const int t = t0 + (wn * NT + j) * 32 + bcol;
+            if (t >= a.T) continue;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) {
+                MI355_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const int cop = 32 * (tile0 + i) + 8 * g + 4 * brow;  // multiple of 4
+                    if (cop >= a.Cout) continue;
+                    const int c = cop / a.shuf_s, r0 = cop - c * a.shuf_s;
+                    const int n0 = t * a.shuf_s + r0 - a.shuf_p;
+                    float v[4];
+                    MI355_UNROLL
+                    for (int m = 0; m < 4; ++m) v[m] = acc[i][j][4 * g + m] + (a.bias ? a.bias[cop + m] : 0.0f);
+                    float* yp = a.y + (long)b * a.y_bs + (long)c * a.y_ld + n0;
+                    if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 3) == 0 && a.yvec) {
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 1) == 0 && a.yvec) {
+                        *reinterpret_cast<float2*>(yp) = make_float2(v[0], v[1]);
+                        *reinterpret_cast<float2*>(yp + 2) = make_float2(v[2], v[3]);
+                    } else {
+                        MI355_UNROLL
+                        for (int m = 0; m < 4; ++m)
+                            if (n0 + m >= 0 && n0 + m < a.shuf_T) yp[m] = v[m];
+                    }
+                }
+            }
+        }
+        return;
+    }
     MI355_UNROLL
     for (int j = 0; j < NT; ++j) {
         const int t = t0 + (wn * NT + j) * 32 + bcol;
@@ -360,6 +394,101 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K = 1 convolutions (q/k/v/o, res_skip, 1x1 of the duration predictor, flow pre/post): a pointwise GEMM has no
+// halo and every input element is used by one column tile only, so staging through LDS buys nothing and costs two
+// barriers per chunk.  Both MFMA operands stream from global memory (A: packed weights; B: 32 consecutive time
+// samples of two channels per half-wave = 128-byte segments) through 8-register rings four steps ahead.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void k_conv1x1_mfma(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int T_B = 32 * NT * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * T_B;
+    const int n_tiles = (EPI == EPI_GATE) ? 2 * ((a.H + 31) / 32) : (a.Cout + 31) / 32;
+    const int tile0 = (blockIdx.y * WM + wm) * MT;
+    const int cpairs = a.Cin >> 1;
+    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
+    int tend = a.in_len ? a.in_len[b] : Tin;
+    if (tend > Tin) tend = Tin;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+
+    f32x16 acc[MT][NT];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const float* wp[MT];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i) {
+        int tile = tile0 + i;
+        if (tile >= n_tiles) tile = n_tiles - 1;
+        wp[i] = a.w + (long)tile * cpairs * 64 + lane;
+    }
+    const float* xp[NT];
+    bool ok[NT];
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j) {
+        const int t = t0 - a.pad + (wn * NT + j) * 32 + bcol;
+        ok[j] = t >= 0 && t < tend;
+        xp[j] = a.x + (long)b * a.x_bs + (long)brow * a.x_ld + (ok[j] ? t : 0);
+    }
+    const long xstep = 2L * a.x_ld;
+    const int steps = cpairs;  // multiple of 8 (checked by the launcher)
+    float ra[MT][8], rb[NT][8];
+    MI355_UNROLL
+    for (int u = 0; u < 4; ++u) {
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i) ra[i][u] = wp[i][u * 64];
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j) rb[j][u] = ok[j] ? xp[j][u * xstep] : 0.0f;
+    }
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+        MI355_UNROLL
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + u;
+            float af[MT], bf[NT];
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) af[i] = ra[i][u];
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) bf[j] = lrelu_f(rb[j][u], a.in_slope);
+            const int sn = s + 4 < steps ? s + 4 : steps - 1;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) ra[i][(u + 4) & 7] = wp[i][sn * 64];
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) rb[j][(u + 4) & 7] = ok[j] ? xp[j][sn * xstep] : 0.0f;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j) {
+        const int t = t0 + (wn * NT + j) * 32 + bcol;
+        if (t >= a.T) continue;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * brow;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) {
+                const int co = 32 * (tile0 + i) + row;
+                if (co >= a.Cout) continue;
+                if (EPI == EPI_RESSKIP) epi_resskip(a, b, co, t, acc[i][j][r], out_len);
+                else epi_std(a, b, co, t, acc[i][j][r], out_len);
+            }
+        }
+    }
+}
+
 namespace {
 
 struct TileCfg { int MT, NT, WM, WN; };
@@ -368,12 +497,12 @@ template <int MT, int NT, int WM, int WN, int EPI>
 void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
     const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
-    // C_in chunk: fixed by C_in alone (largest even divisor <= 32) so that the summation order — and with it
+    // C_in chunk: fixed by C_in alone (largest even divisor <= 64) so that the summation order — and with it
     // every output bit — does not depend on the tile shape chosen for a batch size; only a receptive field too
     // large for LDS shrinks it further.
     auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= 60 * 1024; };
     int ci_c = 0;
-    for (int c = 32; c >= 2; c -= 2)
+    for (int c = 64; c >= 2; c -= 2)
         if (a.Cin % c == 0 && fits(c)) { ci_c = c; break; }
     if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
     const size_t shmem = (size_t)ci_c * LD * sizeof(float);
@@ -381,7 +510,16 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI>;
     ConvArgs av = a;
     av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
+    av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
     LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
+}
+
+template <int MT, int NT, int WM, int WN, int EPI>
+void launch_direct(const ConvArgs& a, int n_tiles, hipStream_t s) {
+    constexpr int T_B = 32 * NT * WN;
+    dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
+    auto kfn = k_conv1x1_mfma<MT, NT, WM, WN, EPI>;
+    LAUNCH_KERNEL(kfn, grid, dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -396,6 +534,18 @@ void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s) {
         return ((a.T + tb - 1) / tb) * ((n_tiles + MT * WM - 1) / (MT * WM)) * (long)a.B;
     };
     const long want = 512;
+    if (a.K == 1 && a.epi != EPI_GATE && ((a.Cin >> 1) % 8) == 0 && !a.shuf_s) {
+        // pointwise: LDS-free streaming kernel
+        if (a.epi == EPI_RESSKIP) {
+            if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) launch_direct<2, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+            else launch_direct<1, 1, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        } else {
+            if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) launch_direct<2, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+            else if (n_tiles >= 2) launch_direct<1, 1, 2, 2, EPI_STD>(a, n_tiles, s);
+            else launch_direct<1, 1, 1, 4, EPI_STD>(a, n_tiles, s);
+        }
+        return;
+    }
     if (a.epi == EPI_GATE) {
         if (blocks(2, 2, 2, 2) >= want) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, n_tiles, s);
         else launch_cfg<2, 1, 2, 2, EPI_GATE>(a, n_tiles, s);
@@ -497,18 +647,19 @@ void launch_conv_transpose1d(const ConvTArgs& a, hipStream_t s) {
 
 // Polyphase view of ConvTranspose1d (A.2): output n = i*s + r - p, r in [0,s) takes taps k = r + m*s (m = 0..taps-1)
 // of inputs x[i - m].  As a stride-1 Conv1d over positions i with `taps` taps and left padding taps-1:
-//   y'[r*Cout + co][i] = sum_ci sum_j W'[r*Cout + co][ci][j] * x[ci][i - (taps-1) + j],  W'[..][j] = W[ci][co][r + (taps-1-j)*s]
+//   y'[co*s + r][i] = sum_ci sum_j W'[co*s + r][ci][j] * x[ci][i - (taps-1) + j],  W'[..][j] = W[ci][co][r + (taps-1-j)*s]
+// (channel-major / phase-minor rows: the MFMA C layout then gives every lane runs of consecutive output samples)
 int convt_taps(int K, int stride) { return (K + stride - 1) / stride; }
 void convt_to_polyphase(const float* w, const float* bias, int Cin, int Cout, int K, int stride, float* w_out,
                         float* bias_out) {
     const int taps = convt_taps(K, stride);
     for (int r = 0; r < stride; ++r)
         for (int co = 0; co < Cout; ++co) {
-            if (bias_out) bias_out[r * Cout + co] = bias ? bias[co] : 0.0f;
+            if (bias_out) bias_out[co * stride + r] = bias ? bias[co] : 0.0f;
             for (int ci = 0; ci < Cin; ++ci)
                 for (int j = 0; j < taps; ++j) {
                     const int k = r + (taps - 1 - j) * stride;
-                    w_out[(((size_t)r * Cout + co) * Cin + ci) * taps + j] = k < K ? w[((size_t)ci * Cout + co) * K + k] : 0.0f;
+                    w_out[(((size_t)co * stride + r) * Cin + ci) * taps + j] = k < K ? w[((size_t)ci * Cout + co) * K + k] : 0.0f;
                 }
         }
 }

@@ -53,47 +53,53 @@ void launch_embed(const long long* ids, const int* len, const float* emb, int B,
 
 // ------------------------------------------------------------------------------------------------
 // channel LayerNorm (A.3) over [B,C,T], optional residual input, GELU, additive output, mask.
-// Workgroup = 64 time columns x 4 channel groups; every thread owns one column slice, so all global
-// accesses are coalesced along time; three cached sweeps (mean, biased variance, write).
+// Every thread owns one (time column, channel group) slice, so global accesses run along time; three cached sweeps
+// (mean, biased variance, write).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-__device__ __forceinline__ float block4_sum(float v, float* red, int tl, int cg) {
+// Workgroup = LN_TT time columns x LN_CG channel groups (256 threads).  16 x 16 keeps >= 256 workgroups in flight
+// for the encoder-sized tensors ([B,192,128]) while a row of 16 consecutive samples is still a 64-byte segment.
+constexpr int LN_TT = 16, LN_CG = 16;
+__device__ __forceinline__ float block_cg_sum(float v, float* red, int tl, int cg) {
     __syncthreads();
-    red[cg * 64 + tl] = v;
+    red[cg * LN_TT + tl] = v;
     __syncthreads();
-    return red[tl] + red[64 + tl] + red[128 + tl] + red[192 + tl];
+    float s = 0.0f;
+    MI355_UNROLL
+    for (int g = 0; g < LN_CG; ++g) s += red[g * LN_TT + tl];
+    return s;
 }
 
 __global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
     DYN_SMEM(float, red);
     const int b = blockIdx.y;
-    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + tl;
+    const int tl = threadIdx.x % LN_TT, cg = threadIdx.x / LN_TT;
+    const int t = blockIdx.x * LN_TT + tl;
     const bool live = t < a.T;
     const long base = (long)b * a.C * a.T + (live ? t : 0);
     float sum = 0.0f;
     if (live)
-        for (int c = cg; c < a.C; c += 4) {
+        for (int c = cg; c < a.C; c += LN_CG) {
             float v = a.x[base + (long)c * a.T];
             if (a.res) v += a.res[base + (long)c * a.T];
             sum += v;
         }
-    const float mean = block4_sum(sum, red, tl, cg) / (float)a.C;
+    const float mean = block_cg_sum(sum, red, tl, cg) / (float)a.C;
     float sq = 0.0f;
     if (live)
-        for (int c = cg; c < a.C; c += 4) {
+        for (int c = cg; c < a.C; c += LN_CG) {
             float v = a.x[base + (long)c * a.T];
             if (a.res) v += a.res[base + (long)c * a.T];
             v -= mean;
             sq += v * v;
         }
-    const float var = block4_sum(sq, red, tl, cg) / (float)a.C;
+    const float var = block_cg_sum(sq, red, tl, cg) / (float)a.C;
     const float rstd = 1.0f / sqrtf(var + a.eps);
     __syncthreads();  // in-place use: all reads of x above are done before anyone writes y
     if (!live) return;
     const bool masked = a.out_len && t >= a.out_len[b];
-    for (int c = cg; c < a.C; c += 4) {
+    for (int c = cg; c < a.C; c += LN_CG) {
         float v = a.x[base + (long)c * a.T];
         if (a.res) v += a.res[base + (long)c * a.T];
         v = (v - mean) * rstd * a.gamma[c] + a.beta[c];
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
 }
 void launch_layernorm(const LNArgs& a, hipStream_t s) {
     if (a.T <= 0) return;
-    LAUNCH_KERNEL(k_layernorm, dim3((a.T + 63) / 64, a.B), dim3(256), 256 * sizeof(float), s, a);
+    LAUNCH_KERNEL(k_layernorm, dim3((a.T + LN_TT - 1) / LN_TT, a.B), dim3(256), 256 * sizeof(float), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -126,25 +132,25 @@ __global__ __launch_bounds__(256) void k_dds_dwconv_ln_gelu(const float* x, cons
                                                             int C, int T, int K, int dil, float* y) {
     DYN_SMEM(float, red);
     const int b = blockIdx.y;
-    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + tl;
+    const int tl = threadIdx.x % LN_TT, cg = threadIdx.x / LN_TT;
+    const int t = blockIdx.x * LN_TT + tl;
     const bool live = t < T;
     const int L = len[b];
     const float* xb = x + (long)b * C * T;
     float sum = 0.0f;
     if (live)
-        for (int c = cg; c < C; c += 4) sum += dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil);
-    const float mean = block4_sum(sum, red, tl, cg) / (float)C;
+        for (int c = cg; c < C; c += LN_CG) sum += dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil);
+    const float mean = block_cg_sum(sum, red, tl, cg) / (float)C;
     float sq = 0.0f;
     if (live)
-        for (int c = cg; c < C; c += 4) {
+        for (int c = cg; c < C; c += LN_CG) {
             const float v = dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil) - mean;
             sq += v * v;
         }
-    const float var = block4_sum(sq, red, tl, cg) / (float)C;
+    const float var = block_cg_sum(sq, red, tl, cg) / (float)C;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     if (!live) return;
-    for (int c = cg; c < C; c += 4) {
+    for (int c = cg; c < C; c += LN_CG) {
         float v = dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil);
         v = (v - mean) * rstd * gamma[c] + beta[c];
         y[((long)b * C + c) * T + t] = gelu_erf(v);
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void k_dds_dwconv_ln_gelu(const float* x, cons
 void launch_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias, const float* gamma,
                                const float* beta, const int* len, int B, int C, int T, int K, int dil, float* y,
                                hipStream_t s) {
-    LAUNCH_KERNEL(k_dds_dwconv_ln_gelu, dim3((T + 63) / 64, B), dim3(256), 256 * sizeof(float), s, x, w, bias, gamma,
+    LAUNCH_KERNEL(k_dds_dwconv_ln_gelu, dim3((T + LN_TT - 1) / LN_TT, B), dim3(256), 256 * sizeof(float), s, x, w, bias, gamma,
                   beta, len, C, T, K, dil, y);
 }
 

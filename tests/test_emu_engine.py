@@ -59,14 +59,15 @@ def test_conv1d_accumulate_and_ressub(emu_lib):
         assert np.abs(y - ref).max() < 1e-5
 
 
-@pytest.mark.parametrize("case", [(1, 8, 4, 10, 16, 8), (2, 32, 16, 37, 8, 4), (1, 6, 3, 5, 4, 2), (1, 4, 2, 9, 3, 1)])
-def test_conv_transpose1d(emu_lib, case):
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("case", [(1, 8, 4, 10, 16, 8), (2, 32, 16, 37, 8, 4), (1, 6, 3, 5, 4, 2), (1, 4, 2, 9, 3, 1), (1, 16, 8, 70, 16, 8)])
+def test_conv_transpose1d(emu_lib, case, impl):
     B, Cin, Cout, Tin, K, s = case
     rng = np.random.default_rng(sum(case))
     x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
     w = rng.standard_normal((Cin, Cout, K)).astype(np.float32) * 0.3
     b = rng.standard_normal(Cout).astype(np.float32)
-    y = emu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1)
+    y = emu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1, impl=impl)
     ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x), 0.1), torch.from_numpy(w), torch.from_numpy(b), stride=s,
                              padding=(K - s) // 2).numpy()
     assert y.shape == ref.shape

@@ -48,14 +48,15 @@ def test_conv1d_kernels(gpu_lib, impl, case):
     assert np.abs(y - ref).max() < 5e-5, np.abs(y - ref).max()
 
 
+@pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("case", [(1, 256, 128, 100, 16, 8), (2, 128, 64, 333, 16, 8), (1, 64, 32, 1000, 8, 4), (1, 6, 3, 5, 4, 2)])
-def test_conv_transpose1d(gpu_lib, case):
+def test_conv_transpose1d(gpu_lib, case, impl):
     B, Cin, Cout, Tin, K, s = case
     rng = np.random.default_rng(sum(case))
     x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
     w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(2 * Cin)).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
-    y = gpu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1)
+    y = gpu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1, impl=impl)
     ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(),
                              torch.from_numpy(b).double(), stride=s, padding=(K - s) // 2).numpy()
     assert np.abs(y - ref).max() < 5e-5
