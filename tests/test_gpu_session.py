@@ -1,0 +1,53 @@
+"""The reference-interface mirror on the real device (pytest -m gpu)."""
+import numpy as np
+import pytest
+
+from mimic3_amd import weights as W
+from mimic3_amd.config import VitsConfig
+from mimic3_amd.session import InferenceSession, SessionOptions
+from oracle.vits_oracle import VitsOracle, audio_float_to_int16
+
+pytestmark = pytest.mark.gpu
+
+
+def test_session_run_matches_oracle_and_reference_int16(tmp_path):
+    cfg = VitsConfig.vctk_low()
+    w = W.synthetic_weights(cfg, seed=31, frames_per_id=2.5)
+    W.save(tmp_path / "generator.m355", cfg, w)
+    so = SessionOptions()
+    so.use_deterministic_compute = True
+    sess = InferenceSession(str(tmp_path / "generator.onnx"), sess_options=so, providers=["CUDAExecutionProvider"])
+    ids = np.expand_dims(np.random.default_rng(3).integers(1, 50, 24).astype(np.int64), 0)
+    feed = {"input": ids, "input_lengths": np.array([24], np.int64), "scales": np.array([0.0, 1.0, 0.0], np.float32),
+            "sid": np.array([17], np.int64)}
+    audio = sess.run(None, feed)[0].squeeze()               # voice.py:230
+    ref = VitsOracle(cfg, w).infer(ids, feed["input_lengths"], feed["scales"], sid=feed["sid"])
+    assert audio.shape[0] == int(ref["audio_lengths"][0])
+    r = ref["audio"][0, 0]
+    assert np.sqrt(np.mean((audio - r) ** 2)) / np.sqrt(np.mean(r ** 2)) < 1e-4
+    pcm, _ = sess.run_pcm16(feed)
+    assert np.array_equal(pcm[0], audio_float_to_int16(audio))  # utils.py:237-244, fused on the GPU
+
+
+def test_session_is_thread_safe_like_shared_ort_sessions(tmp_path):
+    """mimic3_http workers share one session per voice and call run() concurrently (voice.py:277-292)."""
+    import threading
+
+    cfg = VitsConfig.tiny()
+    w = W.synthetic_weights(cfg, seed=2)
+    sess = InferenceSession(W.pack(cfg, w))
+    rng = np.random.default_rng(0)
+    feeds = [{"input": rng.integers(1, 20, (1, 12)).astype(np.int64), "input_lengths": np.array([12]),
+              "scales": np.array([0.0, 1.0, 0.0], np.float32)} for _ in range(8)]
+    expect = [sess.run(None, f)[0] for f in feeds]
+    got = [None] * 8
+
+    def work(i):
+        for _ in range(5):
+            got[i] = sess.run(None, feeds[i])[0]
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for e, g in zip(expect, got):
+        assert np.array_equal(e, g)
