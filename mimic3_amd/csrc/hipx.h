@@ -17,6 +17,8 @@ typedef hipemu_f32x4 f32x4;
 #define DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu::tl_worker->dyn_smem)
 #define MI355_UNROLL
 #define WAVE_UNIFORM(x) (x)
+#define FAST_EXPF(x) expf(x)
+#define FAST_RCPF(x) (1.0f / (x))
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,6 +34,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MI355_UNROLL _Pragma("unroll")
 // value known to be identical in all lanes of a wave: move it to an SGPR so branches on it are scalar
 #define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// hardware transcendental paths (v_exp_f32 / v_rcp_f32, ~1 ulp): used where the result feeds a bounded
+// non-linearity (WaveNet gate), not where exact rounding matters (durations, int16 scaling)
+#define FAST_EXPF(x) __expf(x)
+#define FAST_RCPF(x) __frcp_rn(x)
 #endif
 
 #include <cstdint>
@@ -72,37 +78,46 @@ template <int NW>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
                                            float slope, float* __restrict__ dst, int vec) {
     const int lane = threadIdx.x & 63, wid = WAVE_UNIFORM(threadIdx.x >> 6);
-    constexpr int RU = 32 / NW;  // 8 rows in flight per wave with 4 waves, 4 with 8 waves
+    constexpr int RU = 32 / NW;  // rows per wave per batch: 8 with 4 waves, 4 with 8 waves
+    constexpr int QU = 3;        // column groups per batch: up to RU * QU 16-byte loads in flight per lane
     if (vec) {
         const int ld4 = LD >> 2;
-        for (int c4 = lane; c4 < ld4; c4 += 64) {
-            const int t = ts + 4 * c4;
-            const bool inner = t >= 0 && t + 3 < tend;
+        for (int cb = 0; cb < ld4; cb += 64 * QU) {
             for (int r0 = wid; r0 < rows; r0 += NW * RU) {
-                float4 v[RU];
+                float4 v[QU][RU];
                 MI355_UNROLL
-                for (int u = 0; u < RU; ++u) {
-                    const int r = r0 + NW * u;
-                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (r < rows) {
-                        const float* row = xb + (long)r * x_ld;
-                        if (inner) {
-                            v[u] = *reinterpret_cast<const float4*>(row + t);
-                        } else {
-                            if (t >= 0 && t < tend) v[u].x = row[t];
-                            if (t + 1 >= 0 && t + 1 < tend) v[u].y = row[t + 1];
-                            if (t + 2 >= 0 && t + 2 < tend) v[u].z = row[t + 2];
-                            if (t + 3 >= 0 && t + 3 < tend) v[u].w = row[t + 3];
+                for (int q = 0; q < QU; ++q) {
+                    const int c4 = cb + 64 * q + lane;
+                    const int t = ts + 4 * c4;
+                    const bool inner = t >= 0 && t + 3 < tend;
+                    MI355_UNROLL
+                    for (int u = 0; u < RU; ++u) {
+                        const int r = r0 + NW * u;
+                        v[q][u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (r < rows && c4 < ld4) {
+                            const float* row = xb + (long)r * x_ld;
+                            if (inner) {
+                                v[q][u] = *reinterpret_cast<const float4*>(row + t);
+                            } else {
+                                if (t >= 0 && t < tend) v[q][u].x = row[t];
+                                if (t + 1 >= 0 && t + 1 < tend) v[q][u].y = row[t + 1];
+                                if (t + 2 >= 0 && t + 2 < tend) v[q][u].z = row[t + 2];
+                                if (t + 3 >= 0 && t + 3 < tend) v[q][u].w = row[t + 3];
+                            }
                         }
                     }
                 }
                 MI355_UNROLL
-                for (int u = 0; u < RU; ++u) {
-                    const int r = r0 + NW * u;
-                    if (r < rows) {
-                        float4 o = v[u];
-                        o.x = lrelu_f(o.x, slope); o.y = lrelu_f(o.y, slope); o.z = lrelu_f(o.z, slope); o.w = lrelu_f(o.w, slope);
-                        *reinterpret_cast<float4*>(dst + (long)r * LD + 4 * c4) = o;
+                for (int q = 0; q < QU; ++q) {
+                    const int c4 = cb + 64 * q + lane;
+                    MI355_UNROLL
+                    for (int u = 0; u < RU; ++u) {
+                        const int r = r0 + NW * u;
+                        if (r < rows && c4 < ld4) {
+                            float4 o = v[q][u];
+                            o.x = lrelu_f(o.x, slope); o.y = lrelu_f(o.y, slope); o.z = lrelu_f(o.z, slope); o.w = lrelu_f(o.w, slope);
+                            *reinterpret_cast<float4*>(dst + (long)r * LD + 4 * c4) = o;
+                        }
                     }
                 }
             }

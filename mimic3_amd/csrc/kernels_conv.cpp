@@ -44,8 +44,11 @@ __device__ __forceinline__ void epi_std(const ConvArgs& a, int b, int co, int t,
 __device__ __forceinline__ void epi_gate(const ConvArgs& a, int b, int c, int t, float v0, float v1) {
     if (a.bias) { v0 += a.bias[c]; v1 += a.bias[c + a.H]; }
     if (a.cond) { v0 += a.cond[(long)b * a.cond_bs + c]; v1 += a.cond[(long)b * a.cond_bs + c + a.H]; }
-    const float u = tanhf(v0) * (1.0f / (1.0f + expf(-v1)));
-    a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = u;
+    // tanh(x) = 1 - 2 / (exp(2x) + 1), sigmoid(x) = 1 / (1 + exp(-x)); clamp keeps exp finite
+    const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(v0, -15.0f), 15.0f));
+    const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
+    const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(v1, -30.0f), 30.0f)));
+    a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = th * sg;
 }
 
 // WaveNet res/skip update (A.9): h = (h + rs[:H]) * mask ; skip += rs[H:]  (last layer: skip += rs)
@@ -528,44 +531,70 @@ void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
     const int n_tiles = n_tiles_for(a.epi, a.Cout, a.H);
-    // Tile choice: the largest workgroup tile that still leaves >= ~2 workgroups per CU, else smaller.
+    // Tile choice.  Every CU works through ceil(blocks / 256) workgroups' worth of MFMA time, so a grid of 576
+    // workgroups runs at 576 / 768 = 75 % of one of 1152: take the largest tile whose grid fills the 256 CUs to
+    // >= 85 %, else the candidate that fills them best (small problems: the finest tile = most parallelism).
     auto blocks = [&](int MT, int NT, int WM, int WN) {
         const long tb = 32L * NT * WN;
         return ((a.T + tb - 1) / tb) * ((n_tiles + MT * WM - 1) / (MT * WM)) * (long)a.B;
     };
-    const long want = 512;
-    if (a.K == 1 && a.epi != EPI_GATE && ((a.Cin >> 1) % 8) == 0 && !a.shuf_s) {
-        // pointwise: LDS-free streaming kernel
-        if (a.epi == EPI_RESSKIP) {
-            if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) launch_direct<2, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
-            else launch_direct<1, 1, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
-        } else {
-            if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) launch_direct<2, 2, 2, 2, EPI_STD>(a, n_tiles, s);
-            else if (n_tiles >= 2) launch_direct<1, 1, 2, 2, EPI_STD>(a, n_tiles, s);
-            else launch_direct<1, 1, 1, 4, EPI_STD>(a, n_tiles, s);
+    auto fill = [&](long nb) { return (double)nb / (256.0 * (double)((nb + 255) / 256)); };
+    struct Cand { int MT, NT, WM, WN; };
+    auto choose = [&](const Cand* c, int n) {
+        int best = n - 1;
+        double bf = -1.0;
+        for (int i = 0; i < n; ++i) {  // candidates ordered from the largest tile to the smallest
+            const double f = fill(blocks(c[i].MT, c[i].NT, c[i].WM, c[i].WN));
+            if (f >= 0.85) return i;
+            if (f > bf + 1e-9) { bf = f; best = i; }
         }
-        return;
-    }
+        return best;
+    };
+    const bool direct = a.K == 1 && a.epi != EPI_GATE && ((a.Cin >> 1) % 8) == 0 && !a.shuf_s;
     if (a.epi == EPI_GATE) {
-        if (blocks(2, 2, 2, 2) >= want) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, n_tiles, s);
+        const Cand c[] = {{2, 2, 2, 2}, {2, 1, 2, 2}};
+        if (choose(c, 2) == 0) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, n_tiles, s);
         else launch_cfg<2, 1, 2, 2, EPI_GATE>(a, n_tiles, s);
         return;
     }
     if (a.epi == EPI_RESSKIP) {
-        if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
-        else if (n_tiles >= 2 && blocks(1, 2, 2, 2) >= want) launch_cfg<1, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
-        else launch_cfg<1, 1, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        const Cand c[] = {{2, 2, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}};
+        const int k = choose(c + (n_tiles >= 4 ? 0 : (n_tiles >= 2 ? 1 : 2)), n_tiles >= 4 ? 3 : (n_tiles >= 2 ? 2 : 1)) +
+                      (n_tiles >= 4 ? 0 : (n_tiles >= 2 ? 1 : 2));
+        if (direct) {
+            if (k == 0) launch_direct<2, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+            else if (k == 1) launch_direct<1, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+            else launch_direct<1, 1, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        } else {
+            if (k == 0) launch_cfg<2, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+            else if (k == 1) launch_cfg<1, 2, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+            else launch_cfg<1, 1, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        }
         return;
     }
     if (n_tiles == 1) {
-        if (blocks(1, 2, 1, 4) >= want) launch_cfg<1, 2, 1, 4, EPI_STD>(a, n_tiles, s);
-        else launch_cfg<1, 1, 1, 4, EPI_STD>(a, n_tiles, s);
-    } else if (n_tiles >= 4 && blocks(2, 2, 2, 2) >= want) {
-        launch_cfg<2, 2, 2, 2, EPI_STD>(a, n_tiles, s);
-    } else if (blocks(1, 2, 2, 2) >= want) {
-        launch_cfg<1, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+        const Cand c[] = {{1, 2, 1, 4}, {1, 1, 1, 4}};
+        const int k = choose(c, 2);
+        if (direct) {
+            if (k == 0) launch_direct<1, 2, 1, 4, EPI_STD>(a, n_tiles, s);
+            else launch_direct<1, 1, 1, 4, EPI_STD>(a, n_tiles, s);
+        } else {
+            if (k == 0) launch_cfg<1, 2, 1, 4, EPI_STD>(a, n_tiles, s);
+            else launch_cfg<1, 1, 1, 4, EPI_STD>(a, n_tiles, s);
+        }
+        return;
+    }
+    const Cand c[] = {{2, 2, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}};
+    const int first = n_tiles >= 4 ? 0 : 1;
+    const int k = choose(c + first, 3 - first) + first;
+    if (direct) {
+        if (k == 0) launch_direct<2, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+        else if (k == 1) launch_direct<1, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+        else launch_direct<1, 1, 2, 2, EPI_STD>(a, n_tiles, s);
     } else {
-        launch_cfg<1, 1, 2, 2, EPI_STD>(a, n_tiles, s);
+        if (k == 0) launch_cfg<2, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+        else if (k == 1) launch_cfg<1, 2, 2, 2, EPI_STD>(a, n_tiles, s);
+        else launch_cfg<1, 1, 2, 2, EPI_STD>(a, n_tiles, s);
     }
 }
 

@@ -57,75 +57,59 @@ __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float* 
     }
 }
 
-// conv1 of a resblock for a wave that owns NTL column tiles q = wt + WT*i of the extended range:
-// x1 = x + bias + conv(lrelu(x)), zero outside the row, written to the X1 tile.  The residual and the bias are
-// loaded into the accumulators up front, so the epilogue is a masked LDS store.
-template <int NTL, int CP, int WT>
-__device__ __forceinline__ void mrf_conv1(const float* __restrict__ wp, const float* __restrict__ bias, const float* X,
-                                          float* X1, int LDX, int LD1, int R, int r1, int r2, int K, int d1, int wm,
-                                          int wt, int brow, int bcol, int t0, int len) {
-    f32x16 acc[NTL];
-    float bs[16];
-    MI355_UNROLL
-    for (int r = 0; r < 16; ++r) bs[r] = bias[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow];
+// conv1 of a resblock, MFMA part, for a wave that owns NTL column tiles q = wt + WT*i of the extended range:
+// acc = x + bias + conv(lrelu(x)).  Reads only the X tile, so it may run before the barrier that releases X1.
+template <int NTL, int NA, int CP, int WT>
+__device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float* __restrict__ wp, const float* bs /*LDS*/,
+                                                  const float* X, int LDX, int R, int r1, int r2, int K, int d1, int wm,
+                                                  int wt, int brow, int bcol) {
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
         const int e = (wt + WT * i) * 32 + bcol;
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            acc[i][r] = X[co * LDX + (R - r2) + e] + bs[r];
+            acc[i][r] = X[co * LDX + (R - r2) + e] + bs[co];
         }
     }
     const float* xw = X + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
-    mfma_conv_tiles<NTL, NTL, CP>(acc, wp, xw, WT * 32, LDX, K, d1);
-    MI355_UNROLL
-    for (int i = 0; i < NTL; ++i) {
-        const int e = (wt + WT * i) * 32 + bcol;
-        const int t = t0 - r2 + e;
-        const bool live = t >= 0 && t < len;
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            X1[co * LD1 + e] = live ? acc[i][r] : 0.0f;
-        }
-    }
+    mfma_conv_tiles<NTL, NA, CP>(acc, wp, xw, WT * 32, LDX, K, d1);
 }
 
 // conv2 for a wave that owns NTL output tiles p = wt + WT*i:  out += x1 + bias + conv(lrelu(x1)), accumulated
 // straight into the wave's persistent output registers (no epilogue).
 template <int NTL, int NA, int CP, int WT>
-__device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __restrict__ wp, const float* __restrict__ bias,
+__device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __restrict__ wp, const float* bs /*LDS*/,
                                           const float* X1, int LD1, int r2, int K, int d2, int wm, int wt, int brow, int bcol) {
-    float bs[16];
-    MI355_UNROLL
-    for (int r = 0; r < 16; ++r) bs[r] = bias[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow];
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
         const int c0 = (wt + WT * i) * 32 + bcol;
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            out[i][r] += X1[co * LD1 + c0 + r2] + bs[r];
+            out[i][r] += X1[co * LD1 + c0 + r2] + bs[co];
         }
     }
     const float* xw = X1 + brow * LD1 + bcol + wt * 32;
     mfma_conv_tiles<NTL, NA, CP>(out, wp, xw, WT * 32, LD1, K, d2);
 }
 
-// WM x WT = 8 waves (two per SIMD: one wave's LDS epilogue / barrier wait overlaps its partner's MFMA stream).
-// Output tile T_B = 32 * N2 columns; column tiles of both convs are dealt round-robin to the WT time waves.
+// WM x WT = 8 waves (two per SIMD).  Output tile T_B = 32 * N2 columns; column tiles of both convs are dealt
+// round-robin to the WT time waves.  Barrier placement: conv1 of resblock j+1 only reads the X tile, so it is issued
+// right after conv2 of resblock j and the barrier that releases X1 sits before conv1's *epilogue* — a wave that
+// finishes its conv2 share early flows straight into the next MFMA stream instead of idling at a barrier.
 template <int WM, int WT, int N2, int NT1MAX, int NT2MAX>
 __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 8, "8 waves per workgroup");
-    static_assert(NT1MAX <= 3 && NT2MAX <= 2, "static dispatch below");
+    static_assert(NT1MAX == 3 && NT2MAX == 2, "static dispatch below");
     constexpr int C = 32 * WM;
     constexpr int T_B = 32 * N2;
     constexpr int CP = C / 2;
     DYN_SMEM(float, smem);
     const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
-    float* X = smem;             // [C][LDX]  raw x, zero outside the row
-    float* X1 = smem + C * LDX;  // [C][LD1]  x1 of the current resblock, zero outside the row
+    float* X = smem;               // [C][LDX]  raw x, zero outside the row
+    float* X1 = smem + C * LDX;    // [C][LD1]  x1 of the current resblock, zero outside the row
+    float* BS = X1 + C * LD1;      // [nrb][2][C] biases
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
     // waves w and w+4 share a SIMD: give them complementary tile counts (wt < WT/2 gets the extra tile)
     const int wm = (WM == 1) ? 0 : ((wid >> 1) & 1);
@@ -136,6 +120,10 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     int len = a.len ? a.len[b] : a.T;
     if (len > a.T) len = a.T;
 
+    for (int i = tid; i < a.nrb * 2 * C; i += 512) {
+        const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
+        BS[i] = a.bias[j][q][c];
+    }
     stage_tile<8>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
     __syncthreads();
 
@@ -145,29 +133,49 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) out[i][r] = 0.0f;
     const int nt2 = (N2 - wt + WT - 1) / WT;  // output tiles of this wave (wave-uniform)
+    f32x16 acc1[NT1MAX];
+    int nt1 = 0;
 
-    for (int j = 0; j < a.nrb; ++j) {
-        const int K = a.k[j], d1 = a.d1[j], d2 = a.d2[j];
-        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
+    auto conv1_compute = [&](int j) {
+        const int K = a.k[j], d1 = a.d1[j];
+        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * a.d2[j];
         const int n1 = (T_B + 2 * r2 + 31) / 32;  // conv1 column tiles: extended column e <-> t = t0 - r2 + e
-        {
-            const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
-            const float* bias = a.bias[j][0];
-            const int nt1 = n1 > wt ? (n1 - wt + WT - 1) / WT : 0;
-#define MRF_CONV1(N) mrf_conv1<N, CP, WT>(wp, bias, X, X1, LDX, LD1, R, r1, r2, K, d1, wm, wt, brow, bcol, t0, len)
-            if (nt1 >= 3) { if (NT1MAX >= 3) MRF_CONV1((NT1MAX >= 3 ? 3 : 1)); }
-            else if (nt1 == 2) { if (NT1MAX >= 2) MRF_CONV1((NT1MAX >= 2 ? 2 : 1)); }
-            else if (nt1 == 1) MRF_CONV1(1);
-#undef MRF_CONV1
+        nt1 = n1 > wt ? (n1 - wt + WT - 1) / WT : 0;
+        const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
+        const float* bs = BS + (j * 2 + 0) * C;
+        if (nt1 >= 3) mrf_conv1_compute<3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol);
+        else if (nt1 == 2) mrf_conv1_compute<2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol);
+        else if (nt1 == 1) mrf_conv1_compute<1, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol);
+    };
+
+    conv1_compute(0);
+    for (int j = 0; j < a.nrb; ++j) {
+        const int K = a.k[j], d2 = a.d2[j];
+        const int r2 = (K - 1) / 2 * d2;
+        if (j > 0) __syncthreads();  // every wave is done reading the previous resblock's x1
+        // ---- conv1 epilogue: x1 (zero outside the row) -> LDS
+        MI355_UNROLL
+        for (int i = 0; i < NT1MAX; ++i) {
+            if (i < nt1) {
+                const int e = (wt + WT * i) * 32 + bcol;
+                const int t = t0 - r2 + e;
+                const bool live = t >= 0 && t < len;
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                    X1[co * LD1 + e] = live ? acc1[i][r] : 0.0f;
+                }
+            }
         }
         __syncthreads();
+        // ---- conv2 into the output registers, then straight on to the next resblock's conv1
         {
             const float* wp = a.w[j][1] + (long)wm * K * CP * 64 + lane;
-            const float* bias = a.bias[j][1];
-            if (nt2 >= 2) { if (NT2MAX >= 2) mrf_conv2<(NT2MAX >= 2 ? 2 : 1), NT2MAX, CP, WT>(out, wp, bias, X1, LD1, r2, K, d2, wm, wt, brow, bcol); }
-            else if (nt2 == 1) mrf_conv2<1, NT2MAX, CP, WT>(out, wp, bias, X1, LD1, r2, K, d2, wm, wt, brow, bcol);
+            const float* bs = BS + (j * 2 + 1) * C;
+            if (nt2 >= 2) mrf_conv2<2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol);
+            else if (nt2 == 1) mrf_conv2<1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol);
         }
-        __syncthreads();
+        if (j + 1 < a.nrb) conv1_compute(j + 1);
     }
 
     const float n = (float)a.nrb;
@@ -210,7 +218,7 @@ bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int*
     const int Rp = (R + 3) & ~3;
     const size_t ldx = (size_t)g.T_B + 2 * Rp + 32;
     const size_t ld1 = (size_t)((g.T_B + 2 * r2max + 31) / 32) * 32;
-    return (size_t)C * (ldx + ld1) * sizeof(float) <= LDS_LIMIT;
+    return ((size_t)C * (ldx + ld1) + (size_t)nrb * 2 * C) * sizeof(float) <= LDS_LIMIT;
 }
 
 void launch_mrf_fused(MrfArgs a, hipStream_t s) {
@@ -228,7 +236,7 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     a.ldx = g.T_B + 2 * a.R + 32;     // +32: conv1's last (rounded-up) column tile stays inside its row
     a.ld1 = ((g.T_B + 2 * r2max + 31) / 32) * 32;
     a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
-    const size_t shmem = (size_t)a.C * (a.ldx + a.ld1) * sizeof(float);
+    const size_t shmem = ((size_t)a.C * (a.ldx + a.ld1) + (size_t)a.nrb * 2 * a.C) * sizeof(float);
     dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
     if (a.C == 32) {
         auto kfn = k_mrf_fused<1, 8, 16, 3, 2>;
