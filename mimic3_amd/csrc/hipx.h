@@ -74,12 +74,11 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v >= 0.0f ? v : v * slope; }
 
-template <int NW>
+template <int NW, int QU>  // QU column groups (64 x 16 B each) per batch: RU * QU 16-byte loads in flight per lane
 __device__ __forceinline__ void stage_tile(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
                                            float slope, float* __restrict__ dst, int vec) {
     const int lane = threadIdx.x & 63, wid = WAVE_UNIFORM(threadIdx.x >> 6);
     constexpr int RU = 32 / NW;  // rows per wave per batch: 8 with 4 waves, 4 with 8 waves
-    constexpr int QU = 3;        // column groups per batch: up to RU * QU 16-byte loads in flight per lane
     if (vec) {
         const int ld4 = LD >> 2;
         for (int cb = 0; cb < ld4; cb += 64 * QU) {
@@ -145,5 +144,5 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ xb, long x_
 
 __device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
                                                float slope, float* __restrict__ dst, int vec) {
-    stage_tile<4>(xb, x_ld, rows, LD, ts, tend, slope, dst, vec);
+    stage_tile<4, 1>(xb, x_ld, rows, LD, ts, tend, slope, dst, vec);
 }

@@ -222,7 +222,7 @@ bool conv1d_mfma_supported(int Cin, int Cout, int K, int dil) {
 // wp[i]: packed A fragments of tile i at (k = 0, first pair of the chunk), lane offset included; record (k, cp)
 // sits (k * cpairs + cp) * 64 floats further.  When the step count is a multiple of 8 the A fragments run through an
 // 8-register ring four steps ahead (no drain at the loop edge); B fragments (LDS) are fetched one step ahead.
-template <int MT, int NT>
+template <int MT, int NT, bool RING>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* const (&wp)[MT], const float* __restrict__ xw,
                                            int LD, int K, int cpn, int cpairs, int dil) {
     const int steps = K * cpn;
@@ -230,7 +230,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
     MI355_UNROLL
     for (int j = 0; j < NT; ++j) bf_n[j] = xw[j * 32];
     int k = 0, cp = 0;
-    if ((steps & 7) == 0) {
+    if (RING) {  // the launcher guarantees steps % 8 == 0
         float ring[MT][8];
         int kp = 0, cpp = 0;  // position of the prefetch stream
         MI355_UNROLL
@@ -290,7 +290,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
     }
 }
 
-template <int MT, int NT, int WM, int WN, int EPI>
+template <int MT, int NT, int WM, int WN, int EPI, bool RING>
 __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
                 if (tile >= n_tiles) tile = n_tiles - 1;  // out-of-range tile: recompute the last one, discarded below
                 wp[i] = a.w + ((long)tile * a.K * cpairs + (c0 >> 1)) * 64 + lane;
             }
-            mfma_chunk<MT, NT>(acc, wp, xs + brow * LD + bcol + wn * NT * 32 + toff, LD, a.K, CI_C >> 1, cpairs, a.dil);
+            mfma_chunk<MT, NT, RING>(acc, wp, xs + brow * LD + bcol + wn * NT * 32 + toff, LD, a.K, CI_C >> 1, cpairs, a.dil);
         }
         __syncthreads();
     }
@@ -510,11 +510,16 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
     const size_t shmem = (size_t)ci_c * LD * sizeof(float);
     dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
-    auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI>;
     ConvArgs av = a;
     av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
-    LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
+    if (((a.K * (ci_c >> 1)) & 7) == 0) {
+        auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, true>;
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
+    } else {
+        auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, false>;
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
+    }
 }
 
 template <int MT, int NT, int WM, int WN, int EPI>

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
         BS[i] = a.bias[j][q][c];
     }
-    stage_tile<8>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
+    stage_tile<8, 3>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
     __syncthreads();
 
     f32x16 out[NT2MAX];
