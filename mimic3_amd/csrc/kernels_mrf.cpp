@@ -15,6 +15,8 @@
 // Wave layout: WM waves over the C/32 output-channel tiles x WT waves over time; 4 waves, one per SIMD; LDS ~155 KiB
 // (one workgroup per CU).  Columns are processed in 32-wide MFMA tiles; conv1's ceil((T_B+2*r2)/32) tiles are dealt
 // round-robin to the WT time waves.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace m355 {
@@ -25,9 +27,10 @@ namespace m355 {
 // edge); B fragments: one step ahead; leaky-relu applied as the fragment is consumed.
 template <int NTL, int NA, int CP>
 __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float* __restrict__ wp, const float* __restrict__ xw,
-                                                int tstride, int LD, int K, int dil) {
+                                                int tstride, int LD, int K, int dil, int ablate) {
     static_assert(NTL <= NA, "tile count");
-    const int steps = K * CP;  // multiple of 8 (CP >= 16)
+    const int steps = (ablate & 1) ? 0 : K * CP;  // multiple of 8 (CP >= 16)
+    if (steps == 0) return;
     float a_ring[8];
     MI355_UNROLL
     for (int u = 0; u < 4; ++u) a_ring[u] = wp[(long)u * 64];
@@ -62,7 +65,7 @@ __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float* 
 template <int NTL, int NA, int CP, int WT>
 __device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float* __restrict__ wp, const float* bs /*LDS*/,
                                                   const float* X, int LDX, int R, int r1, int r2, int K, int d1, int wm,
-                                                  int wt, int brow, int bcol) {
+                                                  int wt, int brow, int bcol, int ablate) {
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
         const int e = (wt + WT * i) * 32 + bcol;
@@ -73,14 +76,14 @@ __device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float
         }
     }
     const float* xw = X + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
-    mfma_conv_tiles<NTL, NA, CP>(acc, wp, xw, WT * 32, LDX, K, d1);
+    mfma_conv_tiles<NTL, NA, CP>(acc, wp, xw, WT * 32, LDX, K, d1, ablate);
 }
 
 // conv2 for a wave that owns NTL output tiles p = wt + WT*i:  out += x1 + bias + conv(lrelu(x1)), accumulated
 // straight into the wave's persistent output registers (no epilogue).
 template <int NTL, int NA, int CP, int WT>
 __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __restrict__ wp, const float* bs /*LDS*/,
-                                          const float* X1, int LD1, int r2, int K, int d2, int wm, int wt, int brow, int bcol) {
+                                          const float* X1, int LD1, int r2, int K, int d2, int wm, int wt, int brow, int bcol, int ablate) {
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
         const int c0 = (wt + WT * i) * 32 + bcol;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
         }
     }
     const float* xw = X1 + brow * LD1 + bcol + wt * 32;
-    mfma_conv_tiles<NTL, NA, CP>(out, wp, xw, WT * 32, LD1, K, d2);
+    mfma_conv_tiles<NTL, NA, CP>(out, wp, xw, WT * 32, LD1, K, d2, ablate);
 }
 
 // WM x WT = 8 waves (two per SIMD).  Output tile T_B = 32 * N2 columns; column tiles of both convs are dealt
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
         BS[i] = a.bias[j][q][c];
     }
-    stage_tile<8, 3>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
+    if (!(a.ablate & 2)) stage_tile<8, 3>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
     __syncthreads();
 
     f32x16 out[NT2MAX];
@@ -143,9 +146,9 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         nt1 = n1 > wt ? (n1 - wt + WT - 1) / WT : 0;
         const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
         const float* bs = BS + (j * 2 + 0) * C;
-        if (nt1 >= 3) mrf_conv1_compute<3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol);
-        else if (nt1 == 2) mrf_conv1_compute<2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol);
-        else if (nt1 == 1) mrf_conv1_compute<1, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol);
+        if (nt1 >= 3) mrf_conv1_compute<3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
+        else if (nt1 == 2) mrf_conv1_compute<2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
+        else if (nt1 == 1) mrf_conv1_compute<1, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
     };
 
     conv1_compute(0);
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         {
             const float* wp = a.w[j][1] + (long)wm * K * CP * 64 + lane;
             const float* bs = BS + (j * 2 + 1) * C;
-            if (nt2 >= 2) mrf_conv2<2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol);
-            else if (nt2 == 1) mrf_conv2<1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol);
+            if (nt2 >= 2) mrf_conv2<2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
+            else if (nt2 == 1) mrf_conv2<1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
         }
         if (j + 1 < a.nrb) conv1_compute(j + 1);
     }
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     MI355_UNROLL
     for (int i = 0; i < NT2MAX; ++i) {
         const int t = t0 + (wt + WT * i) * 32 + bcol;
-        if (i < nt2 && t < a.T) {
+        if (i < nt2 && t < a.T && !(a.ablate & 4)) {
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
@@ -236,6 +239,10 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     a.ldx = g.T_B + 2 * a.R + 32;     // +32: conv1's last (rounded-up) column tile stays inside its row
     a.ld1 = ((g.T_B + 2 * r2max + 31) / 32) * 32;
     a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
+    {
+        const char* ab = getenv("MI355VITS_MRF_ABLATE");
+        a.ablate = ab ? atoi(ab) : 0;
+    }
     const size_t shmem = ((size_t)a.C * (a.ldx + a.ld1) + (size_t)a.nrb * 2 * a.C) * sizeof(float);
     dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
     if (a.C == 32) {
