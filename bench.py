@@ -149,6 +149,23 @@ def main():
             lat.append(time.perf_counter() - t1)
         n1 = int(o1["lengths"][0])
         med = float(np.median(lat))
+        if not args.no_roofline:
+            eng.profile_enable(True)
+            eng.profile_reset()
+            for _ in range(3):
+                eng.run(ids1, [Txg], scales, forced_durations=f1, want_float=False, want_pcm16=True)
+            rep1 = eng.profile_report()
+            eng.profile_enable(False)
+            eng.profile_reset()
+            rows1 = sorted(({"kernel": k, "launches": v["calls"] // 3, "ms": v["ms"] / 3} for k, v in rep1.items()),
+                           key=lambda r: -r["ms"])
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_b1.json"), "w") as f:
+                json.dump(rows1, f, indent=1)
+            print("batch-1 golden shape, per-kernel (HIP events): total %.3f ms over %d launches" %
+                  (sum(r["ms"] for r in rows1), sum(r["launches"] for r in rows1)), file=sys.stderr)
+            for r in rows1[:10]:
+                print(f"  {r['kernel']:22s} {r['launches']:4d} launches {r['ms']:8.3f} ms", file=sys.stderr)
         result["latency_b1"] = {
             "workload": "en_UK/apope_low batch 1, 180 ids -> 991 frames = 253,696 samples (golden-utterance shape), "
                         "host ids in -> host int16 out (PCIe included)",
@@ -184,7 +201,7 @@ def main():
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
-            "traffic": None,
+            "traffic": _pmc_traffic(dom["kernel"], B, Tx, fpi),
             "avg_launch_us": drec["ms"] * 1e3 / drec["calls"],
             "launches": drec["calls"],
             "hbm_algorithmic_gbs": drec["bytes"] / dsec / 1e9,
@@ -243,6 +260,21 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel, B, Tx, fpi):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), valid for
+    the workload they were collected on; None otherwise (counters cannot be read from inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(kernel)
+        if e and e["workload"] == [B, Tx, fpi]:
+            return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
+                    "source": e["source"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def _cpu_model():

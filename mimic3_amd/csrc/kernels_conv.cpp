@@ -398,13 +398,14 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K = 1 convolutions (q/k/v/o, res_skip, 1x1 of the duration predictor, flow pre/post): a pointwise GEMM has no
-// halo and every input element is used by one column tile only, so staging through LDS buys nothing and costs two
-// barriers per chunk.  Both MFMA operands stream from global memory (A: packed weights; B: 32 consecutive time
-// samples of two channels per half-wave = 128-byte segments) through 8-register rings four steps ahead.
+// LDS-free variant for pointwise convs (q/k/v/o, res_skip, 1x1 of the duration predictor, flow pre/post) and for
+// short-sequence convs (encoder FFN, K = 3, T = phonemes): no halo worth staging / too few workgroups to hide the
+// stage-barrier-compute cycle.  Both MFMA operands stream from global memory (A: packed weights; B: 32 consecutive
+// time samples of two channels per half-wave, one 128-byte segment per tap, served by L1/L2) through 8-register
+// rings four steps ahead; no barriers at all.
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NT, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void k_conv1x1_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256) void k_conv_direct_mfma(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int T_B = 32 * NT * WN;
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
@@ -433,40 +434,39 @@ __global__ __launch_bounds__(256) void k_conv1x1_mfma(ConvArgs a) {
     for (int i = 0; i < MT; ++i) {
         int tile = tile0 + i;
         if (tile >= n_tiles) tile = n_tiles - 1;
-        wp[i] = a.w + (long)tile * cpairs * 64 + lane;
+        wp[i] = a.w + (long)tile * a.K * cpairs * 64 + lane;
     }
-    const float* xp[NT];
-    bool ok[NT];
+    const float* xrow = a.x + (long)b * a.x_bs + (long)brow * a.x_ld;
+    int tj[NT];
     MI355_UNROLL
-    for (int j = 0; j < NT; ++j) {
-        const int t = t0 - a.pad + (wn * NT + j) * 32 + bcol;
-        ok[j] = t >= 0 && t < tend;
-        xp[j] = a.x + (long)b * a.x_bs + (long)brow * a.x_ld + (ok[j] ? t : 0);
-    }
+    for (int j = 0; j < NT; ++j) tj[j] = t0 - a.pad + (wn * NT + j) * 32 + bcol;
     const long xstep = 2L * a.x_ld;
-    const int steps = cpairs;  // multiple of 8 (checked by the launcher)
+    const int steps = a.K * cpairs;  // multiple of 8 (checked by the launcher)
     float ra[MT][8], rb[NT][8];
+    int kp = 0, cpp = 0;  // prefetch stream position (tap, channel pair)
+    auto fetch = [&](int slot) {
+        const int kk = kp < a.K ? kp : a.K - 1;
+        const int cc = kp < a.K ? cpp : cpairs - 1;
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i) ra[i][slot] = wp[i][(kk * cpairs + cc) * 64];
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j) {
+            const int t = tj[j] + kk * a.dil;
+            rb[j][slot] = (t >= 0 && t < tend) ? xrow[cc * xstep + t] : 0.0f;
+        }
+        if (++cpp == cpairs) { cpp = 0; ++kp; }
+    };
     MI355_UNROLL
-    for (int u = 0; u < 4; ++u) {
-        MI355_UNROLL
-        for (int i = 0; i < MT; ++i) ra[i][u] = wp[i][u * 64];
-        MI355_UNROLL
-        for (int j = 0; j < NT; ++j) rb[j][u] = ok[j] ? xp[j][u * xstep] : 0.0f;
-    }
+    for (int u = 0; u < 4; ++u) fetch(u);
     for (int s0 = 0; s0 < steps; s0 += 8) {
         MI355_UNROLL
         for (int u = 0; u < 8; ++u) {
-            const int s = s0 + u;
             float af[MT], bf[NT];
             MI355_UNROLL
             for (int i = 0; i < MT; ++i) af[i] = ra[i][u];
             MI355_UNROLL
             for (int j = 0; j < NT; ++j) bf[j] = lrelu_f(rb[j][u], a.in_slope);
-            const int sn = s + 4 < steps ? s + 4 : steps - 1;
-            MI355_UNROLL
-            for (int i = 0; i < MT; ++i) ra[i][(u + 4) & 7] = wp[i][sn * 64];
-            MI355_UNROLL
-            for (int j = 0; j < NT; ++j) rb[j][(u + 4) & 7] = ok[j] ? xp[j][sn * xstep] : 0.0f;
+            fetch((u + 4) & 7);
             MI355_UNROLL
             for (int i = 0; i < MT; ++i)
                 MI355_UNROLL
@@ -526,7 +526,7 @@ template <int MT, int NT, int WM, int WN, int EPI>
 void launch_direct(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
     dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
-    auto kfn = k_conv1x1_mfma<MT, NT, WM, WN, EPI>;
+    auto kfn = k_conv_direct_mfma<MT, NT, WM, WN, EPI>;
     LAUNCH_KERNEL(kfn, grid, dim3(256), 0, s, a);
 }
 
@@ -555,7 +555,10 @@ void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s) {
         }
         return best;
     };
-    const bool direct = a.K == 1 && a.epi != EPI_GATE && ((a.Cin >> 1) % 8) == 0 && !a.shuf_s;
+    // LDS-free streaming kernel: pointwise convs, and short sequences (encoder FFN) where the grid is too small to
+    // hide the stage/barrier cycle of the staged kernel
+    const bool direct = a.epi != EPI_GATE && !a.shuf_s && ((a.K * (a.Cin >> 1)) % 8) == 0 &&
+                        (a.K == 1 || (a.K <= 3 && a.T <= 512));
     if (a.epi == EPI_GATE) {
         const Cand c[] = {{2, 2, 2, 2}, {2, 1, 2, 2}};
         if (choose(c, 2) == 0) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, n_tiles, s);
