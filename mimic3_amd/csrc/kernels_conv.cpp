@@ -230,38 +230,47 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
     MI355_UNROLL
     for (int j = 0; j < NT; ++j) bf_n[j] = xw[j * 32];
     int k = 0, cp = 0;
-    if (RING) {  // the launcher guarantees steps % 8 == 0
+    if (RING) {
+        // cpn % 8 == 0 (launcher): steps are walked in groups of 8 channel pairs of one tap, so every address in the
+        // unrolled body is the group base plus a compile-time multiple of the pitch; A through an 8-register ring
+        // four steps ahead, B through two statically indexed buffers one step ahead; no copies, no index arithmetic.
+        const int ld2 = 2 * LD;
         float ring[MT][8];
-        int kp = 0, cpp = 0;  // position of the prefetch stream
         MI355_UNROLL
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4; ++u)
             MI355_UNROLL
-            for (int i = 0; i < MT; ++i) ring[i][u] = wp[i][(kp * cpairs + cpp) * 64];
-            if (++cpp == cpn) { cpp = 0; ++kp; }
-        }
-        for (int s0 = 0; s0 < steps; s0 += 8) {
-            MI355_UNROLL
-            for (int u = 0; u < 8; ++u) {
-                const int s = s0 + u;
-                float af[MT], bf[NT];
+            for (int i = 0; i < MT; ++i) ring[i][u] = wp[i][u * 64];
+        float bb[2][NT];
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j) bb[0][j] = bf_n[j];
+        for (int kk = 0; kk < K; ++kk) {
+            for (int cp0 = 0; cp0 < cpn; cp0 += 8) {
+                const float* base = xw + kk * dil + cp0 * ld2;
+                const bool last = (kk == K - 1) && (cp0 + 8 == cpn);
+                const float* nbase = (cp0 + 8 < cpn) ? base + 8 * ld2 : xw + (kk + 1) * dil;
+                const int woff = (kk * cpairs + cp0) * 64;
+                // A record four steps ahead: same tap while cp0 + u + 4 < cpn, else the next tap's first records
                 MI355_UNROLL
-                for (int i = 0; i < MT; ++i) af[i] = ring[i][u];
-                const int off = (kp < K ? kp * cpairs + cpp : (K - 1) * cpairs + cpn - 1) * 64;  // tail: harmless re-read
-                MI355_UNROLL
-                for (int i = 0; i < MT; ++i) ring[i][(u + 4) & 7] = wp[i][off];
-                if (++cpp == cpn) { cpp = 0; ++kp; }
-                MI355_UNROLL
-                for (int j = 0; j < NT; ++j) bf[j] = bf_n[j];
-                if (++cp == cpn) { cp = 0; ++k; }
-                if (s + 1 < steps) {
-                    const float* xr = xw + (2 * cp) * LD + k * dil;
+                for (int u = 0; u < 8; ++u) {
+                    const int cpa = cp0 + u + 4;
+                    const int aoff = cpa < cpn ? woff + (u + 4) * 64 : ((kk + 1) * cpairs + (cpa - cpn)) * 64;
+                    const bool have = cpa < cpn || kk + 1 < K;
+                    if (have) {
+                        MI355_UNROLL
+                        for (int i = 0; i < MT; ++i) ring[i][(u + 4) & 7] = wp[i][aoff];
+                    }
+                    if (u < 7) {
+                        MI355_UNROLL
+                        for (int j = 0; j < NT; ++j) bb[(u + 1) & 1][j] = base[(u + 1) * ld2 + j * 32];
+                    } else if (!last) {
+                        MI355_UNROLL
+                        for (int j = 0; j < NT; ++j) bb[0][j] = nbase[j * 32];
+                    }
                     MI355_UNROLL
-                    for (int j = 0; j < NT; ++j) bf_n[j] = xr[j * 32];
+                    for (int i = 0; i < MT; ++i)
+                        MI355_UNROLL
+                        for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(ring[i][u], bb[u & 1][j], acc[i][j]);
                 }
-                MI355_UNROLL
-                for (int i = 0; i < MT; ++i)
-                    MI355_UNROLL
-                    for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
             }
         }
     } else {
@@ -513,7 +522,7 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     ConvArgs av = a;
     av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
-    if (((a.K * (ci_c >> 1)) & 7) == 0) {
+    if (((ci_c >> 1) & 7) == 0) {
         auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, true>;
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
     } else {

@@ -4,8 +4,8 @@
 //
 // Conv-by-conv this stage moves ~7 activation tensors per resblock through HBM and its k=3 convs sit at
 // 24 FLOP/B — HBM-bound on MI355X (ridge 19.7 FLOP/B fp32).  Here a workgroup owns a [C, T_B] output tile:
-//   * x[C, T_B + 2R] (R = largest receptive radius of the n resblocks) is staged ONCE into LDS, raw; leaky-relu is
-//     applied when a B fragment is read (max(v, 0.1 v): 2 VALU per 64-cycle MFMA);
+//   * x[C, T_B + 2R] (R = largest receptive radius of the n resblocks) is staged ONCE into LDS, already leaky-relu'd
+//     (the MFMA B operand is then a bare LDS read); the residual path recovers the raw value (v < 0 ? 10 v : v);
 //   * conv1 of a resblock runs on the fp32 matrix cores over T_B + 2*r2 columns and leaves x1 (masked to the row's
 //     own length) in a second LDS tile; conv2 consumes it and accumulates x2 into per-lane registers that persist
 //     across the n resblocks;
@@ -23,42 +23,52 @@ namespace m355 {
 
 // One wave's share of a conv on the matrix cores: NTL column tiles (32 columns each, `tstride` floats apart in the
 // LDS tile), all of the wave's 32 output channels, K taps x CP channel pairs, accumulated INTO acc (callers preload
-// bias / residual there).  A fragments: 8-register ring, four steps ahead (L2 latency, no register copies at the loop
-// edge); B fragments: one step ahead; leaky-relu applied as the fragment is consumed.
+// bias / residual there).  The LDS tiles hold leaky-relu'd activations, so a B fragment is a bare ds_read_b32.
+// The instruction stream per k-step is kept to the MFMAs plus one A load, the B reads and an address add:
+//   * steps are walked in groups of 8 channel pairs of one tap, so every address in the unrolled body is the group
+//     base plus a compile-time multiple of the row pitch (no per-step index arithmetic);
+//   * A fragments: 8-register ring, four steps ahead (L2 latency); B fragments: two statically indexed buffers,
+//     one step ahead — no register copies anywhere in the loop.
 template <int NTL, int NA, int CP>
 __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float* __restrict__ wp, const float* __restrict__ xw,
                                                 int tstride, int LD, int K, int dil, int ablate) {
     static_assert(NTL <= NA, "tile count");
-    const int steps = (ablate & 1) ? 0 : K * CP;  // multiple of 8 (CP >= 16)
-    if (steps == 0) return;
+    static_assert(CP % 8 == 0, "channel pairs per tap must be a multiple of 8");
+    if (ablate & 1) return;
+    const int ld2 = 2 * LD;
     float a_ring[8];
     MI355_UNROLL
-    for (int u = 0; u < 4; ++u) a_ring[u] = wp[(long)u * 64];
-    float b_nxt[NTL];
+    for (int u = 0; u < 4; ++u) a_ring[u] = wp[u * 64];
+    float bb[2][NTL];
     MI355_UNROLL
-    for (int i = 0; i < NTL; ++i) b_nxt[i] = xw[i * tstride];
-    int k = 0, cp = 0;
-    for (int s0 = 0; s0 < steps; s0 += 8) {
-        MI355_UNROLL
-        for (int u = 0; u < 8; ++u) {
-            const int s = s0 + u;
-            const float av = a_ring[u];
-            const int sn = s + 4 < steps ? s + 4 : steps - 1;
-            a_ring[(u + 4) & 7] = wp[(long)sn * 64];
-            float bv[NTL];
+    for (int i = 0; i < NTL; ++i) bb[0][i] = xw[i * tstride];
+    const float* wg = wp;
+    for (int k = 0; k < K; ++k) {
+        for (int cp0 = 0; cp0 < CP; cp0 += 8) {
+            const float* base = xw + k * dil + cp0 * ld2;
+            const bool last = (k == K - 1) && (cp0 + 8 == CP);
+            const float* nbase = (cp0 + 8 < CP) ? base + 8 * ld2 : xw + (k + 1) * dil;
             MI355_UNROLL
-            for (int i = 0; i < NTL; ++i) bv[i] = b_nxt[i];
-            if (++cp == CP) { cp = 0; ++k; }
-            if (s + 1 < steps) {
-                const float* xr = xw + (2 * cp) * LD + k * dil;
+            for (int u = 0; u < 8; ++u) {
+                const float av = a_ring[u];
+                if (u < 4 || !last) a_ring[(u + 4) & 7] = wg[(u + 4) * 64];
+                if (u < 7) {
+                    MI355_UNROLL
+                    for (int i = 0; i < NTL; ++i) bb[(u + 1) & 1][i] = base[(u + 1) * ld2 + i * tstride];
+                } else if (!last) {
+                    MI355_UNROLL
+                    for (int i = 0; i < NTL; ++i) bb[0][i] = nbase[i * tstride];
+                }
                 MI355_UNROLL
-                for (int i = 0; i < NTL; ++i) b_nxt[i] = xr[i * tstride];
+                for (int i = 0; i < NTL; ++i) acc[i] = MFMA_32x32x2_F32(av, bb[u & 1][i], acc[i]);
             }
-            MI355_UNROLL
-            for (int i = 0; i < NTL; ++i) acc[i] = MFMA_32x32x2_F32(av, fmaxf(bv[i], 0.1f * bv[i]), acc[i]);
+            wg += 8 * 64;
         }
     }
 }
+
+// inverse of leaky-relu(0.1) up to one rounding: the LDS tiles keep activated values, the residual needs the raw one
+__device__ __forceinline__ float unlrelu(float v) { return v >= 0.0f ? v : v * 10.0f; }
 
 // conv1 of a resblock, MFMA part, for a wave that owns NTL column tiles q = wt + WT*i of the extended range:
 // acc = x + bias + conv(lrelu(x)).  Reads only the X tile, so it may run before the barrier that releases X1.
@@ -72,7 +82,7 @@ __device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            acc[i][r] = X[co * LDX + (R - r2) + e] + bs[co];
+            acc[i][r] = unlrelu(X[co * LDX + (R - r2) + e]) + bs[co];
         }
     }
     const float* xw = X + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
@@ -90,7 +100,7 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            out[i][r] += X1[co * LD1 + c0 + r2] + bs[co];
+            out[i][r] += unlrelu(X1[co * LD1 + c0 + r2]) + bs[co];
         }
     }
     const float* xw = X1 + brow * LD1 + bcol + wt * 32;
@@ -110,8 +120,8 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     constexpr int CP = C / 2;
     DYN_SMEM(float, smem);
     const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
-    float* X = smem;               // [C][LDX]  raw x, zero outside the row
-    float* X1 = smem + C * LDX;    // [C][LD1]  x1 of the current resblock, zero outside the row
+    float* X = smem;               // [C][LDX]  lrelu(x), zero outside the row
+    float* X1 = smem + C * LDX;    // [C][LD1]  lrelu(x1) of the current resblock, zero outside the row
     float* BS = X1 + C * LD1;      // [nrb][2][C] biases
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
     // waves w and w+4 share a SIMD: give them complementary tile counts (wt < WT/2 gets the extra tile)
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
         BS[i] = a.bias[j][q][c];
     }
-    if (!(a.ablate & 2)) stage_tile<8, 3>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 1.0f, X, a.vec);
+    if (!(a.ablate & 2)) stage_tile<8, 3>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec);
     __syncthreads();
 
     f32x16 out[NT2MAX];
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                    X1[co * LD1 + e] = live ? acc1[i][r] : 0.0f;
+                    X1[co * LD1 + e] = live ? fmaxf(acc1[i][r], 0.1f * acc1[i][r]) : 0.0f;
                 }
             }
         }
