@@ -167,6 +167,11 @@ typedef struct mi355vits_conv_test {
 int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t);
 int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Cout, int Tin, int K, int stride,
                                     const float* x, const float* w, const float* bias, float in_slope, float* y);
+/* Kernel micro-benchmark hook (tools/convbench.py): times `reps` launches of one MFMA Conv1d on random device data.
+ * epi: 0 = standard epilogue (bias + residual), 1 = WaveNet gate (Cout = 2*H), 2 = res/skip.  Tile shape and C_in
+ * chunk can be forced with MI355VITS_CONV_CFG="MT,NT,WM,WN" / MI355VITS_CONV_CHUNK. */
+int mi355vits_bench_conv1d(int device, int B, int Cin, int Cout, int T, int K, int dilation, int epi, int reps,
+                           float* ms_per_launch);
 /* MFMA fragment-layout self test: returns 0 when the 32x32x2 and 16x16x4 f32 MFMA lane maps
  * assumed by the kernels hold on this device; max abs error in *err. */
 int mi355vits_test_mfma_layout(int device, float* err);

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "mi355vits_get_config", "mi355vits_run", "mi355vits_fetch", "mi355vits_free_result",
     "mi355vits_last_error", "mi355vits_profile_enable", "mi355vits_profile_reset",
     "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_list_taps",
-    "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout",
+    "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout", "mi355vits_bench_conv1d",
 )
 
 
@@ -132,6 +132,7 @@ class NativeLibrary:
             ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
             ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
         L.mi355vits_test_mfma_layout.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        L.mi355vits_bench_conv1d.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_float)]
 
     def version(self) -> str:
         return self.lib.mi355vits_version().decode()
@@ -180,6 +181,13 @@ class NativeLibrary:
         if rc != 0:
             raise NativeError(rc, self.create_error())
         return y
+
+    def bench_conv1d(self, B, Cin, Cout, T, K, dilation=1, epi=0, reps=20, device=0) -> float:
+        ms = ctypes.c_float(-1.0)
+        rc = self.lib.mi355vits_bench_conv1d(device, B, Cin, Cout, T, K, dilation, epi, reps, ctypes.byref(ms))
+        if rc != 0:
+            raise NativeError(rc, self.create_error())
+        return float(ms.value)
 
     def test_mfma_layout(self, device=0) -> float:
         err = ctypes.c_float(-1.0)

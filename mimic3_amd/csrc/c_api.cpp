@@ -266,6 +266,59 @@ int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Co
     });
 }
 
+int mi355vits_bench_conv1d(int device, int B, int Cin, int Cout, int T, int K, int dilation, int epi, int reps,
+                           float* ms_per_launch) {
+    return guarded(nullptr, [&] {
+        HIP_CHECK(hipSetDevice(device));
+        if (!conv1d_mfma_supported(Cin, Cout, K, dilation) || reps < 1 || !ms_per_launch) throw EngineError(MI355VITS_ERR_INVALID, "bad arguments");
+        const int H = Cout / 2;
+        const size_t nx = (size_t)B * Cin * T, ny = (size_t)B * Cout * T, nw = (size_t)Cout * Cin * K;
+        std::vector<float> hx(nx), hw(nw), pk(mfma_packed_floats(Cout, Cin, K));
+        unsigned st = 12345u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+        for (auto& v : hx) v = rnd();
+        for (auto& v : hw) v = rnd() * 0.05f;
+        pack_conv_weights_mfma_mode(hw.data(), Cout, Cin, K, epi == 1 ? EPI_GATE : EPI_STD, pk.data());
+        DevBuf dx(nx * 4), dy(ny * 4), dy2(ny * 4), dres(ny * 4), dp(pk.size() * 4), db(Cout * 4);
+        HIP_CHECK(hipMemcpy(dx.p, hx.data(), nx * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dp.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(dy.p, 0, ny * 4));
+        HIP_CHECK(hipMemset(dy2.p, 0, ny * 4));
+        HIP_CHECK(hipMemset(dres.p, 0, ny * 4));
+        HIP_CHECK(hipMemset(db.p, 0, Cout * 4));
+        ConvArgs a;
+        a.x = dx.as<float>(); a.x_bs = (long)Cin * T; a.x_ld = T;
+        a.w = dp.as<float>(); a.bias = db.as<float>();
+        a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.K = K; a.dil = dilation; a.pad = (K * dilation - dilation) / 2;
+        if (epi == 1) {
+            a.epi = EPI_GATE; a.H = H;
+            a.y = dy.as<float>(); a.y_bs = (long)H * T; a.y_ld = T;
+        } else if (epi == 2) {
+            a.epi = EPI_RESSKIP; a.H = Cout / 2;
+            a.y = dy.as<float>(); a.y_bs = (long)a.H * T; a.y_ld = T;
+            a.y2 = dy2.as<float>(); a.y2_bs = (long)a.H * T; a.y2_ld = T;
+        } else {
+            a.y = dy.as<float>(); a.y_bs = (long)Cout * T; a.y_ld = T;
+            a.res = dres.as<float>(); a.res_bs = a.y_bs; a.res_ld = T;
+            a.in_slope = 0.1f;
+        }
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) launch_conv1d_mfma(a, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) launch_conv1d_mfma(a, nullptr);
+        HIP_CHECK(hipEventRecord(e1, nullptr));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_launch = ms / reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    });
+}
+
 int mi355vits_test_mfma_layout(int device, float* err) {
     return guarded(nullptr, [&] {
         HIP_CHECK(hipSetDevice(device));

@@ -11,6 +11,9 @@
 //                       work (bias, speaker conditioning, relu, residual, WaveNet gate, res/skip update,
 //                       coupling subtract, masks, MRF mean) is fused into the epilogue.
 //   * k_conv1d_generic — plain VALU/LDS tiled kernel for any shape; reference for tests and A/B.
+#include <cstdio>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace m355 {
@@ -514,7 +517,8 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     // large for LDS shrinks it further.
     auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= 60 * 1024; };
     int ci_c = 0;
-    for (int c = 64; c >= 2; c -= 2)
+    static const int chunk_max = [] { const char* e = getenv("MI355VITS_CONV_CHUNK"); return e ? atoi(e) : 64; }();
+    for (int c = chunk_max; c >= 2; c -= 2)
         if (a.Cin % c == 0 && fits(c)) { ci_c = c; break; }
     if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
     const size_t shmem = (size_t)ci_c * LD * sizeof(float);
@@ -554,7 +558,16 @@ void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s) {
     };
     auto fill = [&](long nb) { return (double)nb / (256.0 * (double)((nb + 255) / 256)); };
     struct Cand { int MT, NT, WM, WN; };
+    static const Cand forced = [] {
+        Cand f{0, 0, 0, 0};
+        const char* e = getenv("MI355VITS_CONV_CFG");
+        if (e) sscanf(e, "%d,%d,%d,%d", &f.MT, &f.NT, &f.WM, &f.WN);
+        return f;
+    }();
     auto choose = [&](const Cand* c, int n) {
+        if (forced.MT)
+            for (int i = 0; i < n; ++i)
+                if (c[i].MT == forced.MT && c[i].NT == forced.NT && c[i].WM == forced.WM && c[i].WN == forced.WN) return i;
         int best = n - 1;
         double bf = -1.0;
         for (int i = 0; i < n; ++i) {  // candidates ordered from the largest tile to the smallest
