@@ -234,10 +234,12 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
     for (int j = 0; j < NT; ++j) bf_n[j] = xw[j * 32];
     int k = 0, cp = 0;
     if (RING) {
-        // cpn % 8 == 0 (launcher): steps are walked in groups of 8 channel pairs of one tap, so every address in the
-        // unrolled body is the group base plus a compile-time multiple of the pitch; A through an 8-register ring
-        // four steps ahead, B through two statically indexed buffers one step ahead; no copies, no index arithmetic.
+        // cpn % 8 == 0 (launcher): steps are walked in groups of 8 channel pairs of one tap.  Per group one pointer
+        // add per tile; inside the unrolled body every A address is that pointer plus an immediate and every B address
+        // a running LDS address plus an immediate: the loop is MFMAs, loads and one address add per step.
+        // A through an 8-register ring four steps ahead, B through two statically indexed buffers one step ahead.
         const int ld2 = 2 * LD;
+        const int jump = (cpairs - cpn) * 64;  // from the end of this chunk's records of tap k to the start of tap k+1
         float ring[MT][8];
         MI355_UNROLL
         for (int u = 0; u < 4; ++u)
@@ -249,18 +251,24 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
         for (int kk = 0; kk < K; ++kk) {
             for (int cp0 = 0; cp0 < cpn; cp0 += 8) {
                 const float* base = xw + kk * dil + cp0 * ld2;
-                const bool last = (kk == K - 1) && (cp0 + 8 == cpn);
-                const float* nbase = (cp0 + 8 < cpn) ? base + 8 * ld2 : xw + (kk + 1) * dil;
-                const int woff = (kk * cpairs + cp0) * 64;
-                // A record four steps ahead: same tap while cp0 + u + 4 < cpn, else the next tap's first records
+                const bool last_of_tap = cp0 + 8 == cpn;
+                const bool last = (kk == K - 1) && last_of_tap;
+                const float* nbase = last_of_tap ? xw + (kk + 1) * dil : base + 8 * ld2;
+                const float* wg[MT];   // this group's first record
+                const float* wg2[MT];  // where records (u + 4) >= 8 live: next group of the tap, or the next tap
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) {
+                    wg[i] = wp[i] + (kk * cpairs + cp0) * 64;
+                    wg2[i] = last_of_tap ? wg[i] + jump : wg[i];
+                }
                 MI355_UNROLL
                 for (int u = 0; u < 8; ++u) {
-                    const int cpa = cp0 + u + 4;
-                    const int aoff = cpa < cpn ? woff + (u + 4) * 64 : ((kk + 1) * cpairs + (cpa - cpn)) * 64;
-                    const bool have = cpa < cpn || kk + 1 < K;
-                    if (have) {
+                    if (u < 4) {
                         MI355_UNROLL
-                        for (int i = 0; i < MT; ++i) ring[i][(u + 4) & 7] = wp[i][aoff];
+                        for (int i = 0; i < MT; ++i) ring[i][u + 4] = wg[i][(u + 4) * 64];
+                    } else if (!last) {
+                        MI355_UNROLL
+                        for (int i = 0; i < MT; ++i) ring[i][u - 4] = wg2[i][(u + 4) * 64];
                     }
                     if (u < 7) {
                         MI355_UNROLL
