@@ -19,6 +19,7 @@ typedef hipemu_f32x4 f32x4;
 #define WAVE_UNIFORM(x) (x)
 #define FAST_EXPF(x) expf(x)
 #define FAST_RCPF(x) (1.0f / (x))
+#define SCHED_FENCE() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,6 +39,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // non-linearity (WaveNet gate), not where exact rounding matters (durations, int16 scaling)
 #define FAST_EXPF(x) __expf(x)
 #define FAST_RCPF(x) __frcp_rn(x)
+// Pin the hand-written software pipeline: hipcc otherwise clusters the ring's prefetch loads into one burst right
+// before their first use (prefetch distance collapses from four k-steps to one).  Nothing moves across this point.
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 #include <cstdint>

@@ -225,7 +225,10 @@ bool conv1d_mfma_supported(int Cin, int Cout, int K, int dil) {
 // wp[i]: packed A fragments of tile i at (k = 0, first pair of the chunk), lane offset included; record (k, cp)
 // sits (k * cpairs + cp) * 64 floats further.  When the step count is a multiple of 8 the A fragments run through an
 // 8-register ring four steps ahead (no drain at the loop edge); B fragments (LDS) are fetched one step ahead.
-template <int MT, int NT, bool RING>
+// RING: -1 = plain loop (any step count); 0 = ring pipeline, runtime number of 8-step groups per tap;
+// N > 0 = ring pipeline with the N channel pairs of a tap fully unrolled (N = 32 <=> 64-channel chunks): hipcc drains
+// the vector-memory counter at every loop header, so the ring keeps its distance only inside straight-line code.
+template <int MT, int NT, int RING>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* const (&wp)[MT], const float* __restrict__ xw,
                                            int LD, int K, int cpn, int cpairs, int dil) {
     const int steps = K * cpn;
@@ -233,7 +236,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
     MI355_UNROLL
     for (int j = 0; j < NT; ++j) bf_n[j] = xw[j * 32];
     int k = 0, cp = 0;
-    if (RING) {
+    if (RING >= 0) {
         // cpn % 8 == 0 (launcher): steps are walked in groups of 8 channel pairs of one tap.  Per group one pointer
         // add per tile; inside the unrolled body every A address is that pointer plus an immediate and every B address
         // a running LDS address plus an immediate: the loop is MFMAs, loads and one address add per step.
@@ -248,32 +251,36 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
         float bb[2][NT];
         MI355_UNROLL
         for (int j = 0; j < NT; ++j) bb[0][j] = bf_n[j];
+        const int cpn_s = RING > 0 ? RING : cpn;  // compile-time when the tap is unrolled
         for (int kk = 0; kk < K; ++kk) {
-            for (int cp0 = 0; cp0 < cpn; cp0 += 8) {
+            MI355_UNROLL
+            for (int cp0 = 0; cp0 < cpn_s; cp0 += 8) {
                 const float* base = xw + kk * dil + cp0 * ld2;
-                const bool last_of_tap = cp0 + 8 == cpn;
+                const bool last_of_tap = cp0 + 8 == cpn_s;
                 const bool last = (kk == K - 1) && last_of_tap;
-                const float* nbase = last_of_tap ? xw + (kk + 1) * dil : base + 8 * ld2;
+                // (the very last group prefetches harmlessly from itself: loads stay unconditional, so the compiler's
+                //  s_waitcnt counts stay exact and the ring keeps its four-step distance)
+                const float* nbase = last ? base : (last_of_tap ? xw + (kk + 1) * dil : base + 8 * ld2);
                 const float* wg[MT];   // this group's first record
                 const float* wg2[MT];  // where records (u + 4) >= 8 live: next group of the tap, or the next tap
                 MI355_UNROLL
                 for (int i = 0; i < MT; ++i) {
                     wg[i] = wp[i] + (kk * cpairs + cp0) * 64;
-                    wg2[i] = last_of_tap ? wg[i] + jump : wg[i];
+                    wg2[i] = last ? wg[i] - 8 * 64 : (last_of_tap ? wg[i] + jump : wg[i]);
                 }
                 MI355_UNROLL
                 for (int u = 0; u < 8; ++u) {
                     if (u < 4) {
                         MI355_UNROLL
                         for (int i = 0; i < MT; ++i) ring[i][u + 4] = wg[i][(u + 4) * 64];
-                    } else if (!last) {
+                    } else {
                         MI355_UNROLL
                         for (int i = 0; i < MT; ++i) ring[i][u - 4] = wg2[i][(u + 4) * 64];
                     }
                     if (u < 7) {
                         MI355_UNROLL
                         for (int j = 0; j < NT; ++j) bb[(u + 1) & 1][j] = base[(u + 1) * ld2 + j * 32];
-                    } else if (!last) {
+                    } else {
                         MI355_UNROLL
                         for (int j = 0; j < NT; ++j) bb[0][j] = nbase[j * 32];
                     }
@@ -281,6 +288,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
                     for (int i = 0; i < MT; ++i)
                         MI355_UNROLL
                         for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(ring[i][u], bb[u & 1][j], acc[i][j]);
+                    SCHED_FENCE();
                 }
             }
         }
@@ -310,7 +318,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
     }
 }
 
-template <int MT, int NT, int WM, int WN, int EPI, bool RING>
+template <int MT, int NT, int WM, int WN, int EPI, int RING>
 __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
@@ -491,6 +499,7 @@ __global__ __launch_bounds__(256) void k_conv_direct_mfma(ConvArgs a) {
             for (int i = 0; i < MT; ++i)
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_32x32x2_F32(af[i], bf[j], acc[i][j]);
+            SCHED_FENCE();
         }
     }
 
@@ -534,11 +543,14 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     ConvArgs av = a;
     av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
-    if (((ci_c >> 1) & 7) == 0) {
-        auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, true>;
+    if (ci_c == 64) {
+        auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, 32>;
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
+    } else if (((ci_c >> 1) & 7) == 0) {
+        auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, 0>;
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
     } else {
-        auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, false>;
+        auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, -1>;
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
     }
 }

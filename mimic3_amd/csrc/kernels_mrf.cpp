@@ -44,23 +44,30 @@ __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float* 
     for (int i = 0; i < NTL; ++i) bb[0][i] = xw[i * tstride];
     const float* wg = wp;
     for (int k = 0; k < K; ++k) {
+        // all CP / 8 groups of a tap unrolled: hipcc drains the vector-memory counter at every loop header it cannot
+        // see through, so the ring only keeps its distance inside straight-line code
+        MI355_UNROLL
         for (int cp0 = 0; cp0 < CP; cp0 += 8) {
             const float* base = xw + k * dil + cp0 * ld2;
             const bool last = (k == K - 1) && (cp0 + 8 == CP);
-            const float* nbase = (cp0 + 8 < CP) ? base + 8 * ld2 : xw + (k + 1) * dil;
+            // the very last group prefetches harmlessly from itself, so every load in the body is unconditional and the
+            // compiler's s_waitcnt counts stay exact (conditional loads make it drain the ring)
+            const float* nbase = last ? base : ((cp0 + 8 < CP) ? base + 8 * ld2 : xw + (k + 1) * dil);
+            const float* wg_hi = last ? wg - 8 * 64 : wg;
             MI355_UNROLL
             for (int u = 0; u < 8; ++u) {
                 const float av = a_ring[u];
-                if (u < 4 || !last) a_ring[(u + 4) & 7] = wg[(u + 4) * 64];
+                a_ring[(u + 4) & 7] = (u < 4) ? wg[(u + 4) * 64] : wg_hi[(u + 4) * 64];
                 if (u < 7) {
                     MI355_UNROLL
                     for (int i = 0; i < NTL; ++i) bb[(u + 1) & 1][i] = base[(u + 1) * ld2 + i * tstride];
-                } else if (!last) {
+                } else {
                     MI355_UNROLL
                     for (int i = 0; i < NTL; ++i) bb[0][i] = nbase[i * tstride];
                 }
                 MI355_UNROLL
                 for (int i = 0; i < NTL; ++i) acc[i] = MFMA_32x32x2_F32(av, bb[u & 1][i], acc[i]);
+                SCHED_FENCE();
             }
             wg += 8 * 64;
         }
