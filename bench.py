@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--frames-per-id", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU-baseline sample")
     args = ap.parse_args()
 
     import torch
@@ -240,7 +240,7 @@ def main():
         cpu_once()
         times = []
         t_begin = time.perf_counter()
-        while len(times) < 3 or (time.perf_counter() - t_begin < args.cpu_seconds and len(times) < 20):
+        while len(times) < 3 or (time.perf_counter() - t_begin < args.cpu_seconds and len(times) < 500):
             t1 = time.perf_counter()
             pcm = cpu_once()
             times.append(time.perf_counter() - t1)
