@@ -357,7 +357,5 @@ class Engine:
         n2 = self.native.lib.mi355vits_get_tap(self._h, name.encode(), _fptr(out), out.size, dims)
         if n2 < 0:
             self._check(int(n2))
-        shape = [int(d) for d in dims]
-        while len(shape) > 1 and shape[-1] == 1 and int(np.prod(shape[:-1])) == n:
-            shape.pop()  # dims beyond the tensor's rank are reported as 1
+        shape = [int(d) for d in dims][:3]  # taps are [B, C, T]
         return out.reshape(shape)

@@ -47,6 +47,11 @@ class SessionOptions:
         # engine extensions (not in onnxruntime)
         self.device_id: Optional[int] = None
         self.seed: Optional[int] = None
+        # caller-side micro-batching: concurrent single-utterance run() calls of the server's
+        # worker threads that arrive within this window are synthesised as ONE batched engine call (a batch is
+        # bitwise equal to separate calls).  0 = off.  Also MI355VITS_MICROBATCH_MS.
+        self.micro_batch_window_ms: float = float(os.environ.get("MI355VITS_MICROBATCH_MS", "0") or 0)
+        self.micro_batch_max: int = 64
 
 
 class NodeArg:
@@ -97,6 +102,99 @@ def _device_from_providers(providers, provider_options, sess_options) -> int:
     return dev
 
 
+class _MicroBatcher:
+    """Coalesces concurrent B = 1 requests into batched engine calls (one dispatcher thread per session).
+
+    The reference issues one ``run`` per sentence from each of its ``--num-threads`` synthesis workers
+    (``mimic3_http/synthesis.py:88-136``); behind an unchanged API this is where batch parallelism comes from."""
+
+    def __init__(self, session: "InferenceSession", window_s: float, max_batch: int):
+        import queue
+
+        self._session = session
+        self._window = window_s
+        self._max = max(1, int(max_batch))
+        self._q: "queue.Queue" = queue.Queue()
+        self.batches = 0
+        self.requests = 0
+        self._thread = threading.Thread(target=self._loop, name="mi355vits-microbatch", daemon=True)
+        self._thread.start()
+
+    def submit(self, ids, lengths, scales, sid, kw):
+        from concurrent.futures import Future
+
+        fut: "Future" = Future()
+        self._q.put((ids, lengths, scales, sid, kw, fut))
+        return fut
+
+    def _loop(self):
+        import queue
+        import time
+
+        while True:
+            first = self._q.get()
+            if first is None:
+                return
+            items = [first]
+            deadline = time.perf_counter() + self._window
+            while len(items) < self._max:
+                left = deadline - time.perf_counter()
+                if left <= 0:
+                    break
+                try:
+                    nxt = self._q.get(timeout=left)
+                except queue.Empty:
+                    break
+                if nxt is None:
+                    self._q.put(None)
+                    break
+                items.append(nxt)
+            # only requests with identical scales / output kind can share a call (the ABI takes one `scales`)
+            groups: Dict[Any, list] = {}
+            for it in items:
+                key = (tuple(np.asarray(it[2], np.float32).tolist()), it[3] is None, tuple(sorted(it[4].items())))
+                groups.setdefault(key, []).append(it)
+            for group in groups.values():
+                self._run_group(group)
+
+    def _run_group(self, group):
+        try:
+            tx = max(int(g[0].shape[1]) for g in group)
+            B = len(group)
+            ids = np.zeros((B, tx), np.int64)
+            lens = np.zeros(B, np.int64)
+            for b, g in enumerate(group):
+                n = int(g[1][0])
+                ids[b, :n] = g[0][0, :n]
+                lens[b] = n
+            sid = None if group[0][3] is None else np.array([int(g[3][0]) for g in group], np.int64)
+            kw = dict(group[0][4])
+            out = self._session._engine_run(ids, lens, group[0][2], sid, **kw)
+            self.batches += 1
+            self.requests += B
+            for b, g in enumerate(group):
+                L = int(out["lengths"][b])
+                res = {"lengths": out["lengths"][b:b + 1].copy(), "peaks": out["peaks"][b:b + 1].copy()}
+                if "audio" in out:
+                    res["audio"] = out["audio"][b:b + 1, :L].copy()
+                if "pcm" in out:
+                    res["pcm"] = out["pcm"][b:b + 1, :L].copy()
+                g[5].set_result(res)
+        except BaseException as e:
+            if len(group) > 1:
+                # a bad request must not poison its batch-mates: fall back to one call per request
+                for g in group:
+                    if not g[5].done():
+                        self._run_group([g])
+                return
+            for g in group:  # every waiter gets its error; nobody hangs
+                if not g[5].done():
+                    g[5].set_exception(e)
+
+    def close(self):
+        self._q.put(None)
+
+
 class InferenceSession:
     """Drop-in for the object stored in ``Mimic3Voice.onnx_model``."""
 
@@ -121,6 +219,10 @@ class InferenceSession:
         self._utterances = 0
         self._lock = threading.Lock()
         self.last_lengths: Optional[np.ndarray] = None
+        self._batcher: Optional[_MicroBatcher] = None
+        if self._sess_options.micro_batch_window_ms and self._sess_options.micro_batch_window_ms > 0:
+            self._batcher = _MicroBatcher(self, self._sess_options.micro_batch_window_ms * 1e-3,
+                                          self._sess_options.micro_batch_max)
 
     # ---- onnxruntime surface ----------------------------------------------------------------
     def get_providers(self) -> List[str]:
@@ -174,18 +276,25 @@ class InferenceSession:
         if not np.issubdtype(ids.dtype, np.integer):
             raise InvalidArgument("'input' must be an int64 tensor")
         sid = input_feed.get("sid") if self.config.is_multispeaker else None
+        lengths = np.asarray(input_feed["input_lengths"]).reshape(-1)
+        if self._batcher is not None and ids.shape[0] == 1 and lengths.shape[0] == 1 and 0 <= int(lengths[0]) <= ids.shape[1]:
+            sid1 = None if sid is None else np.asarray(sid).reshape(-1)
+            out = self._batcher.submit(np.asarray(ids, np.int64), lengths.astype(np.int64), input_feed["scales"], sid1, kw).result()
+        else:
+            out = self._engine_run(ids, lengths, input_feed["scales"], sid, **kw)
+        self.last_lengths = out["lengths"]
+        return out
+
+    def _engine_run(self, ids, lengths, scales, sid, **kw) -> Dict[str, np.ndarray]:
         with self._lock:
             base = self._utterances
             self._utterances += ids.shape[0]
         try:
-            out = self._engine.run(ids, input_feed["input_lengths"], input_feed["scales"], sid, seed=self._seed,
-                                   utterance_base=base, **kw)
+            return self._engine.run(ids, lengths, scales, sid, seed=self._seed, utterance_base=base, **kw)
         except _native.NativeError as e:
             if e.code == -1:
                 raise InvalidArgument(str(e)) from None
             raise RuntimeError(str(e)) from None
-        self.last_lengths = out["lengths"]
-        return out
 
     @property
     def engine(self) -> _native.Engine:

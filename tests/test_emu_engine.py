@@ -135,6 +135,11 @@ def test_attention_across_key_and_query_tiles(emu_lib, B, Tx):
     check_parity(emu_lib, VitsConfig.tiny(), B=B, Tx=Tx, seed=40 + Tx, frames_per_id=1.2)
 
 
+def test_single_phoneme_and_fallback_attention(emu_lib):
+    check_parity(emu_lib, VitsConfig.tiny(), B=1, Tx=1, seed=51)
+    check_parity(emu_lib, VitsConfig.tiny(), B=1, Tx=530, seed=52, frames_per_id=1.05)  # T > 512: VALU attention kernel
+
+
 def test_generic_kernels_agree_with_mfma_path(emu_lib):
     """MI355VITS_FORCE_GENERIC=1 routes every conv / attention through the plain VALU kernels."""
     import os

@@ -136,3 +136,22 @@ def test_golden_shape_utterance(gpu_lib):
     assert int(out["lengths"][0]) == 253696
     assert np.abs(out["pcm"]).max() >= 32766
     eng.close()
+
+
+def test_default_modelconfig_graph_matches_oracle(gpu_lib):
+    """The reference's ModelConfig defaults (mimic3_tts/config.py:112-139): ResBlock1, kernels 3/7/11 with dilations
+    (1,3,5), four upsample stages 8-8-2-2 from 512 channels — the 'high quality' voice family."""
+    cfg = VitsConfig(num_symbols=60, resblock="1", resblock_kernel_sizes=(3, 7, 11),
+                     resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)), upsample_rates=(8, 8, 2, 2),
+                     upsample_initial_channel=512, upsample_kernel_sizes=(16, 16, 4, 4))
+    check_parity(gpu_lib, cfg, B=2, Tx=14, seed=41, frames_per_id=2.0)
+
+
+@pytest.mark.parametrize("Tx", [1, 33, 300, 600])
+def test_sequence_length_extremes(gpu_lib, Tx):
+    """One phoneme; just over one MFMA tile; 16 key tiles in registers (T <= 512); beyond that the VALU attention."""
+    check_parity(gpu_lib, VitsConfig.tiny(), B=1, Tx=Tx, seed=50 + Tx, frames_per_id=1.1)
+
+
+def test_length_scale_and_rate(gpu_lib):
+    check_parity(gpu_lib, VitsConfig.tiny_wide(), B=2, Tx=12, seed=61, scales=(0.0, 1.37, 0.0))

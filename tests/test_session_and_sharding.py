@@ -70,6 +70,44 @@ def test_session_errors_like_onnxruntime(emu_lib, tmp_path):
         InferenceSession(str(tmp_path / "nowhere" / "generator.onnx"), _library=emu_lib)
 
 
+def test_micro_batching_coalesces_concurrent_calls(emu_lib):
+    """N2: concurrent B = 1 run() calls from worker threads become batched engine calls with identical results."""
+    import threading
+
+    cfg = VitsConfig.tiny()
+    blob = W.pack(cfg, W.synthetic_weights(cfg, seed=9))
+    plain = InferenceSession(blob, _library=emu_lib)
+    so = SessionOptions()
+    so.micro_batch_window_ms = 200.0
+    so.micro_batch_max = 8
+    mb = InferenceSession(blob, sess_options=so, _library=emu_lib)
+    rng = np.random.default_rng(1)
+    feeds = []
+    for i in range(8):
+        n = int(rng.integers(3, 12))
+        feeds.append({"input": rng.integers(1, 20, (1, n)).astype(np.int64), "input_lengths": np.array([n], np.int64),
+                      "scales": np.array([0.0, 1.0 if i % 2 else 1.5, 0.0], np.float32)})
+    expect = [plain.run(None, f)[0] for f in feeds]
+    got = [None] * 8
+    errs = []
+
+    def work(i):
+        try:
+            got[i] = mb.run(None, feeds[i])[0]
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for e, g in zip(expect, got):
+        assert e.shape == g.shape and np.array_equal(e, g)
+    assert mb._batcher.requests == 8 and mb._batcher.batches < 8  # two scale groups -> 2 (or a few) engine calls
+    with pytest.raises(ValueError):  # errors propagate to the waiting caller
+        mb.run(None, {"input": np.full((1, 3), 999, np.int64), "input_lengths": np.array([3]), "scales": np.array([0, 1, 0], np.float32)})
+
+
 def test_onnxruntime_shim_module_surface():
     import mimic3_amd.onnxruntime_shim as shim
 
