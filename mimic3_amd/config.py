@@ -142,6 +142,15 @@ class VitsConfig:
         c.resblock_dilation_sizes = ((1, 2), (2, 6), (3, 12))
         return c
 
+    @staticmethod
+    def tiny_h192(n_speakers: int = 1) -> "VitsConfig":
+        """Tiny decoder / depth with the real hidden width (192): exercises the 6-wave fused WaveNet-layer kernel
+        and the head-dimension-96 attention on the CPU model."""
+        c = VitsConfig.tiny(n_speakers=n_speakers)
+        c.hidden_channels = 192
+        c.n_layers = 1
+        return c
+
     # ------------------------------------------------------------------ (de)serialisation
     @staticmethod
     def from_json(text_or_dict) -> "VitsConfig":

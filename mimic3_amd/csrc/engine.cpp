@@ -285,6 +285,8 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
     prof_.stream = stream_;
     const char* fg = getenv("MI355VITS_FORCE_GENERIC");
     force_generic_ = fg && fg[0] == '1';
+    const char* nw = getenv("MI355VITS_NO_FUSED_WN");
+    no_fused_wn_ = nw && nw[0] == '1';
     const char* nf = getenv("MI355VITS_NO_FUSED_MRF");
     no_fused_mrf_ = nf && nf[0] == '1';
 
@@ -714,27 +716,47 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         pre.out_len = d_ylen_;
         pre.B = B; pre.T = Ty;
         conv("flow.pre", cw(S("flow.%d.pre", j)), pre);
+        float* hcur = d_fh_;
+        float* hnext = d_fh2_;
         for (int l = 0; l < c.flow_wn_layers; ++l) {
             int dil = 1;
             for (int q = 0; q < l; ++q) dil *= c.flow_wn_dilation_rate;
+            const ConvW& win = cw(S("flow.%d.in.%d", j, l));
+            const ConvW& wrs = cw(S("flow.%d.rs.%d", j, l));
+            const float* cond_l = d_cond_flow_.empty() ? nullptr : d_cond_flow_[j] + (long)l * 2 * H;
+            if (!force_generic_ && !no_fused_wn_ && wn_layer_fused_supported(H, win.K, dil)) {
+                WnArgs w;
+                w.h_in = hcur; w.h_out = hnext; w.h_bs = hbs; w.h_ld = Ty;
+                w.skip = d_fskip_; w.s_bs = hbs; w.s_ld = Ty;
+                w.w_in = P(win.packed); w.b_in = P(win.bias);
+                w.w_rs = P(wrs.packed); w.b_rs = P(wrs.bias);
+                w.cond = cond_l; w.cond_bs = 2L * H * c.flow_wn_layers;
+                w.len = d_ylen_;
+                w.B = B; w.H = H; w.T = Ty; w.K = win.K; w.dil = dil; w.Crs = wrs.Cout; w.skip_init = (l == 0);
+                const double fl = 2.0 * B * (double)Ty * H * ((double)win.Cout * win.K + wrs.Cout);
+                ProfScope ps(prof_, "flow.wn_layer", fl, 4.0 * B * (double)Ty * H * 4);
+                launch_wn_layer(w, stream_);
+                if (wrs.Cout == 2 * H) std::swap(hcur, hnext);  // the last layer leaves h untouched
+                continue;
+            }
             ConvArgs in;
-            in.x = d_fh_; in.x_bs = hbs; in.x_ld = Ty;
+            in.x = hcur; in.x_bs = hbs; in.x_ld = Ty;
             in.y = d_fu_; in.y_bs = hbs; in.y_ld = Ty;
             in.epi = EPI_GATE; in.H = H; in.dil = dil;
-            if (!d_cond_flow_.empty()) {
-                in.cond = d_cond_flow_[j] + (long)l * 2 * H;
+            if (cond_l) {
+                in.cond = cond_l;
                 in.cond_bs = 2L * H * c.flow_wn_layers;
             }
             in.B = B; in.T = Ty;
-            conv("flow.in_gate", cw(S("flow.%d.in.%d", j, l)), in);
+            conv("flow.in_gate", win, in);
             ConvArgs rs;
             rs.x = d_fu_; rs.x_bs = hbs; rs.x_ld = Ty;
-            rs.y = d_fh_; rs.y_bs = hbs; rs.y_ld = Ty;
+            rs.y = hcur; rs.y_bs = hbs; rs.y_ld = Ty;
             rs.y2 = d_fskip_; rs.y2_bs = hbs; rs.y2_ld = Ty;
             rs.epi = EPI_RESSKIP; rs.H = H; rs.skip_init = (l == 0);
             rs.out_len = d_ylen_;
             rs.B = B; rs.T = Ty;
-            conv("flow.res_skip", cw(S("flow.%d.rs.%d", j, l)), rs);
+            conv("flow.res_skip", wrs, rs);
         }
         ConvArgs post;
         post.x = d_fskip_; post.x_bs = hbs; post.x_ld = Ty;
@@ -1035,7 +1057,7 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
         }
     }
     const size_t fBTy = (size_t)B * Ty;
-    size_t need_b = pad(fBTy * I * 4) + 3 * pad(fBTy * H * 4);
+    size_t need_b = pad(fBTy * I * 4) + 4 * pad(fBTy * H * 4);
     if (args.noise_z && args.scales[0] != 0.0f) need_b += pad((size_t)B * I * args.noise_z_frames * 4);
     need_b += 4 * pad((size_t)B * max_stage * 4) + pad((size_t)B * L_ * 4) + pad((size_t)B * L_ * 2);
     need_b += pad((size_t)(c.n_upsamples + 1) * B * 4);
@@ -1043,6 +1065,7 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     arena_b_.reset();
     d_z_ = arena_b_.alloc<float>(fBTy * I);
     d_fh_ = arena_b_.alloc<float>(fBTy * H);
+    d_fh2_ = arena_b_.alloc<float>(fBTy * H);
     d_fskip_ = arena_b_.alloc<float>(fBTy * H);
     d_fu_ = arena_b_.alloc<float>(fBTy * H);
     d_noise_z_ = nullptr;

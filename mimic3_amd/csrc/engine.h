@@ -137,6 +137,7 @@ class Engine {
     hipEvent_t ev_start_ = nullptr, ev_end_ = nullptr;
     bool timed_ = false;
     bool force_generic_ = false;
+    bool no_fused_wn_ = false;   // MI355VITS_NO_FUSED_WN=1: in-layer + res/skip as two launches (A/B + fallback)
     bool no_fused_mrf_ = false;  // MI355VITS_NO_FUSED_MRF=1: conv-by-conv resblocks (A/B + fallback)
     Profiler prof_;
 
@@ -164,6 +165,7 @@ class Engine {
     float *d_cond_dp_ = nullptr, *d_cond_dec_ = nullptr;
     std::vector<float*> d_cond_flow_;
     // phase-B buffers (sized by B, Ty)
+    float* d_fh2_ = nullptr;  // second h buffer of the fused WaveNet layers (ping-pong)
     float *d_z_ = nullptr, *d_fh_ = nullptr, *d_fu_ = nullptr, *d_fskip_ = nullptr, *d_noise_z_ = nullptr;
     float *d_bufA_ = nullptr, *d_bufB_ = nullptr, *d_bufT_ = nullptr, *d_bufC_ = nullptr;
     float* d_audio_ = nullptr;

@@ -88,6 +88,23 @@ struct MrfArgs {
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);
 
+// ---------------------------------------------------------------- fused WaveNet layer of the coupling flow (K8)
+// u = tanh(in(h)[:H] + cond) * sigmoid(in(h)[H:] + cond); rs = res_skip(u); h' = (h + rs[:H]) * mask; skip += rs[H:]
+struct WnArgs {
+    const float* h_in = nullptr; float* h_out = nullptr; long h_bs = 0; int h_ld = 0;  // [B,H,T], ping-pong
+    float* skip = nullptr; long s_bs = 0; int s_ld = 0;                                 // [B,H,T]
+    const float* w_in = nullptr;   // MFMA-packed, gate tile map [2*H/32][K][H/2][64]
+    const float* b_in = nullptr;   // [2H]
+    const float* w_rs = nullptr;   // MFMA-packed [Crs/32][1][H/2][64]
+    const float* b_rs = nullptr;   // [Crs]
+    const float* cond = nullptr; long cond_bs = 0;  // this layer's [B][2H] conditioning slice or null
+    const int* len = nullptr;
+    int B = 1, H = 0, T = 0, K = 1, dil = 1, Crs = 0, skip_init = 0;
+    int ldx = 0, vec = 0;  // filled by the launcher
+};
+bool wn_layer_fused_supported(int H, int K, int dil);
+void launch_wn_layer(WnArgs a, hipStream_t s);
+
 // ---------------------------------------------------------------- decoder tail
 // y = tanh(conv_post(lrelu_0.01(x * mask))) (Cout = 1, no bias) + per-utterance max|y| over valid samples;
 // mask = t < valid_len[b]: every row of a batch is synthesised as if it were alone (zero padding at its own end).

@@ -1,0 +1,181 @@
+// kernels_wn.cpp — one WaveNet layer of the residual-coupling flow as ONE kernel.
+//
+//   a  = in_l(h) [+ cond_l(g)]              k=5 conv, H -> 2H
+//   u  = tanh(a[:H]) * sigmoid(a[H:])
+//   rs = res_skip_l(u)                      1x1 conv, H -> 2H (last layer: H -> H)
+//   h' = (h + rs[:H]) * mask ;  skip += rs[H:]        (last layer: skip += rs)
+//
+// Layer-at-a-time this is two launches and moves u (H x T) through HBM; here a workgroup owns 32 time columns of ALL
+// channels: the h tile (+halo) is staged once into LDS, wave p of the H/32 waves computes gate pair p (rows c and
+// H + c land in the same lane, so the gate is pure register math), u goes to a second LDS tile, and the same waves
+// run the 1x1 conv from it: wave p produces rows {c, H + c} again, i.e. exactly its own slice of h' and of skip.
+// Both MFMA operand streams follow the pipeline of kernels_mrf.cpp (A: 8-register rings four steps ahead from
+// L2; B: LDS, one step ahead; taps unrolled).  h is read from one buffer and written to another (neighbouring
+// workgroups read each other's halo columns).
+#include "kernels.h"
+
+namespace m355 {
+
+// two output tiles (A streams wp0 / wp1), one 32-column tile, K taps x CP channel pairs, accumulate into acc0/acc1
+template <int CP>
+__device__ __forceinline__ void wn_mfma2(f32x16& acc0, f32x16& acc1, const float* __restrict__ wp0,
+                                         const float* __restrict__ wp1, const float* __restrict__ xw, int LD, int K, int dil) {
+    static_assert(CP % 8 == 0, "channel pairs per tap must be a multiple of 8");
+    const int ld2 = 2 * LD;
+    float r0[8], r1[8];
+    MI355_UNROLL
+    for (int u = 0; u < 4; ++u) { r0[u] = wp0[u * 64]; r1[u] = wp1[u * 64]; }
+    float bb[2];
+    bb[0] = xw[0];
+    const float* g0 = wp0;
+    const float* g1 = wp1;
+    for (int k = 0; k < K; ++k) {
+        MI355_UNROLL
+        for (int cp0 = 0; cp0 < CP; cp0 += 8) {
+            const float* base = xw + k * dil + cp0 * ld2;
+            const bool last = (k == K - 1) && (cp0 + 8 == CP);
+            const float* nbase = last ? base : ((cp0 + 8 < CP) ? base + 8 * ld2 : xw + (k + 1) * dil);
+            const float* h0 = last ? g0 - 8 * 64 : g0;  // the last group prefetches harmlessly from itself
+            const float* h1 = last ? g1 - 8 * 64 : g1;
+            MI355_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const float a0 = r0[u], a1 = r1[u];
+                r0[(u + 4) & 7] = (u < 4) ? g0[(u + 4) * 64] : h0[(u + 4) * 64];
+                r1[(u + 4) & 7] = (u < 4) ? g1[(u + 4) * 64] : h1[(u + 4) * 64];
+                bb[(u + 1) & 1] = (u < 7) ? base[(u + 1) * ld2] : nbase[0];
+                acc0 = MFMA_32x32x2_F32(a0, bb[u & 1], acc0);
+                acc1 = MFMA_32x32x2_F32(a1, bb[u & 1], acc1);
+                SCHED_FENCE();
+            }
+            g0 += 8 * 64;
+            g1 += 8 * 64;
+        }
+    }
+}
+
+template <int NP>  // H = 32 * NP hidden channels, NP waves
+__global__ __launch_bounds__(64 * NP) void k_wn_layer(WnArgs a) {
+    constexpr int H = 32 * NP;
+    constexpr int CP = H / 2;
+    constexpr int T_B = 32;
+    DYN_SMEM(float, smem);
+    const int LDX = a.ldx;
+    float* X = smem;            // [H][LDX] h tile (+halo), zero outside the row
+    float* U = smem + H * LDX;  // [H][32]  gated activations
+    const int tid = threadIdx.x, lane = tid & 63, p = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * T_B;
+    int len = a.len ? a.len[b] : a.T;
+    if (len > a.T) len = a.T;
+    const int pad = (a.K - 1) / 2 * a.dil;
+    const int tlo = t0 - pad;
+    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
+    const int toff = tlo - ts;
+
+    {   // stage h[b, :, ts : ts + LDX)
+        const float* hb = a.h_in + (long)b * a.h_bs;
+        if (a.vec) {
+            const int ld4 = LDX >> 2;
+            for (int idx = tid; idx < H * ld4; idx += 64 * NP) {
+                const int r = idx / ld4, c4 = idx - r * ld4;
+                const int t = ts + 4 * c4;
+                const float* row = hb + (long)r * a.h_ld;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (t >= 0 && t + 3 < len) {
+                    v = *reinterpret_cast<const float4*>(row + t);
+                } else {
+                    if (t >= 0 && t < len) v.x = row[t];
+                    if (t + 1 >= 0 && t + 1 < len) v.y = row[t + 1];
+                    if (t + 2 >= 0 && t + 2 < len) v.z = row[t + 2];
+                    if (t + 3 >= 0 && t + 3 < len) v.w = row[t + 3];
+                }
+                *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = v;
+            }
+        } else {
+            for (int idx = tid; idx < H * LDX; idx += 64 * NP) {
+                const int r = idx / LDX, c = idx - r * LDX;
+                const int t = ts + c;
+                X[idx] = (t >= 0 && t < len) ? hb[(long)r * a.h_ld + t] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int t = t0 + bcol;
+    // ---- in-layer conv (gate pair p) + gate
+    {
+        f32x16 acc0, acc1;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            float v0 = a.b_in[c], v1 = a.b_in[H + c];
+            if (a.cond) { v0 += a.cond[(long)b * a.cond_bs + c]; v1 += a.cond[(long)b * a.cond_bs + H + c]; }
+            acc0[r] = v0;
+            acc1[r] = v1;
+        }
+        const float* wp0 = a.w_in + (long)(2 * p) * a.K * CP * 64 + lane;
+        const float* wp1 = wp0 + (long)a.K * CP * 64;
+        wn_mfma2<CP>(acc0, acc1, wp0, wp1, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(acc0[r], -15.0f), 15.0f));
+            const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
+            const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(acc1[r], -30.0f), 30.0f)));
+            U[c * 32 + bcol] = th * sg;
+        }
+    }
+    __syncthreads();
+    // ---- res/skip 1x1 conv: rows c (-> h') and H + c (-> skip); last layer: rows c -> skip
+    {
+        const bool two = a.Crs == 2 * H;
+        f32x16 acc0, acc1;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            acc0[r] = a.b_rs[c];
+            acc1[r] = two ? a.b_rs[H + c] : 0.0f;
+        }
+        const float* wp0 = a.w_rs + (long)p * CP * 64 + lane;
+        const float* wp1 = two ? a.w_rs + (long)(NP + p) * CP * 64 + lane : wp0;
+        wn_mfma2<CP>(acc0, acc1, wp0, wp1, U + brow * 32 + bcol, 32, 1, 0);
+        if (t < a.T) {
+            const bool live = t < len;
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                float* sp = a.skip + (long)b * a.s_bs + (long)c * a.s_ld + t;
+                if (two) {
+                    const float hv = X[c * LDX + toff + pad + bcol] + acc0[r];
+                    a.h_out[(long)b * a.h_bs + (long)c * a.h_ld + t] = live ? hv : 0.0f;
+                    *sp = a.skip_init ? acc1[r] : *sp + acc1[r];
+                } else {
+                    *sp = a.skip_init ? acc0[r] : *sp + acc0[r];
+                }
+            }
+        }
+    }
+}
+
+bool wn_layer_fused_supported(int H, int K, int dil) {
+    return (H == 32 || H == 192) && (K % 2) == 1 && K >= 1 && dil >= 1 && (size_t)H * (32 + (K - 1) * dil + 8 + 32) * 4 <= 64 * 1024;
+}
+
+void launch_wn_layer(WnArgs a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    if (!wn_layer_fused_supported(a.H, a.K, a.dil)) throw std::runtime_error("wn_layer: unsupported shape");
+    a.ldx = (32 + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
+    const size_t shmem = (size_t)a.H * (a.ldx + 32) * sizeof(float);
+    dim3 grid((a.T + 31) / 32, a.B);
+    if (a.H == 192) {
+        auto k = k_wn_layer<6>;
+        LAUNCH_KERNEL(k, grid, dim3(384), shmem, s, a);
+    } else {
+        auto k = k_wn_layer<1>;
+        LAUNCH_KERNEL(k, grid, dim3(64), shmem, s, a);
+    }
+}
+
+}  // namespace m355

@@ -164,6 +164,24 @@ def test_generic_kernels_agree_with_mfma_path(emu_lib):
         assert rel_rms(a["audio"][r, :L], b["audio"][r, :L]) < 1e-5
 
 
+def test_fused_wavenet_layer_hidden_192(emu_lib):
+    """Flow with the real hidden width: k_wn_layer<6> (in-layer conv + gate + res/skip in one kernel, h ping-pong),
+    multi-speaker conditioning included; also against the two-launch path."""
+    import os
+
+    cfg = VitsConfig.tiny_h192(n_speakers=3)
+    w = W.synthetic_weights(cfg, seed=71, frames_per_id=3.0)
+    out, _ = check_parity(emu_lib, cfg, B=2, Tx=14, seed=71, weights=w)
+    os.environ["MI355VITS_NO_FUSED_WN"] = "1"
+    try:
+        out2, _ = check_parity(emu_lib, cfg, B=2, Tx=14, seed=71, weights=w)
+    finally:
+        del os.environ["MI355VITS_NO_FUSED_WN"]
+    for b in range(2):
+        L = int(out["lengths"][b])
+        assert rel_rms(out["audio"][b, :L], out2["audio"][b, :L]) < 1e-5
+
+
 def test_odd_flow_depth_folds_final_flip(emu_lib):
     cfg = VitsConfig.tiny()
     cfg.flow_n_flows = 3
