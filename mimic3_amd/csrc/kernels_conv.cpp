@@ -521,6 +521,77 @@ __global__ __launch_bounds__(256) void k_conv_direct_mfma(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-K variant of the LDS-free kernel for deep, short convs (encoder FFN conv_2: K x C_in = 3 x 768 = 1152
+// k-steps over only 128 phonemes).  One workgroup = one 32 x 32 output tile; its four waves each take a quarter of
+// the k-steps, then reduce through LDS in a fixed order (deterministic) and every wave finishes 4 of the 16 row
+// groups.  Grid = all output tiles (768 at batch 32) instead of a quarter of them, with k-chains a quarter as long.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void k_conv_direct_splitk(ConvArgs a) {
+    DYN_SMEM(float, red);  // [4 waves][16 regs][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32;
+    const int tile = blockIdx.y;
+    const int cpairs = a.Cin >> 1;
+    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
+    int tend = a.in_len ? a.in_len[b] : Tin;
+    if (tend > Tin) tend = Tin;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+
+    f32x16 acc;
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float* wp = a.w + (long)tile * a.K * cpairs * 64 + lane;
+    const float* xrow = a.x + (long)b * a.x_bs + (long)brow * a.x_ld;
+    const int tj = t0 - a.pad + bcol;
+    const long xstep = 2L * a.x_ld;
+    const int steps = (a.K * cpairs) >> 2;  // per wave; multiple of 8 (launcher)
+    const int s_begin = wid * steps;
+    int kp = s_begin / cpairs, cpp = s_begin - kp * cpairs;  // prefetch stream position
+    const int k_end = a.K;
+    float ra[8], rb[8];
+    auto fetch = [&](int slot) {
+        const int kk = kp < k_end ? kp : k_end - 1;
+        const int cc = kp < k_end ? cpp : cpairs - 1;
+        ra[slot] = wp[(kk * cpairs + cc) * 64];
+        const int t = tj + kk * a.dil;
+        rb[slot] = (t >= 0 && t < tend) ? xrow[cc * xstep + t] : 0.0f;
+        if (++cpp == cpairs) { cpp = 0; ++kp; }
+    };
+    MI355_UNROLL
+    for (int u = 0; u < 4; ++u) fetch(u);
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+        MI355_UNROLL
+        for (int u = 0; u < 8; ++u) {
+            const float af = ra[u];
+            const float bf = lrelu_f(rb[u], a.in_slope);
+            fetch((u + 4) & 7);
+            acc = MFMA_32x32x2_F32(af, bf, acc);
+            SCHED_FENCE();
+        }
+    }
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    const int t = t0 + bcol;
+    if (t < a.T) {
+        MI355_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * wid + q;
+            const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
+                            red[(3 * 16 + r) * 64 + lane];
+            const int co = 32 * tile + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            if (co < a.Cout) {
+                if (EPI == EPI_RESSKIP) epi_resskip(a, b, co, t, v, out_len);
+                else epi_std(a, b, co, t, v, out_len);
+            }
+        }
+    }
+}
+
 namespace {
 
 struct TileCfg { int MT, NT, WM, WN; };
@@ -601,6 +672,14 @@ void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s) {
     // hide the stage/barrier cycle of the staged kernel
     const bool direct = a.epi != EPI_GATE && !a.shuf_s && ((a.K * (a.Cin >> 1)) % 8) == 0 &&
                         (a.K == 1 || (a.K <= 3 && a.T <= 512));
+    // deep + short (encoder FFN conv_2): split the k-steps over the four waves of a workgroup.  The rule looks at the
+    // layer shape only, never at the batch size, so a row's bits do not depend on what it is batched with.
+    if (direct && a.epi == EPI_STD && a.T <= 512 && a.K * (a.Cin >> 1) >= 512 && ((a.K * (a.Cin >> 1)) % 32) == 0) {
+        dim3 grid((a.T + 31) / 32, n_tiles, a.B);
+        auto kfn = k_conv_direct_splitk<EPI_STD>;
+        LAUNCH_KERNEL(kfn, grid, dim3(256), 4 * 16 * 64 * sizeof(float), s, a);
+        return;
+    }
     if (a.epi == EPI_GATE) {
         const Cand c[] = {{2, 2, 2, 2}, {2, 1, 2, 2}};
         if (choose(c, 2) == 0) launch_cfg<2, 2, 2, 2, EPI_GATE>(a, n_tiles, s);

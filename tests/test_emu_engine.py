@@ -24,6 +24,7 @@ CONV_CASES = [
     (1, 6, 70, 129, 5, 2),
     (2, 64, 29, 33, 1, 1),
     (1, 96, 96, 64, 5, 1),
+    (2, 384, 40, 45, 3, 1),  # deep + short: split-K kernel (encoder FFN conv_2 shape class)
 ]
 
 
