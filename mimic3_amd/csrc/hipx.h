@@ -20,6 +20,7 @@ typedef hipemu_f32x4 f32x4;
 #define FAST_EXPF(x) expf(x)
 #define FAST_RCPF(x) (1.0f / (x))
 #define SCHED_FENCE() ((void)0)
+#define MIN_WAVES_PER_SIMD(n)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,6 +43,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Pin the hand-written software pipeline: hipcc otherwise clusters the ring's prefetch loads into one burst right
 // before their first use (prefetch distance collapses from four k-steps to one).  Nothing moves across this point.
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// register budget: ask the compiler to keep the kernel within 512 / n registers per lane
+#define MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
 
 #include <cstdint>

@@ -101,6 +101,7 @@ struct WnArgs {
     const int* len = nullptr;
     int B = 1, H = 0, T = 0, K = 1, dil = 1, Crs = 0, skip_init = 0;
     int ldx = 0, vec = 0;  // filled by the launcher
+    int ablate = 0;        // timing experiments only (MI355VITS_WN_ABLATE): 1 no MFMA loops, 2 no staging, 4 no stores
 };
 bool wn_layer_fused_supported(int H, int K, int dil);
 void launch_wn_layer(WnArgs a, hipStream_t s);

@@ -54,14 +54,14 @@ __device__ __forceinline__ void wn_mfma2(f32x16& acc0, f32x16& acc1, const float
 }
 
 template <int NP>  // H = 32 * NP hidden channels, NP waves
-__global__ __launch_bounds__(64 * NP) void k_wn_layer(WnArgs a) {
+__global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_wn_layer(WnArgs a) {
     constexpr int H = 32 * NP;
     constexpr int CP = H / 2;
     constexpr int T_B = 32;
     DYN_SMEM(float, smem);
     const int LDX = a.ldx;
-    float* X = smem;            // [H][LDX] h tile (+halo), zero outside the row
-    float* U = smem + H * LDX;  // [H][32]  gated activations
+    float* X = smem;  // [H][LDX] h tile (+halo), zero outside the row
+    float* U = smem;  // [H][32]  gated activations; reuses the h tile's space once the in-layer conv is done
     const int tid = threadIdx.x, lane = tid & 63, p = WAVE_UNIFORM(tid >> 6);
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.y;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * NP) void k_wn_layer(WnArgs a) {
     const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
     const int toff = tlo - ts;
 
-    {   // stage h[b, :, ts : ts + LDX)
+    if (!(a.ablate & 2)) {   // stage h[b, :, ts : ts + LDX)
         const float* hb = a.h_in + (long)b * a.h_bs;
         if (a.vec) {
             const int ld4 = LDX >> 2;
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64 * NP) void k_wn_layer(WnArgs a) {
 
     const int t = t0 + bcol;
     // ---- in-layer conv (gate pair p) + gate
+    f32x16 gate, hres;
     {
         f32x16 acc0, acc1;
         MI355_UNROLL
@@ -116,15 +117,22 @@ __global__ __launch_bounds__(64 * NP) void k_wn_layer(WnArgs a) {
         }
         const float* wp0 = a.w_in + (long)(2 * p) * a.K * CP * 64 + lane;
         const float* wp1 = wp0 + (long)a.K * CP * 64;
-        wn_mfma2<CP>(acc0, acc1, wp0, wp1, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
+        if (!(a.ablate & 1)) wn_mfma2<CP>(acc0, acc1, wp0, wp1, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
-            const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
             const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(acc0[r], -15.0f), 15.0f));
             const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
             const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(acc1[r], -30.0f), 30.0f)));
-            U[c * 32 + bcol] = th * sg;
+            gate[r] = th * sg;
+            const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            hres[r] = X[c * LDX + toff + pad + bcol];
         }
+    }
+    __syncthreads();  // every wave is done with the h tile: U takes its place
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
+        U[c * 32 + bcol] = gate[r];
     }
     __syncthreads();
     // ---- res/skip 1x1 conv: rows c (-> h') and H + c (-> skip); last layer: rows c -> skip
@@ -134,21 +142,20 @@ __global__ __launch_bounds__(64 * NP) void k_wn_layer(WnArgs a) {
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            acc0[r] = a.b_rs[c];
+            acc0[r] = two ? a.b_rs[c] + hres[r] : a.b_rs[c];
             acc1[r] = two ? a.b_rs[H + c] : 0.0f;
         }
         const float* wp0 = a.w_rs + (long)p * CP * 64 + lane;
         const float* wp1 = two ? a.w_rs + (long)(NP + p) * CP * 64 + lane : wp0;
-        wn_mfma2<CP>(acc0, acc1, wp0, wp1, U + brow * 32 + bcol, 32, 1, 0);
-        if (t < a.T) {
+        if (!(a.ablate & 1)) wn_mfma2<CP>(acc0, acc1, wp0, wp1, U + brow * 32 + bcol, 32, 1, 0);
+        if (t < a.T && !((a.ablate & 4) && acc0[0] != 1.2345f)) {
             const bool live = t < len;
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
                 float* sp = a.skip + (long)b * a.s_bs + (long)c * a.s_ld + t;
                 if (two) {
-                    const float hv = X[c * LDX + toff + pad + bcol] + acc0[r];
-                    a.h_out[(long)b * a.h_bs + (long)c * a.h_ld + t] = live ? hv : 0.0f;
+                    a.h_out[(long)b * a.h_bs + (long)c * a.h_ld + t] = live ? acc0[r] : 0.0f;
                     *sp = a.skip_init ? acc1[r] : *sp + acc1[r];
                 } else {
                     *sp = a.skip_init ? acc0[r] : *sp + acc0[r];
@@ -159,15 +166,17 @@ __global__ __launch_bounds__(64 * NP) void k_wn_layer(WnArgs a) {
 }
 
 bool wn_layer_fused_supported(int H, int K, int dil) {
-    return (H == 32 || H == 192) && (K % 2) == 1 && K >= 1 && dil >= 1 && (size_t)H * (32 + (K - 1) * dil + 8 + 32) * 4 <= 64 * 1024;
+    return (H == 32 || H == 192) && (K % 2) == 1 && K >= 1 && dil >= 1 && (size_t)H * (32 + (K - 1) * dil + 8) * 4 <= 64 * 1024;
 }
 
 void launch_wn_layer(WnArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!wn_layer_fused_supported(a.H, a.K, a.dil)) throw std::runtime_error("wn_layer: unsupported shape");
     a.ldx = (32 + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    static const int ablate = getenv("MI355VITS_WN_ABLATE") ? atoi(getenv("MI355VITS_WN_ABLATE")) : 0;
+    a.ablate = ablate;
     a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
-    const size_t shmem = (size_t)a.H * (a.ldx + 32) * sizeof(float);
+    const size_t shmem = (size_t)a.H * a.ldx * sizeof(float);  // ldx >= 32: U fits in the h tile
     dim3 grid((a.T + 31) / 32, a.B);
     if (a.H == 192) {
         auto k = k_wn_layer<6>;

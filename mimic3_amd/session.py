@@ -9,8 +9,9 @@ meanings and error behaviour (Python exceptions, never partial audio) and forwar
 through the C ABI (``include/mi355vits.h``).  There is no CPU execution path here.
 
 Voice files: the reference passes ``<voice_dir>/generator.onnx`` (``voice.py:273``).  The engine reads the
-voice from ``generator.m355`` beside it (weights + hyper-parameters, written by
-``mimic3_amd.weights.save``); a path that already ends in ``.m355`` is used as is.
+voice from ``generator.m355`` beside it (weights + hyper-parameters, written by ``mimic3_amd.weights.save`` or
+``python -m mimic3_amd.onnx_import``) when that exists and is not older than the ``.onnx``; otherwise the ONNX
+initialisers are converted in memory at load time.  A path that already ends in ``.m355`` is used as is.
 """
 from __future__ import annotations
 
@@ -68,18 +69,39 @@ class InvalidArgument(ValueError):
     """Bad feed (what onnxruntime reports as ``InvalidArgument``)."""
 
 
-def resolve_voice_file(path: Union[str, os.PathLike]) -> str:
+def resolve_voice_file(path: Union[str, os.PathLike]) -> Union[str, bytes]:
+    """What to hand the engine for the model path Mimic 3 passes (``voice.py:273,403``): the ``.m355`` container
+    beside it when there is one, otherwise the ONNX file's initialisers converted in memory
+    (``mimic3_amd.onnx_import``).  ``python -m mimic3_amd.onnx_import generator.onnx`` writes the
+    container once so that later loads skip the conversion."""
     p = os.fspath(path)
     if p.endswith(".m355"):
-        cand = p
-    else:
-        cand = os.path.splitext(p)[0] + ".m355"
-    if not os.path.isfile(cand):
-        raise FileNotFoundError(
-            f"{cand} not found. The MI355X engine loads voices from an .m355 container placed beside "
-            f"generator.onnx (see INTEGRATION.md); converting ONNX initialisers is not available in this build."
-        )
-    return cand
+        if not os.path.isfile(p):
+            raise FileNotFoundError(f"{p} not found")
+        return p
+    cand = os.path.splitext(p)[0] + ".m355"
+    if os.path.isfile(cand) and (not os.path.isfile(p) or os.path.getmtime(cand) >= os.path.getmtime(p)):
+        return cand
+    if not os.path.isfile(p):
+        raise FileNotFoundError(f"neither {p} nor {cand} found (see INTEGRATION.md)")
+    from . import onnx_import
+    with open(p, "rb") as f:
+        blob = f.read()
+    try:
+        return onnx_import.onnx_to_m355_bytes(blob, onnx_import.load_voice_config(p), p)
+    except onnx_import.OnnxImportError as e:
+        raise InvalidArgument(f"cannot load {p}: {e}") from e
+
+
+def _model_bytes(blob: bytes) -> bytes:
+    """``InferenceSession(model_bytes)``: an ``.m355`` container as is, anything else is taken for an ONNX model."""
+    if blob[:8] == b"M355VITS":
+        return blob
+    from . import onnx_import
+    try:
+        return onnx_import.onnx_to_m355_bytes(blob)
+    except onnx_import.OnnxImportError as e:
+        raise InvalidArgument(f"cannot load model bytes: {e}") from e
 
 
 def _device_from_providers(providers, provider_options, sess_options) -> int:
@@ -207,11 +229,11 @@ class InferenceSession:
         device = _device_from_providers(providers, provider_options, self._sess_options)
         library = kwargs.pop("_library", None)  # tests only: an explicit NativeLibrary
         if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
-            weights = bytes(path_or_bytes)
+            weights = _model_bytes(bytes(path_or_bytes))
             self._model_path = None
         else:
-            self._model_path = resolve_voice_file(path_or_bytes)
-            weights = self._model_path
+            weights = resolve_voice_file(path_or_bytes)
+            self._model_path = weights if isinstance(weights, str) else os.fspath(path_or_bytes)
         self._engine = _native.Engine(weights, device=device, library=library)
         self.config: VitsConfig = self._engine.config
         seed = self._sess_options.seed

@@ -51,3 +51,22 @@ def test_session_is_thread_safe_like_shared_ort_sessions(tmp_path):
     [t.join() for t in ts]
     for e, g in zip(expect, got):
         assert np.array_equal(e, g)
+
+
+def test_session_loads_generator_onnx_with_folded_weight_norm(tmp_path):
+    """The voice as Mimic 3 ships it: generator.onnx + config.json, weight-normed convs folded into anonymous
+    initialisers by torch.onnx.export.  No .m355 beside it: converted at load."""
+    from tests.onnx_fixture import export_onnx
+
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=8, frames_per_id=2.0)
+    (tmp_path / "generator.onnx").write_bytes(export_onnx(cfg, w, weight_norm_prefixes=("flow.", "dec.")))
+    (tmp_path / "config.json").write_text(cfg.to_json())
+    sess = InferenceSession(str(tmp_path / "generator.onnx"))
+    assert sess.config.resblock == "2" and tuple(sess.config.upsample_rates) == (8, 8, 4)
+    ids = np.expand_dims(np.random.default_rng(5).integers(1, 50, 20).astype(np.int64), 0)
+    feed = {"input": ids, "input_lengths": np.array([20], np.int64), "scales": np.array([0.0, 1.0, 0.0], np.float32)}
+    audio = sess.run(None, feed)[0].squeeze()
+    r = VitsOracle(cfg, w).infer(ids, feed["input_lengths"], feed["scales"])["audio"][0, 0]
+    assert audio.shape == r.shape
+    assert np.sqrt(np.mean((audio - r) ** 2)) / np.sqrt(np.mean(r ** 2)) < 1e-4
