@@ -43,16 +43,27 @@ __global__ __launch_bounds__(64) void k_rel_attention_mfma(const float* __restri
     for (int t = 0; t < NKT; ++t)
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) st[t][r] = 0.0f;
-    for (int cp = 0; cp < d / 2; ++cp) {
-        const int c = 2 * cp + brow;
-        const float qv = iq ? qb[(long)c * T + i] * scale : 0.0f;         // B[k=c][col=i]
-        const float ekv = bcol < nrel ? ek[bcol * d + c] : 0.0f;          // A[row=r][k=c]
-        rl = MFMA_32x32x2_F32(ekv, qv, rl);
+    // U channel pairs per trip: all their loads are issued before the first MFMA needs one (the loop is latency-bound)
+    constexpr int U = NKT <= 4 ? 4 : (NKT <= 8 ? 2 : 1);
+    for (int cp0 = 0; cp0 < d / 2; cp0 += U) {
+        float qv[U], ekv[U], kv[U][NKT];
         MI355_UNROLL
-        for (int t = 0; t < NKT; ++t) {
-            const int j = t * 32 + bcol;
-            const float kv = j < T ? kb[(long)c * T + j] : 0.0f;          // A[row=j][k=c]
-            st[t] = MFMA_32x32x2_F32(kv, qv, st[t]);
+        for (int u = 0; u < U; ++u) {
+            const int c = 2 * (cp0 + u) + brow;
+            const bool cin = c < d;  // a partial last trip multiplies zeros
+            qv[u] = (iq && cin) ? qb[(long)c * T + i] * scale : 0.0f;          // B[k=c][col=i]
+            ekv[u] = (bcol < nrel && cin) ? ek[bcol * d + c] : 0.0f;           // A[row=r][k=c]
+            MI355_UNROLL
+            for (int t = 0; t < NKT; ++t) {
+                const int j = t * 32 + bcol;
+                kv[u][t] = (j < T && cin) ? kb[(long)c * T + j] : 0.0f;        // A[row=j][k=c]
+            }
+        }
+        MI355_UNROLL
+        for (int u = 0; u < U; ++u) {
+            rl = MFMA_32x32x2_F32(ekv[u], qv[u], rl);
+            MI355_UNROLL
+            for (int t = 0; t < NKT; ++t) st[t] = MFMA_32x32x2_F32(kv[u][t], qv[u], st[t]);
         }
     }
     // rel-k logits -> LDS table [r][i]

@@ -165,8 +165,194 @@ __global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_
     }
 }
 
+
+// MT output tiles (A streams wp[m]), one 32-column tile, K taps x CP channel pairs
+template <int MT, int CP>
+__device__ __forceinline__ void wn_mfma(f32x16 (&acc)[MT], const float* const (&wp)[MT], const float* __restrict__ xw, int LD,
+                                        int K, int dil) {
+    static_assert(CP % 8 == 0, "channel pairs per tap must be a multiple of 8");
+    const int ld2 = 2 * LD;
+    float ra[MT][8];
+    const float* g[MT];
+    MI355_UNROLL
+    for (int m = 0; m < MT; ++m) {
+        g[m] = wp[m];
+        MI355_UNROLL
+        for (int u = 0; u < 4; ++u) ra[m][u] = wp[m][u * 64];
+    }
+    float bb[2];
+    bb[0] = xw[0];
+    for (int k = 0; k < K; ++k) {
+        MI355_UNROLL
+        for (int cp0 = 0; cp0 < CP; cp0 += 8) {
+            const float* base = xw + k * dil + cp0 * ld2;
+            const bool last = (k == K - 1) && (cp0 + 8 == CP);
+            const float* nbase = last ? base : ((cp0 + 8 < CP) ? base + 8 * ld2 : xw + (k + 1) * dil);
+            const int back = last ? 8 * 64 : 0;  // the last group prefetches harmlessly from itself
+            MI355_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                float av[MT];
+                MI355_UNROLL
+                for (int m = 0; m < MT; ++m) {
+                    av[m] = ra[m][u];
+                    ra[m][(u + 4) & 7] = (u < 4) ? g[m][(u + 4) * 64] : (g[m] - back)[(u + 4) * 64];
+                }
+                bb[(u + 1) & 1] = (u < 7) ? base[(u + 1) * ld2] : nbase[0];
+                MI355_UNROLL
+                for (int m = 0; m < MT; ++m) acc[m] = MFMA_32x32x2_F32(av[m], bb[u & 1], acc[m]);
+                SCHED_FENCE();
+            }
+            MI355_UNROLL
+            for (int m = 0; m < MT; ++m) g[m] += 8 * 64;
+        }
+    }
+}
+
+// H = 192: four waves, each three of the twelve 32-row tiles of either conv, 32 time columns per workgroup.  With
+// three MFMA tiles per wave and three workgroups per CU every SIMD carries exactly three waves (six waves of two
+// tiles leave the SIMDs 5/5/4/4), and fewer, fatter waves run the operand streams closer to the matrix-core rate
+// (tools/mfma_ceiling.hip).  The price: tanh and sigmoid rows of a gate pair now sit in different waves, so the raw
+// in-layer result takes a round trip through LDS (it reuses the h tile's space) before gating.
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnArgs a) {
+    constexpr int H = 192, CP = 96, NTILE = 12;
+    DYN_SMEM(float, smem);
+    const int LDX = a.ldx;
+    float* X = smem;  // [H][LDX] h tile (+halo), zero outside the row; later A [2H][32] raw in-layer result, U = A[:H]
+    const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 32;
+    int len = a.len ? a.len[b] : a.T;
+    if (len > a.T) len = a.T;
+    const int pad = (a.K - 1) / 2 * a.dil;
+    const int tlo = t0 - pad;
+    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
+    const int toff = tlo - ts;
+    const float* hb = a.h_in + (long)b * a.h_bs;
+    if (!(a.ablate & 2)) {
+        if (a.vec) {
+            const int ld4 = LDX >> 2;
+            for (int idx = tid; idx < H * ld4; idx += 256) {
+                const int r = idx / ld4, c4 = idx - r * ld4;
+                const int t = ts + 4 * c4;
+                const float* row = hb + (long)r * a.h_ld;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (t >= 0 && t + 3 < len) {
+                    v = *reinterpret_cast<const float4*>(row + t);
+                } else {
+                    if (t >= 0 && t < len) v.x = row[t];
+                    if (t + 1 >= 0 && t + 1 < len) v.y = row[t + 1];
+                    if (t + 2 >= 0 && t + 2 < len) v.z = row[t + 2];
+                    if (t + 3 >= 0 && t + 3 < len) v.w = row[t + 3];
+                }
+                *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = v;
+            }
+        } else {
+            for (int idx = tid; idx < H * LDX; idx += 256) {
+                const int r = idx / LDX, c = idx - r * LDX;
+                const int t = ts + c;
+                X[idx] = (t >= 0 && t < len) ? hb[(long)r * a.h_ld + t] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int t = t0 + bcol;
+    {   // ---- in-layer conv: packed tiles 3w .. 3w+2 (tile 2p = rows 32p.. of the tanh half, 2p+1 = same rows, sigmoid half)
+        f32x16 acc[3];
+        const float* wp[3];
+        MI355_UNROLL
+        for (int m = 0; m < 3; ++m) {
+            const int q = 3 * w + m;
+            const int row0 = ((q & 1) ? H : 0) + 32 * (q >> 1);
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int c = row0 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                float v = a.b_in[c];
+                if (a.cond) v += a.cond[(long)b * a.cond_bs + c];
+                acc[m][r] = v;
+            }
+            wp[m] = a.w_in + (long)q * a.K * CP * 64 + lane;
+        }
+        if (!(a.ablate & 1)) wn_mfma<3, CP>(acc, wp, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
+        __syncthreads();  // every wave is done with the h tile
+        MI355_UNROLL
+        for (int m = 0; m < 3; ++m) {
+            const int q = 3 * w + m;
+            const int row0 = ((q & 1) ? H : 0) + 32 * (q >> 1);
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) X[(row0 + (r & 3) + 8 * (r >> 2) + 4 * brow) * 32 + bcol] = acc[m][r];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < H * 32; idx += 256) {  // gate in place: U[c][t] = tanh(A[c][t]) * sigmoid(A[H + c][t])
+        const float at = X[idx], as = X[H * 32 + idx];
+        const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(at, -15.0f), 15.0f));
+        const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
+        const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(as, -30.0f), 30.0f)));
+        X[idx] = th * sg;
+    }
+    __syncthreads();
+    // ---- res/skip 1x1 conv: row tiles q < 6 -> h', q >= 6 -> skip (last layer: 6 tiles, all -> skip)
+    const bool two = a.Crs == 2 * H;
+    const float* U = X + brow * 32 + bcol;
+    const bool live = t < len;
+    auto finish = [&](const f32x16& acc, int q) {
+        if (t >= a.T || ((a.ablate & 4) && acc[0] != 1.2345f)) return;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            if (two && row < H) {
+                const long o = (long)b * a.h_bs + (long)row * a.h_ld + t;
+                a.h_out[o] = live ? a.h_in[o] + acc[r] : 0.0f;
+            } else {
+                float* sp = a.skip + (long)b * a.s_bs + (long)(two ? row - H : row) * a.s_ld + t;
+                *sp = a.skip_init ? acc[r] : *sp + acc[r];
+            }
+        }
+    };
+    if (two) {
+        f32x16 acc[3];
+        const float* wp[3];
+        MI355_UNROLL
+        for (int m = 0; m < 3; ++m) {
+            const int q = 3 * w + m;
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[m][r] = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow];
+            wp[m] = a.w_rs + (long)q * CP * 64 + lane;
+        }
+        if (!(a.ablate & 1)) wn_mfma<3, CP>(acc, wp, U, 32, 1, 0);
+        MI355_UNROLL
+        for (int m = 0; m < 3; ++m) finish(acc[m], 3 * w + m);
+    } else {  // 6 tiles: waves 0, 1 take two, waves 2, 3 one
+        const int nq = w < 2 ? 2 : 1;
+        f32x16 acc[2];
+        const float* wp[2];
+        MI355_UNROLL
+        for (int m = 0; m < 2; ++m) {
+            const int q = m == 0 ? w : w + 4;
+            const int qq = q < 6 ? q : w;
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[m][r] = a.b_rs[32 * qq + (r & 3) + 8 * (r >> 2) + 4 * brow];
+            wp[m] = a.w_rs + (long)qq * CP * 64 + lane;
+        }
+        if (!(a.ablate & 1)) {
+            if (nq == 2) {
+                wn_mfma<2, CP>(acc, wp, U, 32, 1, 0);
+            } else {
+                f32x16 a1[1] = {acc[0]};
+                const float* w1[1] = {wp[0]};
+                wn_mfma<1, CP>(a1, w1, U, 32, 1, 0);
+                acc[0] = a1[0];
+            }
+        }
+        finish(acc[0], w);
+        if (nq == 2) finish(acc[1], w + 4);
+    }
+}
+
 bool wn_layer_fused_supported(int H, int K, int dil) {
-    return (H == 32 || H == 192) && (K % 2) == 1 && K >= 1 && dil >= 1 && (size_t)H * (32 + (K - 1) * dil + 8) * 4 <= 64 * 1024;
+    return (H == 32 || H == 192) && (K % 2) == 1 && K >= 1 && dil >= 1 && (size_t)H * (32 + (K - 1) * dil + 8) * 4 <= 48 * 1024;
 }
 
 void launch_wn_layer(WnArgs a, hipStream_t s) {
@@ -178,7 +364,11 @@ void launch_wn_layer(WnArgs a, hipStream_t s) {
     a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
     const size_t shmem = (size_t)a.H * a.ldx * sizeof(float);  // ldx >= 32: U fits in the h tile
     dim3 grid((a.T + 31) / 32, a.B);
-    if (a.H == 192) {
+    static const bool six_waves = getenv("MI355VITS_WN_SIX_WAVES") != nullptr;  // the older 6 x 2-tile geometry
+    if (a.H == 192 && !six_waves) {
+        const size_t sh4 = (size_t)a.H * (a.ldx > 64 ? a.ldx : 64) * sizeof(float);  // h tile, then [2H][32] raw result
+        LAUNCH_KERNEL(k_wn_layer_h192, grid, dim3(256), sh4, s, a);
+    } else if (a.H == 192) {
         auto k = k_wn_layer<6>;
         LAUNCH_KERNEL(k, grid, dim3(384), shmem, s, a);
     } else {
