@@ -46,11 +46,13 @@ def make_batch(B, Tx, base):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--tx", type=int, default=128)
     ap.add_argument("--frames-per-id", type=int, default=6)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "2")),
+                    help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU-baseline sample")
@@ -79,28 +81,61 @@ def main():
 
     cfg = VitsConfig.apope_low()
     weights = W.synthetic_weights(cfg, seed=1234)
-    eng = Engine(W.pack(cfg, weights), device=local_rank)
+    blob = W.pack(cfg, weights)
+    eng = Engine(blob, device=local_rank)
+    engines = [eng] + [Engine(blob, device=local_rank) for _ in range(max(1, args.streams) - 1)]
 
     B, Tx, fpi = args.batch, args.tx, args.frames_per_id
     ids, lengths = make_batch(B, Tx, rank * B)
     forced = np.full((B, Tx), fpi, np.int32)
     scales = np.array([0.667, 1.0, 0.8], np.float32)
 
-    def step(i):
-        return eng.run(ids, lengths, scales, forced_durations=forced, seed=1, utterance_base=rank * B + i * world * B,
-                       want_float=False, want_pcm16=True, device_only=True)
+    def step(i, e=None):
+        return (e or eng).run(ids, lengths, scales, forced_durations=forced, seed=1,
+                              utterance_base=rank * B + i * world * B, want_float=False, want_pcm16=True, device_only=True)
+
+    def run_steps(n):
+        """n steps; with --streams S > 1, S host threads each drive one engine handle (own HIP stream and workspace)
+        and take step numbers from a shared counter, so the small-kernel front half of one batch overlaps the
+        matrix-core back half of another.  Every step is a complete, independent run()."""
+        if len(engines) == 1:
+            last = None
+            for i in range(n):
+                last = step(i)
+            return last
+        import itertools
+        import threading
+
+        counter = itertools.count()
+        outs = [None] * len(engines)
+        errs = []
+
+        def work(k):
+            try:
+                while True:
+                    i = next(counter)
+                    if i >= n:
+                        return
+                    outs[k] = step(i, engines[k])
+            except Exception as ex:  # noqa: BLE001 - re-raised below
+                errs.append(ex)
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(len(engines))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        if errs:
+            raise errs[0]
+        return next(o for o in outs if o is not None)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(max(args.warmup, len(engines) if args.warmup else 0))
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
+    out = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -128,6 +163,7 @@ def main():
             "workload": f"en_UK/apope_low, {B} utterances/GPU x {Tx} phoneme ids, forced {fpi} frames/id "
                         f"({Tx * fpi} frames = {Tx * fpi * cfg.hop_length} samples each); 8 GPUs = BASELINE batch 256",
             "global_batch": B * world, "phonemes": Tx, "frames": Tx * fpi, "parallelism": f"batch-shard x{world}",
+            "streams_per_gpu": len(engines),
             "scales": [0.667, 1.0, 0.8],
         },
         "rtf": elapsed / args.steps / (samples_per_step / SAMPLE_RATE),

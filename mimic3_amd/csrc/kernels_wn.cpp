@@ -258,6 +258,8 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
     __syncthreads();
 
     const int t = t0 + bcol;
+    const bool two = a.Crs == 2 * H;
+    f32x16 hres[3];
     {   // ---- in-layer conv: packed tiles 3w .. 3w+2 (tile 2p = rows 32p.. of the tanh half, 2p+1 = same rows, sigmoid half)
         f32x16 acc[3];
         const float* wp[3];
@@ -275,6 +277,13 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
             wp[m] = a.w_in + (long)q * a.K * CP * 64 + lane;
         }
         if (!(a.ablate & 1)) wn_mfma<3, CP>(acc, wp, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
+        if (two && w < 2) {  // the residual input of this wave's h' tiles, while the h tile is still there
+            MI355_UNROLL
+            for (int m = 0; m < 3; ++m)
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    hres[m][r] = X[(32 * (3 * w + m) + (r & 3) + 8 * (r >> 2) + 4 * brow) * LDX + toff + pad + bcol];
+        }
         __syncthreads();  // every wave is done with the h tile
         MI355_UNROLL
         for (int m = 0; m < 3; ++m) {
@@ -294,17 +303,15 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
     }
     __syncthreads();
     // ---- res/skip 1x1 conv: row tiles q < 6 -> h', q >= 6 -> skip (last layer: 6 tiles, all -> skip)
-    const bool two = a.Crs == 2 * H;
     const float* U = X + brow * 32 + bcol;
     const bool live = t < len;
-    auto finish = [&](const f32x16& acc, int q) {
+    auto finish = [&](const f32x16& acc, int q, const f32x16& hr) {
         if (t >= a.T || ((a.ablate & 4) && acc[0] != 1.2345f)) return;
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
             if (two && row < H) {
-                const long o = (long)b * a.h_bs + (long)row * a.h_ld + t;
-                a.h_out[o] = live ? a.h_in[o] + acc[r] : 0.0f;
+                a.h_out[(long)b * a.h_bs + (long)row * a.h_ld + t] = live ? hr[r] + acc[r] : 0.0f;
             } else {
                 float* sp = a.skip + (long)b * a.s_bs + (long)(two ? row - H : row) * a.s_ld + t;
                 *sp = a.skip_init ? acc[r] : *sp + acc[r];
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
         }
         if (!(a.ablate & 1)) wn_mfma<3, CP>(acc, wp, U, 32, 1, 0);
         MI355_UNROLL
-        for (int m = 0; m < 3; ++m) finish(acc[m], 3 * w + m);
+        for (int m = 0; m < 3; ++m) finish(acc[m], 3 * w + m, hres[m]);
     } else {  // 6 tiles: waves 0, 1 take two, waves 2, 3 one
         const int nq = w < 2 ? 2 : 1;
         f32x16 acc[2];
@@ -346,8 +353,8 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
                 acc[0] = a1[0];
             }
         }
-        finish(acc[0], w);
-        if (nq == 2) finish(acc[1], w + 4);
+        finish(acc[0], w, hres[0]);
+        if (nq == 2) finish(acc[1], w + 4, hres[0]);
     }
 }
 
