@@ -1,0 +1,8 @@
+"""Empty stand-in for espeak_phonemizer (tests only): imported at module top by mimic3_tts/voice.py, not used by SymbolsVoice."""
+
+
+def _unavailable(*a, **k):
+    raise RuntimeError("espeak_phonemizer is not installed in this environment (tests/refshim stand-in)")
+
+
+sentences = Phonemizer = Epitran = _unavailable
