@@ -55,6 +55,8 @@ def main():
                     help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg (profiling runs: keeps per-kernel "
+                    "averages pure batch-32)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -170,7 +172,7 @@ def main():
         "x_realtime": (samples_per_step / SAMPLE_RATE) / (elapsed / args.steps),
     }
 
-    if rank == 0:
+    if rank == 0 and not args.no_b1:
         # ---- configs[1]: batch 1, golden-utterance shape (991 frames = 253,696 samples = 11.505 s)
         Txg = 180
         ids1 = np.random.default_rng(99).integers(1, 50, (1, Txg)).astype(np.int64)
@@ -237,7 +239,8 @@ def main():
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
-            "traffic": _pmc_traffic(dom["kernel"], B, Tx, fpi),
+            "traffic": (_pmc_traffic(dom["kernel"], B, Tx, fpi) or {}).get("hbm_bytes_per_launch"),
+            "traffic_detail": _pmc_traffic(dom["kernel"], B, Tx, fpi),
             "avg_launch_us": drec["ms"] * 1e3 / drec["calls"],
             "launches": drec["calls"],
             "hbm_algorithmic_gbs": drec["bytes"] / dsec / 1e9,

@@ -118,7 +118,9 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
 // round-robin to the WT time waves.  Barrier placement: conv1 of resblock j+1 only reads the X tile, so it is issued
 // right after conv2 of resblock j and the barrier that releases X1 sits before conv1's *epilogue* — a wave that
 // finishes its conv2 share early flows straight into the next MFMA stream instead of idling at a barrier.
-template <int WM, int WT, int N2, int NT1MAX, int NT2MAX>
+// LDXC / LD1C: row pitches of the two LDS tiles when known at compile time (the "_low" voices' stage shapes): every
+// ds_read of an unrolled k-step group then carries its offset as an immediate; 0 = take them from the arguments.
+template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0>
 __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 8, "8 waves per workgroup");
     static_assert(NT1MAX == 3 && NT2MAX == 2, "static dispatch below");
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     constexpr int T_B = 32 * N2;
     constexpr int CP = C / 2;
     DYN_SMEM(float, smem);
-    const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
+    const int LDX = LDXC ? LDXC : a.ldx, LD1 = LD1C ? LD1C : a.ld1, R = a.R;
     float* X = smem;               // [C][LDX]  lrelu(x), zero outside the row
     float* X1 = smem + C * LDX;    // [C][LD1]  lrelu(x1) of the current resblock, zero outside the row
     float* BS = X1 + C * LD1;      // [nrb][2][C] biases
@@ -262,20 +264,18 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     }
     const size_t shmem = ((size_t)a.C * (a.ldx + a.ld1) + (size_t)a.nrb * 2 * a.C) * sizeof(float);
     dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
+    auto go = [&](auto kfn) {
+#ifndef MI355_EMU
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+        (void)once;
+#endif
+        LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
+    };
     if (a.C == 32) {
-        auto kfn = k_mrf_fused<1, 8, 16, 3, 2>;
-#ifndef MI355_EMU
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-        (void)once;
-#endif
-        LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
+        go(k_mrf_fused<1, 8, 16, 3, 2>);  // immediates cost this variant registers (spills): pitches stay run-time
     } else {
-        auto kfn = k_mrf_fused<2, 4, 6, 3, 2>;
-#ifndef MI355_EMU
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-        (void)once;
-#endif
-        LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
+        if (a.ldx == 320 && a.ld1 == 288) go(k_mrf_fused<2, 4, 6, 3, 2, 320, 288>);
+        else go(k_mrf_fused<2, 4, 6, 3, 2>);
     }
 }
 

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 output directory (rocpd sqlite) into the text summaries committed under profiles/.
+
+    python tools/rocprof_summary.py stats  gpurun_out/prof_stats            # --kernel-trace --stats run
+    python tools/rocprof_summary.py pmc    gpurun_out/prof_pmc1 [more dirs] # --pmc runs (one counter set per dir)
+
+`pmc` prints, per kernel name and counter, the per-launch mean of the counter summed over its instances (XCDs /
+channels); HBM bytes follow MI355X_MICROARCH.md: bytes = 2 x FETCH_SIZE(KB) x 1024 / 2 ... see DESIGN.md §6 for
+the gfx950 correction actually applied (FETCH_SIZE counts 64 B per 128 B request -> reads = 2 x FETCH_SIZE KiB).
+"""
+import glob
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def _db(d):
+    dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
+    if not dbs:
+        raise SystemExit(f"no rocpd .db under {d}")
+    return sqlite3.connect(dbs[0])
+
+
+def stats(d, limit=40):
+    c = _db(d)
+    print(f"{'kernel':100s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
+    for name, calls, total, avg, pct in c.execute(
+            "select name, total_calls, total_duration, average, percentage from top_kernels limit ?", (limit,)):
+        print(f"{name[:100]:100s} {calls:7d} {total:12.1f} {avg:10.2f} {pct:6.2f}")
+
+
+def pmc(dirs, min_us=20.0):
+    rows = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [per-dispatch sum]
+    dur = defaultdict(list)
+    for d in dirs:
+        c = _db(d)
+        per = defaultdict(float)
+        meta = {}
+        for disp, kname, cname, val, dd in c.execute(
+                "select dispatch_id, kernel_name, counter_name, value, duration from counters_collection"):
+            per[(disp, cname)] += val
+            meta[disp] = (kname, dd)
+        seen = set()
+        for (disp, cname), v in per.items():
+            kname, dd = meta[disp]
+            rows[kname][cname].append(v)
+            if (d, disp) not in seen:
+                seen.add((d, disp))
+                dur[kname].append(dd / 1e3)
+    print(f"{'kernel':80s} {'launches':>8s} {'avg_us':>10s}  counters (per-launch mean)")
+    for kname in sorted(rows, key=lambda k: -sum(dur[k])):
+        avg = sum(dur[kname]) / max(1, len(dur[kname]))
+        if avg < min_us:
+            continue
+        cs = "  ".join(f"{cn}={sum(v) / len(v):.4g}" for cn, v in sorted(rows[kname].items()))
+        print(f"{kname[:80]:80s} {len(dur[kname]):8d} {avg:10.1f}  {cs}")
+
+
+# bench.py profiler label -> (kernel name as rocprofv3 prints it, algorithmic bytes per launch for B x Tx x fpi)
+def _labels(B, Tx, fpi):
+    Ty = Tx * fpi
+    return {
+        "dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2>", 2 * 4 * B * 64 * Ty * 64),      # read x + write y, [64, 64 Ty]
+        "dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2>", 2 * 4 * B * 32 * Ty * 256),    # [32, 256 Ty]
+        "flow.wn_layer": ("k_wn_layer_h192", 4 * 4 * B * 192 * Ty + 4 * (384 * 192 * 5 + 384 * 192)),  # h r+w, skip r+w, weights
+    }
+
+
+def traffic(dirs, out_path, B=32, Tx=128, fpi=6):
+    """profiles/pmc_traffic.json: HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB; on gfx950
+    FETCH_SIZE tallies 64 B per 128-B read request, MI355X_MICROARCH.md "HBM")."""
+    import json
+
+    sums = defaultdict(lambda: defaultdict(list))
+    for d in dirs:
+        c = _db(d)
+        per = defaultdict(float)
+        names = {}
+        for disp, kname, cname, val in c.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection "
+                                                 "where counter_name in ('FETCH_SIZE', 'WRITE_SIZE')"):
+            per[(disp, cname)] += val
+            names[disp] = kname
+        for (disp, cname), v in per.items():
+            sums[names[disp]][cname].append(v)
+    out = {}
+    for label, (needle, algo) in _labels(B, Tx, fpi).items():
+        for kname, cs in sums.items():
+            if needle in kname and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
+                w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+                out[label] = {"workload": [B, Tx, fpi], "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+                              "algorithmic_bytes_per_launch": int(algo), "fetch_size_kib": f, "write_size_kib": w,
+                              "launches": len(cs["FETCH_SIZE"]),
+                              "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of {needle}: "
+                                        f"2 x FETCH_SIZE + WRITE_SIZE, per launch (gfx950 FETCH_SIZE counts 64 B per 128 B request)"}
+    with open(out_path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 3 or sys.argv[1] not in ("stats", "pmc", "traffic"):
+        raise SystemExit(__doc__)
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[3:], sys.argv[2])
+    else:
+        pmc(sys.argv[2:])
