@@ -38,6 +38,8 @@ struct ConvArgs {
     int shuf_s = 0, shuf_p = 0, shuf_cout = 0, shuf_T = 0;
     int vec = 0;   // set by the launcher: input rows are 16-byte aligned -> 16-byte staging loads
     int yvec = 0;  // set by the launcher: output rows are 16-byte aligned -> vector stores (polyphase epilogue)
+    int ovec = 0;  // set by the launcher: row-major epilogue through LDS (16-byte loads / stores of y, res)
+    int ablate = 0;  // timing experiments only (MI355VITS_CONV_ABLATE): 1 no MFMA loop, 2 no staging, 4 no epilogue
 };
 
 // Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).

@@ -43,6 +43,34 @@ __device__ __forceinline__ void epi_std(const ConvArgs& a, int b, int co, int t,
     *yp = v;
 }
 
+// epi_std on four consecutive time samples t .. t+3 (all < T, rows 16-byte aligned): 16-byte loads / stores
+__device__ __forceinline__ void epi_std4(const ConvArgs& a, int b, int co, int t, float4 v, int out_len) {
+    float x[4] = {v.x, v.y, v.z, v.w};
+    const float bias = (a.bias ? a.bias[co] : 0.0f) + (a.cond ? a.cond[(long)b * a.cond_bs + co] : 0.0f);
+    float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.res) r4 = *reinterpret_cast<const float4*>(a.res + (long)b * a.res_bs + (long)co * a.res_ld + t);
+    const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+    float* yp = a.y + (long)b * a.y_bs + (long)co * a.y_ld + t;
+    float4 y4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.accumulate) y4 = *reinterpret_cast<const float4*>(yp);
+    const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+    MI355_UNROLL
+    for (int m = 0; m < 4; ++m) {
+        float q = x[m];
+        if (a.bias) q += a.bias[co];  // same order of additions as epi_std: bias, then cond
+        if (a.cond) q += a.cond[(long)b * a.cond_bs + co];
+        if (a.relu) q = fmaxf(q, 0.0f);
+        if (a.mask_before_res && t + m >= out_len) q = 0.0f;
+        if (a.res) q = a.res_sub ? rr[m] - q : rr[m] + q;
+        q *= a.out_scale;
+        if (!a.mask_before_res && t + m >= out_len) q = 0.0f;
+        if (a.accumulate) q += yy[m];
+        x[m] = q;
+    }
+    (void)bias;
+    *reinterpret_cast<float4*>(yp) = make_float4(x[0], x[1], x[2], x[3]);
+}
+
 // WaveNet gate (A.9): u = tanh(a[:H] + cond) * sigmoid(a[H:] + cond)
 __device__ __forceinline__ void epi_gate(const ConvArgs& a, int b, int c, int t, float v0, float v1) {
     if (a.bias) { v0 += a.bias[c]; v1 += a.bias[c + a.H]; }
@@ -319,7 +347,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
 }
 
 template <int MT, int NT, int WM, int WN, int EPI, int RING>
-__global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
     DYN_SMEM(float, xs);  // [CI_C][LD]
@@ -352,9 +380,9 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     const int brow = lane >> 5, bcol = lane & 31;
     for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
         // ---- stage x[c0:c0+CI_C, ts : ts+LD) with mask + leaky-relu fused
-        stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
+        if (!(a.ablate & 2)) stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
         __syncthreads();
-        {
+        if (!(a.ablate & 1)) {
             const float* wp[MT];
             MI355_UNROLL
             for (int i = 0; i < MT; ++i) {
@@ -368,6 +396,72 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(ConvArgs a, int CI_C) {
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if ((a.ablate & 4) && acc[0][0][0] != 1.2345f) return;
+    if (EPI == EPI_STD && a.ovec) {
+        // Through LDS (free after the last chunk) so that global memory sees whole rows: the C/D fragment gives a lane
+        // one column of 16 rows, i.e. 128-byte pieces per store instruction; re-read row-major, every lane moves 16
+        // bytes and a wave 1 KiB of one row (residual / accumulate reads likewise).  One pass per MT index: the block's
+        // WM x 32 rows of that index.  Polyphase ConvTranspose1d (rows = channel-major / phase-minor): the LDS row of a
+        // channel is its T_B * s consecutive output samples.
+        constexpr int ROWS = 32 * WM;
+        const int s_ = a.shuf_s ? a.shuf_s : 1;
+        const int rows_o = ROWS / s_;          // output rows (channels) per pass
+        const int cols_o = T_B * s_;           // output samples per row
+        const int LDO = cols_o + 4;
+        const long n_lo = (long)t0 * s_ - a.shuf_p;                              // global sample of LDS column 0
+        long n_end = (long)(t0 + T_B < a.T ? t0 + T_B : a.T) * s_ - a.shuf_p;    // exclusive
+        const long n_max = a.shuf_s ? a.shuf_T : a.T;
+        if (n_end > n_max) n_end = n_max;
+        const long n4_lo = n_lo >= 0 ? (n_lo & ~3L) : 0;
+        const int quads = (int)((n_end - n4_lo + 3) / 4);
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i) {
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) {
+                const int tcol = (wn * NT + j) * 32 + bcol;
+                MI355_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const int row = wm * 32 + 8 * g + 4 * brow;  // + m, m = 0..3
+                    if (a.shuf_s) {
+                        const int cop = 32 * (tile0 + i) + 8 * g + 4 * brow;
+                        float4 v;
+                        v.x = acc[i][j][4 * g + 0] + ((a.bias && cop + 0 < a.Cout) ? a.bias[cop + 0] : 0.0f);
+                        v.y = acc[i][j][4 * g + 1] + ((a.bias && cop + 1 < a.Cout) ? a.bias[cop + 1] : 0.0f);
+                        v.z = acc[i][j][4 * g + 2] + ((a.bias && cop + 2 < a.Cout) ? a.bias[cop + 2] : 0.0f);
+                        v.w = acc[i][j][4 * g + 3] + ((a.bias && cop + 3 < a.Cout) ? a.bias[cop + 3] : 0.0f);
+                        *reinterpret_cast<float4*>(xs + (row / s_) * LDO + tcol * s_ + (row % s_)) = v;
+                    } else {
+                        MI355_UNROLL
+                        for (int m = 0; m < 4; ++m) xs[(row + m) * LDO + tcol] = acc[i][j][4 * g + m];
+                    }
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < rows_o * quads; idx += 256) {
+                const int rr = idx / quads, q = idx - rr * quads;
+                const int wmr = (rr * s_) / 32;                                    // which wave row this came from
+                const int cop = 32 * ((blockIdx.y * WM + wmr) * MT + i) + (rr * s_) % 32;
+                if (cop >= a.Cout) continue;
+                const long n = n4_lo + 4L * q;
+                const float* src = xs + rr * LDO + (n - n_lo);
+                if (n >= n_lo && n + 3 < n_end) {
+                    float4 v;
+                    if (((n - n_lo) & 3) == 0) v = *reinterpret_cast<const float4*>(src);
+                    else v = make_float4(src[0], src[1], src[2], src[3]);
+                    if (a.shuf_s) *reinterpret_cast<float4*>(a.y + (long)b * a.y_bs + (long)(cop / s_) * a.y_ld + n) = v;
+                    else epi_std4(a, b, cop, (int)n, v, out_len);
+                } else {
+                    for (int m = 0; m < 4; ++m) {
+                        if (n + m < n_lo || n + m < 0 || n + m >= n_end) continue;
+                        if (a.shuf_s) a.y[(long)b * a.y_bs + (long)(cop / s_) * a.y_ld + n + m] = src[m];
+                        else epi_std(a, b, cop, (int)(n + m), src[m], out_len);
+                    }
+                }
+            }
+            if (i + 1 < MT) __syncthreads();
+        }
+        return;
+    }
     if (EPI == EPI_STD && a.shuf_s && (a.shuf_s & 3) == 0) {
         // polyphase ConvTranspose1d, output channels ordered co' = c*s + r: the 4 consecutive rows a lane holds per
         // register group are 4 consecutive phases of one channel = 4 consecutive output samples -> 16-byte stores
@@ -609,11 +703,25 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     for (int c = chunk_max; c >= 2; c -= 2)
         if (a.Cin % c == 0 && fits(c)) { ci_c = c; break; }
     if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
-    const size_t shmem = (size_t)ci_c * LD * sizeof(float);
+    size_t shmem = (size_t)ci_c * LD * sizeof(float);
     dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
     ConvArgs av = a;
     av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
+    // row-major epilogue through LDS (EPI_STD): needs 16-byte aligned output / residual rows; for the polyphase
+    // scatter also a phase count that divides the 32-row tile and keeps a lane's 4 rows inside one channel
+    static const bool no_ovec = getenv("MI355VITS_CONV_NO_OVEC") != nullptr;
+    // the polyphase scatter straight from registers already writes 1 KiB contiguous per store instruction (a lane owns
+    // 4 consecutive samples); routing it through LDS measured slower (upsample 1.91 -> 2.34 ms/step), so it is opt-in
+    static const bool polyphase_via_lds = getenv("MI355VITS_CONV_POLY_LDS") != nullptr;
+    av.ovec = EPI == EPI_STD && !no_ovec && av.yvec &&
+              (!a.res || ((a.res_ld % 4 == 0) && (a.res_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.res) % 16 == 0))) &&
+              (!a.shuf_s || (polyphase_via_lds && 32 % a.shuf_s == 0 && a.shuf_s % 4 == 0 && a.Cout % 4 == 0));
+    if (av.ovec) {
+        const size_t s_ = a.shuf_s ? a.shuf_s : 1;
+        const size_t need = (32 * WM / s_) * (T_B * s_ + 4) * sizeof(float);
+        if (need > shmem) shmem = need;
+    }
     if (ci_c == 64) {
         auto kfn = k_conv1d_mfma<MT, NT, WM, WN, EPI, 32>;
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av, ci_c);
@@ -636,8 +744,11 @@ void launch_direct(const ConvArgs& a, int n_tiles, hipStream_t s) {
 
 }  // namespace
 
-void launch_conv1d_mfma(const ConvArgs& a, hipStream_t s) {
-    if (a.T <= 0 || a.B <= 0) return;
+void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
+    if (a_in.T <= 0 || a_in.B <= 0) return;
+    static const int ablate = getenv("MI355VITS_CONV_ABLATE") ? atoi(getenv("MI355VITS_CONV_ABLATE")) : 0;
+    ConvArgs a = a_in;
+    a.ablate = ablate;
     if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
     const int n_tiles = n_tiles_for(a.epi, a.Cout, a.H);
     // Tile choice.  Every CU works through ceil(blocks / 256) workgroups' worth of MFMA time, so a grid of 576
