@@ -697,7 +697,8 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     // C_in chunk: fixed by C_in alone (largest even divisor <= 64) so that the summation order — and with it
     // every output bit — does not depend on the tile shape chosen for a batch size; only a receptive field too
     // large for LDS shrinks it further.
-    auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= 60 * 1024; };
+    static const size_t lds_cap = [] { const char* e = getenv("MI355VITS_CONV_LDS_KB"); return (size_t)(e ? atoi(e) : 60) * 1024; }();
+    auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= lds_cap; };
     int ci_c = 0;
     static const int chunk_max = [] { const char* e = getenv("MI355VITS_CONV_CHUNK"); return e ? atoi(e) : 64; }();
     for (int c = chunk_max; c >= 2; c -= 2)
