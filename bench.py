@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--tx", type=int, default=128)
     ap.add_argument("--frames-per-id", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "3")),
                     help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

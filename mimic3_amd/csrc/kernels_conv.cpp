@@ -997,9 +997,92 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const float* x, long x_b
     }
 }
 
+// Row-aligned variant without LDS: a lane owns 8 consecutive samples and reads x[c, t-4 .. t+11] as four 16-byte
+// loads per channel (the overlap with its neighbours is served by L1), several channels in flight.  Same (channel,
+// tap) summation order as the staged kernel above, so both give identical bits.
+constexpr int CPV_T = 2048;  // samples per workgroup (8 per thread)
+
+__global__ __launch_bounds__(256) void k_conv_post_tanh_vec(const float* __restrict__ x, long x_bs, int x_ld,
+                                                            const float* __restrict__ w, int Cin, int K, int L,
+                                                            const int* valid_len, float* __restrict__ audio, long audio_bs,
+                                                            unsigned* peak_bits) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * CPV_T + 8 * tid;
+    const int pad = (K - 1) / 2;  // <= 4
+    int vl = valid_len ? valid_len[b] : L;
+    if (vl > L) vl = L;
+    float acc[8];
+    MI355_UNROLL
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
+    const float* xb = x + (long)b * x_bs;
+    if (t < L) {
+        const bool inner = t - 4 >= 0 && t + 11 < vl;
+#pragma unroll 4
+        for (int c = 0; c < Cin; ++c) {
+            const float* row = xb + (long)c * x_ld;
+            float xv[16];
+            if (inner) {
+                MI355_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = *reinterpret_cast<const float4*>(row + t - 4 + 4 * g);
+                    xv[4 * g + 0] = v.x; xv[4 * g + 1] = v.y; xv[4 * g + 2] = v.z; xv[4 * g + 3] = v.w;
+                }
+            } else {
+                MI355_UNROLL
+                for (int i = 0; i < 16; ++i) {
+                    const int tt = t - 4 + i;
+                    xv[i] = (tt >= 0 && tt < vl) ? row[tt] : 0.0f;
+                }
+            }
+            MI355_UNROLL
+            for (int i = 0; i < 16; ++i) xv[i] = xv[i] >= 0.0f ? xv[i] : xv[i] * 0.01f;
+            for (int k = 0; k < K; ++k) {
+                const float wv = w[c * K + k];
+                MI355_UNROLL
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(wv, xv[q + k + 4 - pad], acc[q]);
+            }
+        }
+    }
+    float pk = 0.0f;
+    if (t < L) {
+        float y[8];
+        MI355_UNROLL
+        for (int q = 0; q < 8; ++q) {
+            y[q] = tanhf(acc[q]);
+            if (t + q < vl) pk = fmaxf(pk, fabsf(y[q]));
+        }
+        float* ap = audio + (long)b * audio_bs + t;
+        if (t + 7 < L) {
+            *reinterpret_cast<float4*>(ap) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(ap + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        } else {
+            for (int q = 0; q < 8; ++q)
+                if (t + q < L) ap[q] = y[q];
+        }
+    }
+    pk = wave_reduce_max(pk);
+    if (lane == 0) red[wid] = pk;
+    __syncthreads();
+    if (tid == 0) {
+        pk = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(peak_bits + b, __float_as_uint(pk));
+    }
+}
+
 void launch_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, int Cin, int K, int B, int L,
                            const int* valid_len, float* audio, long audio_bs, unsigned* peak_bits, hipStream_t s) {
     if (L <= 0 || B <= 0) return;
+    static const bool no_vec = getenv("MI355VITS_CONV_POST_STAGED") != nullptr;
+    const bool aligned = (x_ld % 4 == 0) && (x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                         (audio_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(audio) % 16 == 0);
+    if (aligned && K <= 9 && (K & 1) && !no_vec) {
+        dim3 grid((L + CPV_T - 1) / CPV_T, B);
+        LAUNCH_KERNEL(k_conv_post_tanh_vec, grid, dim3(256), 0, s, x, x_bs, x_ld, w, Cin, K, L, valid_len, audio, audio_bs,
+                      peak_bits);
+        return;
+    }
     const size_t shmem = sizeof(float) * ((size_t)8 * (CP_T + K - 1) + (size_t)Cin * K + 4);
     dim3 grid((L + CP_T - 1) / CP_T, B);
     LAUNCH_KERNEL(k_conv_post_tanh, grid, dim3(256), shmem, s, x, x_bs, x_ld, w, Cin, K, L, valid_len, audio, audio_bs,
