@@ -793,7 +793,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             u.pad = up.K - 1; u.Tin = (int)T;
             u.shuf_s = r; u.shuf_p = (k - r) / 2; u.shuf_cout = ch / 2; u.shuf_T = (int)(T * r);
             u.B = B; u.T = (int)T + up.K - 1;
-            conv("dec.upsample", up, u);
+            conv(i == 0 ? "dec.upsample.s0" : (i == 1 ? "dec.upsample.s1" : "dec.upsample.s2+"), up, u);
         } else {
             ConvTArgs u;
             u.x = d_bufC_; u.x_bs = (long)ch * T; u.x_ld = (int)T;

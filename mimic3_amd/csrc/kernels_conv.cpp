@@ -97,6 +97,43 @@ __device__ __forceinline__ void epi_resskip(const ConvArgs& a, int b, int co, in
     }
 }
 
+// Polyphase ConvTranspose1d scatter straight from the accumulators.  Output channels are ordered co' = c*s + r
+// (channel-major / phase-minor), so the 4 consecutive rows a lane holds per register group are 4 consecutive phases of
+// one channel = 4 consecutive output samples: a 16-byte store per lane, 1 KiB contiguous per store instruction.
+template <int MT, int NT>
+__device__ __forceinline__ void epi_polyphase_regs(const ConvArgs& a, const f32x16 (&acc)[MT][NT], int b, int tcol0, int tile0,
+                                                   int brow) {
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j) {
+        const int t = tcol0 + j * 32;
+        if (t >= a.T) continue;
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i) {
+            MI355_UNROLL
+            for (int g = 0; g < 4; ++g) {
+                const int cop = 32 * (tile0 + i) + 8 * g + 4 * brow;  // multiple of 4
+                if (cop >= a.Cout) continue;
+                const int c = cop / a.shuf_s, r0 = cop - c * a.shuf_s;
+                const int n0 = t * a.shuf_s + r0 - a.shuf_p;
+                float v[4];
+                MI355_UNROLL
+                for (int m = 0; m < 4; ++m) v[m] = acc[i][j][4 * g + m] + (a.bias ? a.bias[cop + m] : 0.0f);
+                float* yp = a.y + (long)b * a.y_bs + (long)c * a.y_ld + n0;
+                if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 3) == 0 && a.yvec) {
+                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 1) == 0 && a.yvec) {
+                    *reinterpret_cast<float2*>(yp) = make_float2(v[0], v[1]);
+                    *reinterpret_cast<float2*>(yp + 2) = make_float2(v[2], v[3]);
+                } else {
+                    MI355_UNROLL
+                    for (int m = 0; m < 4; ++m)
+                        if (n0 + m >= 0 && n0 + m < a.shuf_T) yp[m] = v[m];
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic VALU kernel
 // ------------------------------------------------------------------------------------------------
@@ -463,37 +500,7 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void 
         return;
     }
     if (EPI == EPI_STD && a.shuf_s && (a.shuf_s & 3) == 0) {
-        // polyphase ConvTranspose1d, output channels ordered co' = c*s + r: the 4 consecutive rows a lane holds per
-        // register group are 4 consecutive phases of one channel = 4 consecutive output samples -> 16-byte stores
-        MI355_UNROLL
-        for (int j = 0; j < NT; ++j) {
-            const int t = t0 + (wn * NT + j) * 32 + bcol;
-            if (t >= a.T) continue;
-            MI355_UNROLL
-            for (int i = 0; i < MT; ++i) {
-                MI355_UNROLL
-                for (int g = 0; g < 4; ++g) {
-                    const int cop = 32 * (tile0 + i) + 8 * g + 4 * brow;  // multiple of 4
-                    if (cop >= a.Cout) continue;
-                    const int c = cop / a.shuf_s, r0 = cop - c * a.shuf_s;
-                    const int n0 = t * a.shuf_s + r0 - a.shuf_p;
-                    float v[4];
-                    MI355_UNROLL
-                    for (int m = 0; m < 4; ++m) v[m] = acc[i][j][4 * g + m] + (a.bias ? a.bias[cop + m] : 0.0f);
-                    float* yp = a.y + (long)b * a.y_bs + (long)c * a.y_ld + n0;
-                    if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 3) == 0 && a.yvec) {
-                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 1) == 0 && a.yvec) {
-                        *reinterpret_cast<float2*>(yp) = make_float2(v[0], v[1]);
-                        *reinterpret_cast<float2*>(yp + 2) = make_float2(v[2], v[3]);
-                    } else {
-                        MI355_UNROLL
-                        for (int m = 0; m < 4; ++m)
-                            if (n0 + m >= 0 && n0 + m < a.shuf_T) yp[m] = v[m];
-                    }
-                }
-            }
-        }
+        epi_polyphase_regs<MT, NT>(a, acc, b, t0 + wn * NT * 32 + bcol, tile0, brow);
         return;
     }
     MI355_UNROLL
@@ -597,6 +604,10 @@ __global__ __launch_bounds__(256) void k_conv_direct_mfma(ConvArgs a) {
         }
     }
 
+    if (EPI == EPI_STD && a.shuf_s && (a.shuf_s & 3) == 0) {
+        epi_polyphase_regs<MT, NT>(a, acc, b, t0 + wn * NT * 32 + bcol, tile0, brow);
+        return;
+    }
     MI355_UNROLL
     for (int j = 0; j < NT; ++j) {
         const int t = t0 + (wn * NT + j) * 32 + bcol;
@@ -740,7 +751,9 @@ void launch_direct(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
     dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
     auto kfn = k_conv_direct_mfma<MT, NT, WM, WN, EPI>;
-    LAUNCH_KERNEL(kfn, grid, dim3(256), 0, s, a);
+    ConvArgs av = a;
+    av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
+    LAUNCH_KERNEL(kfn, grid, dim3(256), 0, s, av);
 }
 
 }  // namespace
@@ -782,8 +795,10 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     };
     // LDS-free streaming kernel: pointwise convs, and short sequences (encoder FFN) where the grid is too small to
     // hide the stage/barrier cycle of the staged kernel
-    const bool direct = a.epi != EPI_GATE && !a.shuf_s && ((a.K * (a.Cin >> 1)) % 8) == 0 &&
-                        (a.K == 1 || (a.K <= 3 && a.T <= 512));
+    static const int poly_direct_cin = getenv("MI355VITS_POLY_DIRECT_CIN") ? atoi(getenv("MI355VITS_POLY_DIRECT_CIN")) : 64;
+    const bool direct = a.epi != EPI_GATE && ((a.K * (a.Cin >> 1)) % 8) == 0 &&
+                        (a.shuf_s ? (a.K <= 2 && a.Cin <= poly_direct_cin && (a.shuf_s & 3) == 0)
+                                  : (a.K == 1 || (a.K <= 3 && a.T <= 512)));
     // deep + short (encoder FFN conv_2): split the k-steps over the four waves of a workgroup.  The rule looks at the
     // layer shape only, never at the batch size, so a row's bits do not depend on what it is batched with.
     if (direct && a.epi == EPI_STD && a.T <= 512 && a.K * (a.Cin >> 1) >= 512 && ((a.K * (a.Cin >> 1)) % 32) == 0) {

@@ -155,3 +155,13 @@ def test_sequence_length_extremes(gpu_lib, Tx):
 
 def test_length_scale_and_rate(gpu_lib):
     check_parity(gpu_lib, VitsConfig.tiny_wide(), B=2, Tx=12, seed=61, scales=(0.0, 1.37, 0.0))
+
+
+def test_long_form_full_size_utterance(gpu_lib):
+    """600 phoneme ids at the real voice shapes (more than the 512-key register budget of the MFMA attention, so the
+    fallback attention runs at head dimension 96) -> 1800 frames = 20.9 s of audio through every fused kernel."""
+    cfg = VitsConfig.apope_low()
+    Tx = 600
+    forced = np.full((1, Tx), 3, np.int32)
+    out, ora = check_parity(gpu_lib, cfg, B=1, Tx=Tx, seed=77, forced=forced, taps=False, ragged=False)
+    assert int(out["lengths"][0]) == Tx * 3 * 256

@@ -70,3 +70,30 @@ def test_session_loads_generator_onnx_with_folded_weight_norm(tmp_path):
     r = VitsOracle(cfg, w).infer(ids, feed["input_lengths"], feed["scales"])["audio"][0, 0]
     assert audio.shape == r.shape
     assert np.sqrt(np.mean((audio - r) ** 2)) / np.sqrt(np.mean(r ** 2)) < 1e-4
+
+
+def test_lanes_overlap_concurrent_calls_on_the_device():
+    """Three engine handles (HIP streams) behind one session, six threads: same bits as one lane."""
+    import threading
+
+    cfg = VitsConfig.tiny_wide()
+    blob = W.pack(cfg, W.synthetic_weights(cfg, seed=12))
+    so1, so3 = SessionOptions(), SessionOptions()
+    so1.seed = so3.seed = 5
+    so3.lanes = 3
+    one, three = InferenceSession(blob, sess_options=so1), InferenceSession(blob, sess_options=so3)
+    rng = np.random.default_rng(4)
+    feeds = [{"input": rng.integers(1, 20, (3, 40)).astype(np.int64), "input_lengths": np.array([40, 17, 29], np.int64),
+              "scales": np.array([0.0, 1.0, 0.0], np.float32)} for _ in range(6)]
+    expect = [one.run(None, f)[0] for f in feeds]
+    got = [None] * 6
+
+    def work(i):
+        for _ in range(4):
+            got[i] = three.run(None, feeds[i])[0]
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for e, g in zip(expect, got):
+        assert np.array_equal(e, g)
