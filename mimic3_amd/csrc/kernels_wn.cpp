@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            acc0[r] = two ? a.b_rs[c] + hres[r] : a.b_rs[c];
+            acc0[r] = a.b_rs[c];
             acc1[r] = two ? a.b_rs[H + c] : 0.0f;
         }
         const float* wp0 = a.w_rs + (long)p * CP * 64 + lane;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_
                 const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
                 float* sp = a.skip + (long)b * a.s_bs + (long)c * a.s_ld + t;
                 if (two) {
-                    a.h_out[(long)b * a.h_bs + (long)c * a.h_ld + t] = live ? acc0[r] : 0.0f;
+                    a.h_out[(long)b * a.h_bs + (long)c * a.h_ld + t] = live ? hres[r] + acc0[r] : 0.0f;  // same order as k_wn_layer_h192
                     *sp = a.skip_init ? acc1[r] : *sp + acc1[r];
                 } else {
                     *sp = a.skip_init ? acc0[r] : *sp + acc0[r];
@@ -371,7 +371,12 @@ void launch_wn_layer(WnArgs a, hipStream_t s) {
     a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
     const size_t shmem = (size_t)a.H * a.ldx * sizeof(float);  // ldx >= 32: U fits in the h tile
     dim3 grid((a.T + 31) / 32, a.B);
-    static const bool six_waves = getenv("MI355VITS_WN_SIX_WAVES") != nullptr;  // the older 6 x 2-tile geometry
+    // Two geometries with identical arithmetic (same bits): 4 waves x 3 tiles keeps the SIMDs evenly loaded when the grid
+    // fills the chip; 6 waves x 2 tiles has the shorter dependent MFMA chain per wave, which is what matters when only a
+    // few dozen workgroups exist (one utterance: 31 workgroups per layer).
+    const char* six_s = getenv("MI355VITS_WN_SIX_WAVES");  // read per launch: tests flip it inside one process
+    const int six_env = six_s ? atoi(six_s) : -1;
+    const bool six_waves = six_env >= 0 ? six_env != 0 : (long)grid.x * grid.y < 512;
     if (a.H == 192 && !six_waves) {
         const size_t sh4 = (size_t)a.H * (a.ldx > 64 ? a.ldx : 64) * sizeof(float);  // h tile, then [2H][32] raw result
         LAUNCH_KERNEL(k_wn_layer_h192, grid, dim3(256), sh4, s, a);

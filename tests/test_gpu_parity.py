@@ -165,3 +165,22 @@ def test_long_form_full_size_utterance(gpu_lib):
     forced = np.full((1, Tx), 3, np.int32)
     out, ora = check_parity(gpu_lib, cfg, B=1, Tx=Tx, seed=77, forced=forced, taps=False, ragged=False)
     assert int(out["lengths"][0]) == Tx * 3 * 256
+
+
+def test_wavenet_layer_geometries_give_identical_bits(gpu_lib):
+    """The fused WaveNet-layer kernel picks 6 waves x 2 tiles for small grids (one utterance) and 4 waves x 3 tiles for
+    grids that fill the chip; a row's bits must not depend on which one ran."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    eng = Engine(W.pack(cfg, w))
+    ids = np.random.default_rng(3).integers(1, 50, (2, 48)).astype(np.int64)
+    forced = np.full((2, 48), 4, np.int32)
+    outs = {}
+    for six in ("0", "1"):
+        os.environ["MI355VITS_WN_SIX_WAVES"] = six
+        try:
+            outs[six] = eng.run(ids, [48, 31], [0.667, 1.0, 0.8], forced_durations=forced, seed=9)["audio"]
+        finally:
+            del os.environ["MI355VITS_WN_SIX_WAVES"]
+    assert np.array_equal(outs["0"], outs["1"])
+    eng.close()
