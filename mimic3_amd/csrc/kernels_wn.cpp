@@ -213,8 +213,10 @@ __device__ __forceinline__ void wn_mfma(f32x16 (&acc)[MT], const float* const (&
 // tiles leave the SIMDs 5/5/4/4), and fewer, fatter waves run the operand streams closer to the matrix-core rate
 // (tools/mfma_ceiling.hip).  The price: tanh and sigmoid rows of a gate pair now sit in different waves, so the raw
 // in-layer result takes a round trip through LDS (it reuses the h tile's space) before gating.
-__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnArgs a) {
-    constexpr int H = 192, CP = 96, NTILE = 12;
+template <int NW>  // waves per workgroup: 4 (3 tiles each) or 12 (1 tile each: shortest MFMA chain, for tiny grids)
+__global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnArgs a) {
+    constexpr int H = 192, CP = 96, NTILE = 12, MT = NTILE / NW, NTH = 64 * NW;
+    static_assert(NW == 4 || NW == 12, "wave count");
     DYN_SMEM(float, smem);
     const int LDX = a.ldx;
     float* X = smem;  // [H][LDX] h tile (+halo), zero outside the row; later A [2H][32] raw in-layer result, U = A[:H]
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
     if (!(a.ablate & 2)) {
         if (a.vec) {
             const int ld4 = LDX >> 2;
-            for (int idx = tid; idx < H * ld4; idx += 256) {
+            for (int idx = tid; idx < H * ld4; idx += NTH) {
                 const int r = idx / ld4, c4 = idx - r * ld4;
                 const int t = ts + 4 * c4;
                 const float* row = hb + (long)r * a.h_ld;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
                 *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = v;
             }
         } else {
-            for (int idx = tid; idx < H * LDX; idx += 256) {
+            for (int idx = tid; idx < H * LDX; idx += NTH) {
                 const int r = idx / LDX, c = idx - r * LDX;
                 const int t = ts + c;
                 X[idx] = (t >= 0 && t < len) ? hb[(long)r * a.h_ld + t] : 0.0f;
@@ -259,13 +261,13 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
 
     const int t = t0 + bcol;
     const bool two = a.Crs == 2 * H;
-    f32x16 hres[3];
+    f32x16 hres[MT];
     {   // ---- in-layer conv: packed tiles 3w .. 3w+2 (tile 2p = rows 32p.. of the tanh half, 2p+1 = same rows, sigmoid half)
-        f32x16 acc[3];
-        const float* wp[3];
+        f32x16 acc[MT];
+        const float* wp[MT];
         MI355_UNROLL
-        for (int m = 0; m < 3; ++m) {
-            const int q = 3 * w + m;
+        for (int m = 0; m < MT; ++m) {
+            const int q = MT * w + m;
             const int row0 = ((q & 1) ? H : 0) + 32 * (q >> 1);
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
@@ -276,25 +278,25 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
             }
             wp[m] = a.w_in + (long)q * a.K * CP * 64 + lane;
         }
-        if (!(a.ablate & 1)) wn_mfma<3, CP>(acc, wp, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
-        if (two && w < 2) {  // the residual input of this wave's h' tiles, while the h tile is still there
+        if (!(a.ablate & 1)) wn_mfma<MT, CP>(acc, wp, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
+        if (two && MT * w < NTILE / 2) {  // the residual input of this wave's h' tiles, while the h tile is still there
             MI355_UNROLL
-            for (int m = 0; m < 3; ++m)
+            for (int m = 0; m < MT; ++m)
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r)
-                    hres[m][r] = X[(32 * (3 * w + m) + (r & 3) + 8 * (r >> 2) + 4 * brow) * LDX + toff + pad + bcol];
+                    hres[m][r] = X[(32 * (MT * w + m) + (r & 3) + 8 * (r >> 2) + 4 * brow) * LDX + toff + pad + bcol];
         }
         __syncthreads();  // every wave is done with the h tile
         MI355_UNROLL
-        for (int m = 0; m < 3; ++m) {
-            const int q = 3 * w + m;
+        for (int m = 0; m < MT; ++m) {
+            const int q = MT * w + m;
             const int row0 = ((q & 1) ? H : 0) + 32 * (q >> 1);
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) X[(row0 + (r & 3) + 8 * (r >> 2) + 4 * brow) * 32 + bcol] = acc[m][r];
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < H * 32; idx += 256) {  // gate in place: U[c][t] = tanh(A[c][t]) * sigmoid(A[H + c][t])
+    for (int idx = tid; idx < H * 32; idx += NTH) {  // gate in place: U[c][t] = tanh(A[c][t]) * sigmoid(A[H + c][t])
         const float at = X[idx], as = X[H * 32 + idx];
         const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(at, -15.0f), 15.0f));
         const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
@@ -319,18 +321,27 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192(WnA
         }
     };
     if (two) {
-        f32x16 acc[3];
-        const float* wp[3];
+        f32x16 acc[MT];
+        const float* wp[MT];
         MI355_UNROLL
-        for (int m = 0; m < 3; ++m) {
-            const int q = 3 * w + m;
+        for (int m = 0; m < MT; ++m) {
+            const int q = MT * w + m;
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) acc[m][r] = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow];
             wp[m] = a.w_rs + (long)q * CP * 64 + lane;
         }
-        if (!(a.ablate & 1)) wn_mfma<3, CP>(acc, wp, U, 32, 1, 0);
+        if (!(a.ablate & 1)) wn_mfma<MT, CP>(acc, wp, U, 32, 1, 0);
         MI355_UNROLL
-        for (int m = 0; m < 3; ++m) finish(acc[m], 3 * w + m, hres[m]);
+        for (int m = 0; m < MT; ++m) finish(acc[m], MT * w + m, hres[m]);
+    } else if (NW == 12) {  // 6 tiles, one per wave
+        if (w < 6) {
+            f32x16 a1[1];
+            const float* w1[1] = {a.w_rs + (long)w * CP * 64 + lane};
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) a1[0][r] = a.b_rs[32 * w + (r & 3) + 8 * (r >> 2) + 4 * brow];
+            if (!(a.ablate & 1)) wn_mfma<1, CP>(a1, w1, U, 32, 1, 0);
+            finish(a1[0], w, hres[0]);
+        }
     } else {  // 6 tiles: waves 0, 1 take two, waves 2, 3 one
         const int nq = w < 2 ? 2 : 1;
         f32x16 acc[2];
@@ -371,15 +382,18 @@ void launch_wn_layer(WnArgs a, hipStream_t s) {
     a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
     const size_t shmem = (size_t)a.H * a.ldx * sizeof(float);  // ldx >= 32: U fits in the h tile
     dim3 grid((a.T + 31) / 32, a.B);
-    // Two geometries with identical arithmetic (same bits): 4 waves x 3 tiles keeps the SIMDs evenly loaded when the grid
-    // fills the chip; 6 waves x 2 tiles has the shorter dependent MFMA chain per wave, which is what matters when only a
-    // few dozen workgroups exist (one utterance: 31 workgroups per layer).
+    // Three geometries with identical arithmetic (same bits): 4 waves x 3 tiles keeps the SIMDs evenly loaded when the
+    // grid fills the chip; 6 x 2 and 12 x 1 have ever shorter dependent MFMA chains per wave, which is what matters when
+    // only a few dozen workgroups exist (one utterance: 31 workgroups per layer).
     const char* six_s = getenv("MI355VITS_WN_SIX_WAVES");  // read per launch: tests flip it inside one process
     const int six_env = six_s ? atoi(six_s) : -1;
-    const bool six_waves = six_env >= 0 ? six_env != 0 : (long)grid.x * grid.y < 512;
-    if (a.H == 192 && !six_waves) {
-        const size_t sh4 = (size_t)a.H * (a.ldx > 64 ? a.ldx : 64) * sizeof(float);  // h tile, then [2H][32] raw result
-        LAUNCH_KERNEL(k_wn_layer_h192, grid, dim3(256), sh4, s, a);
+    const long nwg = (long)grid.x * grid.y;
+    const int geom = six_env >= 0 ? six_env : (nwg < 128 ? 2 : (nwg < 512 ? 1 : 0));  // 0: 4x3, 1: 6x2, 2: 12x1
+    const size_t sh4 = (size_t)a.H * (a.ldx > 64 ? a.ldx : 64) * sizeof(float);  // h tile, then [2H][32] raw result
+    if (a.H == 192 && geom == 0) {
+        LAUNCH_KERNEL(k_wn_layer_h192<4>, grid, dim3(256), sh4, s, a);
+    } else if (a.H == 192 && geom == 2) {
+        LAUNCH_KERNEL(k_wn_layer_h192<12>, grid, dim3(768), sh4, s, a);
     } else if (a.H == 192) {
         auto k = k_wn_layer<6>;
         LAUNCH_KERNEL(k, grid, dim3(384), shmem, s, a);

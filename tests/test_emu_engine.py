@@ -184,14 +184,15 @@ def test_fused_wavenet_layer_hidden_192(emu_lib):
     # the two geometries of the fused kernel (4 waves x 3 tiles for full grids, 6 waves x 2 tiles for small ones) do the
     # same arithmetic in the same order: identical bits, so the choice may depend on the batch size
     outs = {}
-    for six in ("0", "1"):
+    for six in ("0", "1", "2"):
         os.environ["MI355VITS_WN_SIX_WAVES"] = six
         try:
             outs[six], _ = check_parity(emu_lib, cfg, B=2, Tx=14, seed=71, weights=w)
         finally:
             del os.environ["MI355VITS_WN_SIX_WAVES"]
     assert np.array_equal(outs["0"]["audio"], outs["1"]["audio"])
-    assert np.array_equal(outs["1"]["audio"], out["audio"])  # small grid -> the 6-wave geometry by default
+    assert np.array_equal(outs["0"]["audio"], outs["2"]["audio"])
+    assert np.array_equal(outs["2"]["audio"], out["audio"])  # tiny grid -> the 12-wave geometry by default
 
 
 def test_odd_flow_depth_folds_final_flip(emu_lib):

@@ -176,11 +176,11 @@ def test_wavenet_layer_geometries_give_identical_bits(gpu_lib):
     ids = np.random.default_rng(3).integers(1, 50, (2, 48)).astype(np.int64)
     forced = np.full((2, 48), 4, np.int32)
     outs = {}
-    for six in ("0", "1"):
+    for six in ("0", "1", "2"):
         os.environ["MI355VITS_WN_SIX_WAVES"] = six
         try:
             outs[six] = eng.run(ids, [48, 31], [0.667, 1.0, 0.8], forced_durations=forced, seed=9)["audio"]
         finally:
             del os.environ["MI355VITS_WN_SIX_WAVES"]
-    assert np.array_equal(outs["0"], outs["1"])
+    assert np.array_equal(outs["0"], outs["1"]) and np.array_equal(outs["0"], outs["2"])
     eng.close()
