@@ -147,6 +147,150 @@ __global__ __launch_bounds__(64) void k_rel_attention_mfma(const float* __restri
     }
 }
 
+// Four waves per (batch, head, 32 queries): key tile t belongs to wave t % 4, so a wave holds T / 128 score tiles
+// instead of T / 32 (no spills at T = 512, a quarter of the dependent MFMA chain).  Softmax statistics and the PV
+// partial sums are combined across the waves through LDS in a fixed order (deterministic; key tiles beyond a row's
+// length contribute exact zeros, so the result does not depend on how far the batch pads it).
+template <int NKW>  // key tiles per wave: T <= 128 * NKW
+__global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __restrict__ qkv, const float* __restrict__ ek,
+                                                             const float* __restrict__ ev, const int* __restrict__ len,
+                                                             int T, int H, int nh, int W, float* __restrict__ out) {
+    DYN_SMEM(float, smem);
+    float* tab = smem;                 // [32][32] window table: rel-k logits, later rel probabilities
+    float* red = smem + 32 * 32;       // [2][4][32] max / sum per wave and query
+    float* ored = red + 2 * 4 * 32;    // [4][16][64] partial O^T tiles
+    const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int d = H / nh, nrel = 2 * W + 1;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int i0 = blockIdx.x * 32;
+    const int i = i0 + bcol;
+    const int L = len[b];
+    const float scale = 1.0f / sqrtf((float)d);
+    const float* qb = qkv + ((long)b * 3 * H + h * d) * T;
+    const float* kb = qb + (long)H * T;
+    const float* vb = qb + (long)2 * H * T;
+    const bool iq = i < T;
+
+    f32x16 st[NKW];
+    f32x16 rl;
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) rl[r] = 0.0f;
+    MI355_UNROLL
+    for (int m = 0; m < NKW; ++m)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) st[m][r] = 0.0f;
+    constexpr int U = 4;
+    for (int cp0 = 0; cp0 < d / 2; cp0 += U) {
+        float qv[U], ekv[U], kv[U][NKW];
+        MI355_UNROLL
+        for (int u = 0; u < U; ++u) {
+            const int c = 2 * (cp0 + u) + brow;
+            const bool cin = c < d;
+            qv[u] = (iq && cin) ? qb[(long)c * T + i] * scale : 0.0f;
+            ekv[u] = (w == 0 && bcol < nrel && cin) ? ek[bcol * d + c] : 0.0f;
+            MI355_UNROLL
+            for (int m = 0; m < NKW; ++m) {
+                const int j = (w + 4 * m) * 32 + bcol;
+                kv[u][m] = (j < T && cin) ? kb[(long)c * T + j] : 0.0f;
+            }
+        }
+        MI355_UNROLL
+        for (int u = 0; u < U; ++u) {
+            if (w == 0) rl = MFMA_32x32x2_F32(ekv[u], qv[u], rl);
+            MI355_UNROLL
+            for (int m = 0; m < NKW; ++m) st[m] = MFMA_32x32x2_F32(kv[u][m], qv[u], st[m]);
+        }
+    }
+    if (w == 0) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) tab[((r & 3) + 8 * (r >> 2) + 4 * brow) * 32 + bcol] = rl[r];
+    }
+    __syncthreads();
+
+    float mx = -3.0e38f;
+    MI355_UNROLL
+    for (int m = 0; m < NKW; ++m) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int j = (w + 4 * m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            float sc = st[m][r];
+            const int rel = j - i;
+            if (rel >= -W && rel <= W) sc += tab[(rel + W) * 32 + bcol];
+            if (j >= L || i >= L) sc = -1e4f;
+            if (j >= T) sc = -3.0e38f;
+            st[m][r] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (brow == 0) red[w * 32 + bcol] = mx;
+    __syncthreads();  // maxima visible; everyone has read the logits table
+    mx = fmaxf(fmaxf(red[bcol], red[32 + bcol]), fmaxf(red[64 + bcol], red[96 + bcol]));
+    for (int r = tid >> 5; r < 32; r += 8) tab[r * 32 + bcol] = 0.0f;
+    __syncthreads();
+    float sum = 0.0f;
+    MI355_UNROLL
+    for (int m = 0; m < NKW; ++m) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int j = (w + 4 * m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+            const float e = j < T ? expf(st[m][r] - mx) : 0.0f;
+            st[m][r] = e;
+            sum += e;
+            const int rel = j - i;
+            if (j < T && rel >= -W && rel <= W) tab[(rel + W) * 32 + bcol] = e;
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    if (brow == 0) red[128 + w * 32 + bcol] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (((red[128 + bcol] + red[160 + bcol]) + red[192 + bcol]) + red[224 + bcol]);
+
+    for (int c0 = 0; c0 < d; c0 += 32) {
+        f32x16 o;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+        const int cr = c0 + bcol;
+        const bool cv = cr < d;
+        const float* vr = vb + (long)(cv ? cr : 0) * T;
+        MI355_UNROLL
+        for (int m = 0; m < NKW; ++m) {
+            MI355_UNROLL
+            for (int g = 0; g < 4; ++g) {
+                MI355_UNROLL
+                for (int q = 0; q < 4; ++q) {
+                    const int j = (w + 4 * m) * 32 + 8 * g + 4 * brow + q;
+                    const float vv = (cv && j < T) ? vr[j] : 0.0f;
+                    o = MFMA_32x32x2_F32(vv, st[m][4 * g + q], o);
+                }
+            }
+        }
+        if (w == 0) {
+            for (int s2 = 0; s2 < (nrel + 1) / 2; ++s2) {
+                const int r = 2 * s2 + brow;
+                const float evv = (cv && r < nrel) ? ev[r * d + cr] : 0.0f;
+                const float pv = r < nrel ? tab[r * 32 + bcol] : 0.0f;
+                o = MFMA_32x32x2_F32(evv, pv, o);
+            }
+        }
+        if (c0 > 0) __syncthreads();  // the previous tile's partials have been consumed
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) ored[(w * 16 + r) * 64 + lane] = o[r];
+        __syncthreads();
+        if (iq) {
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * w + q;
+                const float v = ((ored[(0 * 16 + r) * 64 + lane] + ored[(1 * 16 + r) * 64 + lane]) + ored[(2 * 16 + r) * 64 + lane]) +
+                                ored[(3 * 16 + r) * 64 + lane];
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                if (c < d) out[((long)b * H + h * d + c) * T + i] = v * inv;
+            }
+        }
+    }
+}
+
 bool rel_attention_mfma_supported(int T, int H, int n_heads, int window) {
     const int d = H / n_heads;
     return T >= 1 && T <= 512 && (d % 2) == 0 && window >= 0 && 2 * window + 1 <= 32;
@@ -156,6 +300,21 @@ void launch_rel_attention_mfma(const float* qkv, const float* emb_rel_k, const f
                                int T, int H, int n_heads, int window, float* out, hipStream_t s) {
     if (!rel_attention_mfma_supported(T, H, n_heads, window)) throw std::runtime_error("rel_attention_mfma: unsupported shape");
     dim3 grid((T + 31) / 32, n_heads, B);
+    static const bool one_wave = getenv("MI355VITS_ATTN_ONE_WAVE") != nullptr;  // the older single-wave kernel
+    if (!one_wave) {
+        const size_t sh4 = (32 * 32 + 2 * 4 * 32 + 4 * 16 * 64) * sizeof(float);
+        if (T <= 128) {
+            auto k = k_rel_attention_mfma4<1>;
+            LAUNCH_KERNEL(k, grid, dim3(256), sh4, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+        } else if (T <= 256) {
+            auto k = k_rel_attention_mfma4<2>;
+            LAUNCH_KERNEL(k, grid, dim3(256), sh4, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+        } else {
+            auto k = k_rel_attention_mfma4<4>;
+            LAUNCH_KERNEL(k, grid, dim3(256), sh4, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+        }
+        return;
+    }
     const size_t shmem = 32 * 32 * sizeof(float);
     if (T <= 128) {
         auto k = k_rel_attention_mfma<4>;
