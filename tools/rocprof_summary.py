@@ -63,7 +63,7 @@ def _labels(B, Tx, fpi):
     return {
         "dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2", 2 * 4 * B * 64 * Ty * 64),      # read x + write y, [64, 64 Ty]
         "dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2", 2 * 4 * B * 32 * Ty * 256),    # [32, 256 Ty]
-        "flow.wn_layer": ("k_wn_layer_h192", 4 * 4 * B * 192 * Ty + 4 * (384 * 192 * 5 + 384 * 192)),  # h r+w, skip r+w, weights
+        "flow.wn_layer": ("k_wn_layer_h192<4>", 4 * 4 * B * 192 * Ty + 4 * (384 * 192 * 5 + 384 * 192)),  # h r+w, skip r+w, weights
     }
 
 
