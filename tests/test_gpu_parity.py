@@ -184,3 +184,11 @@ def test_wavenet_layer_geometries_give_identical_bits(gpu_lib):
             del os.environ["MI355VITS_WN_SIX_WAVES"]
     assert np.array_equal(outs["0"], outs["1"]) and np.array_equal(outs["0"], outs["2"])
     eng.close()
+
+
+def test_plain_c_client_on_the_device(gpu_lib, tmp_path):
+    """The C ABI driven from plain C against libmi355vits.so on the MI355X (full-size multi-speaker voice)."""
+    from tests.util import run_c_client
+
+    out = run_c_client(gpu_lib, tmp_path, cfg=VitsConfig.vctk_low(), seed=3)
+    assert "gfx950" in out and "speakers 109" in out

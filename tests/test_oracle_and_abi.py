@@ -138,3 +138,12 @@ def test_product_path_has_no_cpu_fallback():
         cfg = VitsConfig.tiny()
         with pytest.raises(NativeError):
             Engine(W.pack(cfg, W.synthetic_weights(cfg, seed=1)))
+
+
+def test_plain_c_client_of_the_header(emu_lib, tmp_path):
+    """include/mi355vits.h compiled as C (gcc -std=c99 -pedantic), linked against the library (here: its CPU model),
+    driving create / get_config / run / free_result / last_error / destroy — the binding any other host language
+    would make.  Its PCM equals what the ctypes path returns."""
+    from tests.util import run_c_client
+
+    run_c_client(emu_lib, tmp_path)

@@ -83,3 +83,30 @@ def check_parity(lib, cfg: VitsConfig, B=2, Tx=9, seed=0, scales=(0.0, 1.0, 0.0)
         assert np.all(out["pcm"][b, L:] == 0)
     eng.close()
     return out, o1
+
+
+def run_c_client(lib, tmp_path, cfg=None, seed=17):
+    """Compile tests/abi/abi_client.c (plain C99) against `lib`, run it on a voice file, compare its PCM with ctypes."""
+    import ctypes
+    import os
+    import subprocess
+
+    from mimic3_amd.config import CVitsConfig
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_client"
+    libdir, libname = os.path.split(lib.path)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "abi", "abi_client.c"), "-o", str(exe), "-L", libdir,
+                    "-l:" + libname, "-Wl,-rpath," + libdir], check=True)
+    cfg = cfg or VitsConfig.tiny()
+    w = W.synthetic_weights(cfg, seed=seed)
+    W.save(str(tmp_path / "voice.m355"), cfg, w)
+    p = subprocess.run([str(exe), str(tmp_path / "voice.m355"), str(tmp_path / "out.raw")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert f"sizeof config {ctypes.sizeof(CVitsConfig)} " in p.stdout
+    assert p.stdout.count("expected failure") == 2
+    pcm = np.fromfile(tmp_path / "out.raw", dtype=np.int16)
+    ref = Engine(W.pack(cfg, w), library=lib).run(np.array([[3, 7, 1, 9, 4]]), [5], [0, 1, 0], want_pcm16=True)
+    assert np.array_equal(pcm, ref["pcm"][0, : int(ref["lengths"][0])])
+    return p.stdout
