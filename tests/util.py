@@ -107,6 +107,7 @@ def run_c_client(lib, tmp_path, cfg=None, seed=17):
     assert f"sizeof config {ctypes.sizeof(CVitsConfig)} " in p.stdout
     assert p.stdout.count("expected failure") == 2
     pcm = np.fromfile(tmp_path / "out.raw", dtype=np.int16)
-    ref = Engine(W.pack(cfg, w), library=lib).run(np.array([[3, 7, 1, 9, 4]]), [5], [0, 1, 0], want_pcm16=True)
+    sid = [0] if cfg.is_multispeaker else None
+    ref = Engine(W.pack(cfg, w), library=lib).run(np.array([[3, 7, 1, 9, 4]]), [5], [0, 1, 0], sid, want_pcm16=True)
     assert np.array_equal(pcm, ref["pcm"][0, : int(ref["lengths"][0])])
     return p.stdout
