@@ -127,14 +127,16 @@ def main():
         [t.join() for t in ts]
         if errs:
             raise errs[0]
-        return next(o for o in outs if o is not None)
+        return next((o for o in outs if o is not None), None)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(max(args.warmup, len(engines) if args.warmup else 0))
+    for e in engines:  # every handle sizes its workspace on first use: never inside the timed region
+        step(0, e)
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
