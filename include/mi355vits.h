@@ -11,6 +11,7 @@
  *                              length_scale, noise_w; "sid" int64 [B] iff multi-speaker)
  *     + MI355VITS_WANT_PCM16   audio_float_to_int16(audio)         mimic3_tts/utils.py:237-244
  *                              (called right after run, inside the timed region, voice.py:231)
+ *     + run_args.pcm_volume    audioop.mul(audio_bytes, 2, volume / 100)   mimic3_tts/tts.py:542-543
  *   mi355vits_destroy          the session's finaliser (voice.py:71-72 keeps sessions in a
  *                              process-wide cache, so they live until exit)
  *   mi355vits_get_config       TrainingConfig.model / .audio       mimic3_tts/config.py:112-143,30-60
@@ -100,6 +101,9 @@ typedef struct mi355vits_run_args {
     int32_t noise_z_frames;
     const int32_t* forced_durations; /* optional [B, tx_max]: overrides ceil(exp(logw)*length_scale) */
     uint32_t flags;
+    double pcm_volume;         /* with WANT_PCM16: audioop.mul(pcm, 2, pcm_volume) fused into the int16 kernel —
+                                * what Mimic3TextToSpeechSystem._speak_sentence_phonemes does on the host with
+                                * settings.volume / 100 (mimic3_tts/tts.py:542-543).  0 or 1 = leave as is. */
 } mi355vits_run_args;
 
 typedef struct mi355vits_result {

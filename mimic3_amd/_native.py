@@ -55,6 +55,7 @@ class RunArgs(ctypes.Structure):
         ("noise_z_frames", ctypes.c_int32),
         ("forced_durations", ctypes.POINTER(ctypes.c_int32)),
         ("flags", ctypes.c_uint32),
+        ("pcm_volume", ctypes.c_double),
     ]
 
 
@@ -249,7 +250,7 @@ class Engine:
     # ---- one synthesis call ---------------------------------------------------------------------
     def run(self, ids, lengths, scales, sid=None, *, seed: int = 0, utterance_base: int = 0, noise_w=None,
             noise_z=None, forced_durations=None, want_float: bool = True, want_pcm16: bool = False,
-            device_only: bool = False, debug_taps: bool = False) -> Dict[str, np.ndarray]:
+            device_only: bool = False, debug_taps: bool = False, pcm_volume: float = 1.0) -> Dict[str, np.ndarray]:
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         if ids.ndim != 2:
             raise ValueError("'input' must have shape [batch, phonemes]")
@@ -295,6 +296,7 @@ class Engine:
             a.forced_durations = forced_durations.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
         a.flags = (WANT_FLOAT if want_float else 0) | (WANT_PCM16 if want_pcm16 else 0) | \
                   (DEVICE_ONLY if device_only else 0) | (DEBUG_TAPS if debug_taps else 0)
+        a.pcm_volume = float(pcm_volume)
         r = Result()
         self._check(self.native.lib.mi355vits_run(self._h, ctypes.byref(a), ctypes.byref(r)))
         del keep

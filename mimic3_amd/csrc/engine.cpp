@@ -1098,7 +1098,8 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     have_pcm_ = false;
     if (args.flags & MI355VITS_WANT_PCM16) {
         ProfScope ps(prof_, "pcm16", 0, 6.0 * B * (double)L_);
-        launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B, (int)L_, d_pcm_, L_, stream_);
+        pcm_volume_ = (args.pcm_volume > 0.0) ? args.pcm_volume : 1.0;
+        launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B, (int)L_, d_pcm_, L_, stream_, pcm_volume_);
         have_pcm_ = true;
     }
     HIP_CHECK(hipEventRecord(ev_end_, stream_));
@@ -1130,7 +1131,7 @@ void Engine::copy_out(uint32_t want, mi355vits_result* out) {
     }
     if (!dev_only && (want & MI355VITS_WANT_PCM16)) {
         if (!have_pcm_) {
-            launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B, (int)L_, d_pcm_, L_, stream_);
+            launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B, (int)L_, d_pcm_, L_, stream_, 1.0);
             have_pcm_ = true;
         }
         HIP_CHECK(hipHostMalloc(&own->pcm, sizeof(int16_t) * (size_t)B * L_ + 16, hipHostMallocDefault));

@@ -154,6 +154,7 @@ class Engine {
     int B_ = 0, Tx_ = 0, Ty_ = 0;
     long L_ = 0;
     bool have_result_ = false, have_pcm_ = false;
+    double pcm_volume_ = 1.0;
     // phase-A buffers (sized by B, Tx)
     long long *d_ids_ = nullptr, *d_sid_ = nullptr;
     int *d_len_ = nullptr, *d_wceil_ = nullptr, *d_cum_ = nullptr, *d_ylen_ = nullptr, *d_alen_ = nullptr,

@@ -114,8 +114,10 @@ void launch_wn_layer(WnArgs a, hipStream_t s);
 void launch_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, int Cin, int K, int B, int L,
                            const int* valid_len, float* audio, long audio_bs, unsigned* peak_bits, hipStream_t s);
 // audio_float_to_int16 per utterance (utils.py:237-244) from the peaks found above.
+// volume != 1: followed by audioop.mul(pcm, 2, volume) (tts.py:542-543): sample * volume in double, clipped to
+// [-32768, 32767], rounded toward minus infinity.
 void launch_pcm16(const float* audio, long audio_bs, const unsigned* peak_bits, const int* valid_len, int B, int L,
-                  int16_t* pcm, long pcm_bs, hipStream_t s);
+                  int16_t* pcm, long pcm_bs, hipStream_t s, double volume = 1.0);
 
 // ---------------------------------------------------------------- encoder pieces
 void launch_embed(const long long* ids, const int* len, const float* emb, int B, int T, int H, int num_symbols,

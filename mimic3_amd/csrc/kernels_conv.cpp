@@ -1107,7 +1107,7 @@ void launch_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, 
 // audio_float_to_int16 (mimic3_tts/utils.py:237-244) per utterance: scale = 32767 / max(0.01, peak),
 // clip to +-32767, truncate toward zero.  Rows are zero beyond their valid length.
 __global__ __launch_bounds__(256) void k_pcm16(const float* audio, long audio_bs, const unsigned* peak_bits,
-                                               const int* valid_len, int L, int16_t* pcm, long pcm_bs) {
+                                               const int* valid_len, int L, int16_t* pcm, long pcm_bs, double volume) {
     const int b = blockIdx.y;
     const float peak = fmaxf(0.01f, __uint_as_float(peak_bits[b]));
     const float scale = 32767.0f / peak;
@@ -1118,16 +1118,24 @@ __global__ __launch_bounds__(256) void k_pcm16(const float* audio, long audio_bs
             v = audio[(long)b * audio_bs + t] * scale;
             v = fminf(fmaxf(v, -32767.0f), 32767.0f);
         }
-        pcm[(long)b * pcm_bs + t] = (int16_t)(int)v;
+        int q = (int)v;  // truncation toward zero: numpy's astype("int16") on an in-range float
+        if (volume != 1.0) {
+            // audioop.mul (CPython Modules/audioop.c, fbound): double product, clip to the int16 range, floor
+            double d = (double)q * volume;
+            if (d > 32767.0) d = 32767.0;
+            else if (d < -32768.0 + 1.0) d = -32768.0;
+            q = (int)floor(d);
+        }
+        pcm[(long)b * pcm_bs + t] = (int16_t)q;
     }
 }
 
 void launch_pcm16(const float* audio, long audio_bs, const unsigned* peak_bits, const int* valid_len, int B, int L,
-                  int16_t* pcm, long pcm_bs, hipStream_t s) {
+                  int16_t* pcm, long pcm_bs, hipStream_t s, double volume) {
     if (L <= 0 || B <= 0) return;
     int gx = (L + 255) / 256;
     if (gx > 2048) gx = 2048;
-    LAUNCH_KERNEL(k_pcm16, dim3(gx, B), dim3(256), 0, s, audio, audio_bs, peak_bits, valid_len, L, pcm, pcm_bs);
+    LAUNCH_KERNEL(k_pcm16, dim3(gx, B), dim3(256), 0, s, audio, audio_bs, peak_bits, valid_len, L, pcm, pcm_bs, volume);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -287,10 +287,20 @@ class InferenceSession:
         return [audio[:, None, :]]
 
     # ---- engine extensions --------------------------------------------------------------------
-    def run_pcm16(self, input_feed: Dict[str, np.ndarray]) -> Tuple[List[np.ndarray], np.ndarray]:
+    def run_pcm16(self, input_feed: Dict[str, np.ndarray], volume: Optional[float] = None
+                  ) -> Tuple[List[np.ndarray], np.ndarray]:
         """``run`` + ``audio_float_to_int16`` (``utils.py:237-244``) fused on the GPU, per utterance over its
-        valid samples.  Returns ([int16 [L_b]] per row, lengths)."""
-        out = self._run(input_feed, want_float=False, want_pcm16=True)
+        valid samples.  Returns ([int16 [L_b]] per row, lengths).
+
+        ``volume`` (percent, like ``Mimic3Settings.volume``): additionally applies
+        ``audioop.mul(audio_bytes, 2, volume / 100)`` (``tts.py:542-543``) in the same kernel — same bytes as the host
+        call, one pass fewer over the audio."""
+        kw = {}
+        if volume is not None and float(volume) != 100.0:
+            if not float(volume) > 0.0:
+                raise InvalidArgument("volume must be > 0 (percent)")
+            kw["pcm_volume"] = float(volume) / 100.0
+        out = self._run(input_feed, want_float=False, want_pcm16=True, **kw)
         return [out["pcm"][b, : int(out["lengths"][b])] for b in range(out["pcm"].shape[0])], out["lengths"]
 
     def _run(self, input_feed, **kw) -> Dict[str, np.ndarray]:

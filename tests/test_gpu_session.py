@@ -97,3 +97,20 @@ def test_lanes_overlap_concurrent_calls_on_the_device():
     [t.join() for t in ts]
     for e, g in zip(expect, got):
         assert np.array_equal(e, g)
+
+
+def test_fused_volume_on_the_device_equals_audioop_mul():
+    import audioop
+
+    cfg = VitsConfig.apope_low()
+    sess = InferenceSession(W.pack(cfg, W.synthetic_weights(cfg, seed=6, frames_per_id=2.0)))
+    ids = np.random.default_rng(1).integers(1, 50, (2, 30)).astype(np.int64)
+    feed = {"input": ids, "input_lengths": np.array([30, 11], np.int64), "scales": np.array([0.667, 1.0, 0.8], np.float32)}
+    sess._seed = 4
+    sess._utterances = 0
+    base, _ = sess.run_pcm16(feed)
+    for vol in (50.0, 33.0, 180.0):
+        sess._utterances = 0  # same noise stream as the base run
+        rows, _ = sess.run_pcm16(feed, volume=vol)
+        for r, b0 in zip(rows, base):
+            assert np.array_equal(r, np.frombuffer(audioop.mul(b0.tobytes(), 2, vol / 100.0), dtype=np.int16))

@@ -234,3 +234,42 @@ def test_two_rank_shard_and_gather_matches_single_process(emu_lib, tmp_path):
     for b in range(5):
         L = int(sess.last_lengths[b])
         assert np.array_equal(got[f"a{b}"], ref[b, 0, :L])
+
+
+def test_fused_volume_equals_audioop_mul_and_wav_helpers(emu_lib):
+    """N4: settings.volume applied inside the int16 kernel gives the bytes audioop.mul gives on the host
+    (tts.py:542-543); silence / WAV framing helpers match add_break and the wave module."""
+    import audioop
+    import io
+    import wave
+
+    from mimic3_amd import postprocess as PP
+
+    cfg = VitsConfig.tiny()
+    sess = InferenceSession(W.pack(cfg, W.synthetic_weights(cfg, seed=3, frames_per_id=3.0)), _library=emu_lib)
+    feed = {"input": np.array([[3, 7, 1, 9, 4, 2, 8], [5, 5, 2, 0, 0, 0, 0]], np.int64),
+            "input_lengths": np.array([7, 3], np.int64), "scales": np.array([0, 1, 0], np.float32)}
+    base, lengths = sess.run_pcm16(feed)
+    assert max(int(np.abs(r).max()) for r in base) >= 32766
+    for vol in (50.0, 33.0, 150.0, 7.5, 99.9, 100.0):
+        rows, _ = sess.run_pcm16(feed, volume=vol)
+        for r, b0 in zip(rows, base):
+            want = np.frombuffer(audioop.mul(b0.tobytes(), 2, vol / 100.0), dtype=np.int16)
+            assert np.array_equal(r, want), vol
+            assert np.array_equal(PP.apply_volume(b0, vol), want), vol
+    with pytest.raises(ValueError):
+        sess.run_pcm16(feed, volume=0.0)
+    edge = np.array([-32768, -32767, -1, 0, 1, 32767], np.int16)
+    for vol in (100.0, 250.0, 1.0, 50.0):
+        assert np.array_equal(PP.apply_volume(edge, vol), np.frombuffer(audioop.mul(edge.tobytes(), 2, vol / 100.0), dtype=np.int16))
+    assert PP.silence(250).shape == (int(0.25 * 22050),) and not PP.silence(250).any()
+    blob = PP.utterances_to_wav(base, 22050, break_ms=100)
+    with wave.open(io.BytesIO(blob), "rb") as wf:
+        assert (wf.getframerate(), wf.getsampwidth(), wf.getnchannels()) == (22050, 2, 1)
+        frames = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
+    assert np.array_equal(frames, np.concatenate([base[0], PP.silence(100), base[1]]))
+    ref = io.BytesIO()
+    with wave.open(ref, "wb") as wf:
+        wf.setframerate(22050); wf.setsampwidth(2); wf.setnchannels(1)
+        wf.writeframes(frames.tobytes())
+    assert blob == ref.getvalue()

@@ -217,5 +217,12 @@ int main(int argc, char** argv) {
     run<1, 1, 3>("A L2 + B LDS", 8, 2, 32768, w, out, wstride, true);
     run<4, 1, 3>("A L2 + B LDS", 4, 2, 32768, w, out, wstride);
     run<4, 1, 3>("A L2 + B LDS", 4, 2, 32768, w, out, wstride, true);
+    run<3, 1, 3>("A L2 + B LDS (wn_layer 4-wave shape)", 4, 3, 49152, w, out, wstride);
+    run<3, 1, 3>("A L2 + B LDS (wn_layer 4-wave shape)", 4, 3, 49152, w, out, wstride, true);
+    run<3, 2, 3>("A L2 + B LDS", 4, 1, 98304, w, out, wstride);
+    run<3, 2, 3>("A L2 + B LDS", 4, 2, 65536, w, out, wstride);
+    run<3, 2, 3>("A L2 + B LDS", 4, 2, 65536, w, out, wstride, true);
+    run<2, 2, 3>("A L2 + B LDS", 4, 3, 49152, w, out, wstride);
+    run<2, 2, 3>("A L2 + B LDS (generic conv shape)", 4, 3, 53248, w, out, wstride);
     return 0;
 }
