@@ -145,6 +145,15 @@ class _MicroBatcher:
         self._q: "queue.Queue" = queue.Queue()
         self.batches = 0
         self.requests = 0
+        self._count_lock = threading.Lock()
+        # with several lanes the dispatcher hands each batch to a worker and goes back to collecting, so that one batch
+        # can run its launch-bound front half while the previous one is still in its matrix-core back half
+        lanes = len(getattr(session, "_engines", [None]))
+        self._pool = None
+        if lanes > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="mi355vits-lane")
         self._thread = threading.Thread(target=self._loop, name="mi355vits-microbatch", daemon=True)
         self._thread.start()
 
@@ -183,7 +192,10 @@ class _MicroBatcher:
                 key = (tuple(np.asarray(it[2], np.float32).tolist()), it[3] is None, tuple(sorted(it[4].items())))
                 groups.setdefault(key, []).append(it)
             for group in groups.values():
-                self._run_group(group)
+                if self._pool is not None:
+                    self._pool.submit(self._run_group, group)
+                else:
+                    self._run_group(group)
 
     def _run_group(self, group):
         try:
@@ -198,8 +210,9 @@ class _MicroBatcher:
             sid = None if group[0][3] is None else np.array([int(g[3][0]) for g in group], np.int64)
             kw = dict(group[0][4])
             out = self._session._engine_run(ids, lens, group[0][2], sid, **kw)
-            self.batches += 1
-            self.requests += B
+            with self._count_lock:
+                self.batches += 1
+                self.requests += B
             for b, g in enumerate(group):
                 L = int(out["lengths"][b])
                 res = {"lengths": out["lengths"][b:b + 1].copy(), "peaks": out["peaks"][b:b + 1].copy()}
