@@ -130,6 +130,43 @@ def _device_from_providers(providers, provider_options, sess_options) -> int:
     return dev
 
 
+class _LanePool:
+    """Engine handles shared by the caller threads, first come first served.  A released handle is handed straight to
+    the longest-waiting caller (no barging): with plain lock / queue semantics a worker that has just finished can
+    grab the handle again before the notified waiter wakes up, and some callers starve for seconds under load."""
+
+    def __init__(self, engines):
+        from collections import deque
+
+        self._free = deque(engines)
+        self._waiters = deque()
+        self._lock = threading.Lock()
+        self.size = len(engines)
+
+    def acquire(self):
+        with self._lock:
+            if self._free and not self._waiters:
+                return self._free.popleft()
+            slot = [None]
+            ev = threading.Event()
+            self._waiters.append((ev, slot))
+        ev.wait()
+        return slot[0]
+
+    def release(self, eng) -> None:
+        with self._lock:
+            if self._waiters:
+                ev, slot = self._waiters.popleft()
+                slot[0] = eng
+                ev.set()
+            else:
+                self._free.append(eng)
+
+    def idle(self) -> int:
+        with self._lock:
+            return len(self._free)
+
+
 class _MicroBatcher:
     """Coalesces concurrent B = 1 requests into batched engine calls (one dispatcher thread per session).
 
@@ -253,14 +290,10 @@ class InferenceSession:
         else:
             weights = resolve_voice_file(path_or_bytes)
             self._model_path = weights if isinstance(weights, str) else os.fspath(path_or_bytes)
-        import queue
-
         lanes = max(1, int(getattr(self._sess_options, "lanes", 1) or 1))
         self._engines = [_native.Engine(weights, device=device, library=library) for _ in range(lanes)]
         self._engine = self._engines[0]
-        self._free_lanes: "queue.LifoQueue[_native.Engine]" = queue.LifoQueue()
-        for e in reversed(self._engines):
-            self._free_lanes.put(e)
+        self._free_lanes = _LanePool(self._engines)
         self.config: VitsConfig = self._engine.config
         seed = self._sess_options.seed
         self._seed = int(seed) if seed is not None else next(InferenceSession._seed_counter)
@@ -347,7 +380,7 @@ class InferenceSession:
         with self._lock:
             base = self._utterances
             self._utterances += ids.shape[0]
-        eng = self._free_lanes.get()  # blocks while every lane is busy
+        eng = self._free_lanes.acquire()  # blocks while every lane is busy; first come first served
         try:
             return eng.run(ids, lengths, scales, sid, seed=self._seed, utterance_base=base, **kw)
         except _native.NativeError as e:
@@ -355,7 +388,7 @@ class InferenceSession:
                 raise InvalidArgument(str(e)) from None
             raise RuntimeError(str(e)) from None
         finally:
-            self._free_lanes.put(eng)
+            self._free_lanes.release(eng)
 
     @property
     def engine(self) -> _native.Engine:

@@ -159,14 +159,14 @@ def test_lanes_run_concurrent_calls_on_separate_engine_handles(emu_lib):
     expect = [one.run(None, f)[0] for f in feeds]
     got = [None] * 6
     seen = set()
-    orig = three._free_lanes.get
+    orig = three._free_lanes.acquire
 
     def spy_get(*a, **k):
         e = orig(*a, **k)
         seen.add(id(e))
         return e
 
-    three._free_lanes.get = spy_get
+    three._free_lanes.acquire = spy_get
     barrier = threading.Barrier(6)
 
     def work(i):
@@ -179,7 +179,7 @@ def test_lanes_run_concurrent_calls_on_separate_engine_handles(emu_lib):
     for e, g in zip(expect, got):
         assert np.array_equal(e, g)
     assert len(seen) >= 2  # more than one lane was used
-    assert three._free_lanes.qsize() == 3  # every lane came back
+    assert three._free_lanes.idle() == 3  # every lane came back
 
 
 def test_onnxruntime_shim_module_surface():
