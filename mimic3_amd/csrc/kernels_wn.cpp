@@ -208,6 +208,52 @@ __device__ __forceinline__ void wn_mfma(f32x16 (&acc)[MT], const float* const (&
     }
 }
 
+// Same product with the B operand packed for 16-byte LDS reads: the tile is stored [channel-pair group of 4][brow][column][4]
+// (element (c, col) at (((c >> 3) * 2 + (c & 1)) * LD + col) * 4 + ((c >> 1) & 3)), so one ds_read_b128 delivers a
+// lane's B fragments for four consecutive k-steps — a quarter of the LDS instructions of the b32 version, worth ~10 % of
+// the loop for this tile shape (tools/mfma_ceiling.hip, "B4").  x4 points at (group 0, this lane's brow, its column).
+template <int MT, int CP>
+__device__ __forceinline__ void wn_mfma_b4(f32x16 (&acc)[MT], const float* const (&wp)[MT], const float4* __restrict__ x4, int LD,
+                                           int K, int dil) {
+    static_assert(CP % 8 == 0, "channel pairs per tap must be a multiple of 8");
+    float ra[MT][8];
+    const float* g[MT];
+    MI355_UNROLL
+    for (int m = 0; m < MT; ++m) {
+        g[m] = wp[m];
+        MI355_UNROLL
+        for (int u = 0; u < 4; ++u) ra[m][u] = wp[m][u * 64];
+    }
+    float4 b0 = x4[0], b1 = b0;
+    for (int k = 0; k < K; ++k) {
+        MI355_UNROLL
+        for (int cp0 = 0; cp0 < CP; cp0 += 8) {
+            const float4* base = x4 + k * dil + (cp0 >> 2) * 2 * LD;
+            const bool last = (k == K - 1) && (cp0 + 8 == CP);
+            const float4* nbase = last ? base : ((cp0 + 8 < CP) ? base + 4 * LD : x4 + (k + 1) * dil);
+            const int back = last ? 8 * 64 : 0;  // the last group prefetches harmlessly from itself
+            MI355_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                float av[MT];
+                MI355_UNROLL
+                for (int m = 0; m < MT; ++m) {
+                    av[m] = ra[m][u];
+                    ra[m][(u + 4) & 7] = (u < 4) ? g[m][(u + 4) * 64] : (g[m] - back)[(u + 4) * 64];
+                }
+                if (u == 0) b1 = base[2 * LD];  // second group of four of this step group
+                const float4 bq = u < 4 ? b0 : b1;
+                const float bv = (u & 3) == 0 ? bq.x : ((u & 3) == 1 ? bq.y : ((u & 3) == 2 ? bq.z : bq.w));
+                if (u == 4) b0 = nbase[0];      // first group of the next step group (b0 is free from here on)
+                MI355_UNROLL
+                for (int m = 0; m < MT; ++m) acc[m] = MFMA_32x32x2_F32(av[m], bv, acc[m]);
+                SCHED_FENCE();
+            }
+            MI355_UNROLL
+            for (int m = 0; m < MT; ++m) g[m] += 8 * 64;
+        }
+    }
+}
+
 // H = 192: four waves, each three of the twelve 32-row tiles of either conv, 32 time columns per workgroup.  With
 // three MFMA tiles per wave and three workgroups per CU every SIMD carries exactly three waves (six waves of two
 // tiles leave the SIMDs 5/5/4/4), and fewer, fatter waves run the operand streams closer to the matrix-core rate
@@ -231,30 +277,23 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
     const int toff = tlo - ts;
     const float* hb = a.h_in + (long)b * a.h_bs;
+    // LDS index of element (channel c, column col) of a tile with `ld` columns: see wn_mfma_b4
+    auto pk = [](int c, int col, int ld) { return ((((c >> 3) * 2 + (c & 1)) * ld + col) << 2) + ((c >> 1) & 3); };
     if (!(a.ablate & 2)) {
-        if (a.vec) {
-            const int ld4 = LDX >> 2;
-            for (int idx = tid; idx < H * ld4; idx += NTH) {
-                const int r = idx / ld4, c4 = idx - r * ld4;
-                const int t = ts + 4 * c4;
-                const float* row = hb + (long)r * a.h_ld;
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (t >= 0 && t + 3 < len) {
-                    v = *reinterpret_cast<const float4*>(row + t);
-                } else {
-                    if (t >= 0 && t < len) v.x = row[t];
-                    if (t + 1 >= 0 && t + 1 < len) v.y = row[t + 1];
-                    if (t + 2 >= 0 && t + 2 < len) v.z = row[t + 2];
-                    if (t + 3 >= 0 && t + 3 < len) v.w = row[t + 3];
-                }
-                *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = v;
+        // one float4 of LDS = four channels (8g + 2q + brow, q = 0..3) at one column: four row-coalesced global loads
+        for (int idx = tid; idx < (H / 4) * LDX; idx += NTH) {
+            const int gb = idx / LDX, col = idx - gb * LDX;  // gb = g * 2 + brow
+            const int c0 = (gb >> 1) * 8 + (gb & 1);
+            const int tt = ts + col;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (tt >= 0 && tt < len) {
+                const float* col_p = hb + tt;
+                v.x = col_p[(long)(c0 + 0) * a.h_ld];
+                v.y = col_p[(long)(c0 + 2) * a.h_ld];
+                v.z = col_p[(long)(c0 + 4) * a.h_ld];
+                v.w = col_p[(long)(c0 + 6) * a.h_ld];
             }
-        } else {
-            for (int idx = tid; idx < H * LDX; idx += NTH) {
-                const int r = idx / LDX, c = idx - r * LDX;
-                const int t = ts + c;
-                X[idx] = (t >= 0 && t < len) ? hb[(long)r * a.h_ld + t] : 0.0f;
-            }
+            reinterpret_cast<float4*>(X)[idx] = v;
         }
     }
     __syncthreads();
@@ -278,13 +317,14 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             }
             wp[m] = a.w_in + (long)q * a.K * CP * 64 + lane;
         }
-        if (!(a.ablate & 1)) wn_mfma<MT, CP>(acc, wp, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
+        if (!(a.ablate & 1))
+            wn_mfma_b4<MT, CP>(acc, wp, reinterpret_cast<const float4*>(X) + brow * LDX + toff + bcol, LDX, a.K, a.dil);
         if (two && MT * w < NTILE / 2) {  // the residual input of this wave's h' tiles, while the h tile is still there
             MI355_UNROLL
             for (int m = 0; m < MT; ++m)
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r)
-                    hres[m][r] = X[(32 * (MT * w + m) + (r & 3) + 8 * (r >> 2) + 4 * brow) * LDX + toff + pad + bcol];
+                    hres[m][r] = X[pk(32 * (MT * w + m) + (r & 3) + 8 * (r >> 2) + 4 * brow, toff + pad + bcol, LDX)];
         }
         __syncthreads();  // every wave is done with the h tile
         MI355_UNROLL
@@ -292,7 +332,10 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             const int q = MT * w + m;
             const int row0 = ((q & 1) ? H : 0) + 32 * (q >> 1);
             MI355_UNROLL
-            for (int r = 0; r < 16; ++r) X[(row0 + (r & 3) + 8 * (r >> 2) + 4 * brow) * 32 + bcol] = acc[m][r];
+            for (int r = 0; r < 16; ++r) {  // both halves in the packed layout of U, so the gate below works in place
+                const int cc = 32 * (q >> 1) + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                X[((q & 1) ? H * 32 : 0) + pk(cc, bcol, 32)] = acc[m][r];
+            }
         }
     }
     __syncthreads();
@@ -305,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     }
     __syncthreads();
     // ---- res/skip 1x1 conv: row tiles q < 6 -> h', q >= 6 -> skip (last layer: 6 tiles, all -> skip)
-    const float* U = X + brow * 32 + bcol;
+    const float4* U = reinterpret_cast<const float4*>(X) + brow * 32 + bcol;
     const bool live = t < len;
     auto finish = [&](const f32x16& acc, int q, const f32x16& hr) {
         if (t >= a.T || ((a.ablate & 4) && acc[0] != 1.2345f)) return;
@@ -330,7 +373,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             for (int r = 0; r < 16; ++r) acc[m][r] = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow];
             wp[m] = a.w_rs + (long)q * CP * 64 + lane;
         }
-        if (!(a.ablate & 1)) wn_mfma<MT, CP>(acc, wp, U, 32, 1, 0);
+        if (!(a.ablate & 1)) wn_mfma_b4<MT, CP>(acc, wp, U, 32, 1, 0);
         MI355_UNROLL
         for (int m = 0; m < MT; ++m) finish(acc[m], MT * w + m, hres[m]);
     } else if (NW == 12) {  // 6 tiles, one per wave
@@ -339,7 +382,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             const float* w1[1] = {a.w_rs + (long)w * CP * 64 + lane};
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) a1[0][r] = a.b_rs[32 * w + (r & 3) + 8 * (r >> 2) + 4 * brow];
-            if (!(a.ablate & 1)) wn_mfma<1, CP>(a1, w1, U, 32, 1, 0);
+            if (!(a.ablate & 1)) wn_mfma_b4<1, CP>(a1, w1, U, 32, 1, 0);
             finish(a1[0], w, hres[0]);
         }
     } else {  // 6 tiles: waves 0, 1 take two, waves 2, 3 one
@@ -356,11 +399,11 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
         }
         if (!(a.ablate & 1)) {
             if (nq == 2) {
-                wn_mfma<2, CP>(acc, wp, U, 32, 1, 0);
+                wn_mfma_b4<2, CP>(acc, wp, U, 32, 1, 0);
             } else {
                 f32x16 a1[1] = {acc[0]};
                 const float* w1[1] = {wp[0]};
-                wn_mfma<1, CP>(a1, w1, U, 32, 1, 0);
+                wn_mfma_b4<1, CP>(a1, w1, U, 32, 1, 0);
                 acc[0] = a1[0];
             }
         }

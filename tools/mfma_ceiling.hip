@@ -145,12 +145,75 @@ __global__ void kv(const float* __restrict__ w, float* __restrict__ out, int ste
     if (sum == 12345.678f) out[blockIdx.x * blockDim.x + tid] = sum;
 }
 
+// A fragments one dword per step through the 8-register ring (as in k), B fragments as one ds_read_b128 per four k-steps
+// (LDS tile packed [channel-pair group][column][4]), fetched one group ahead.
+template <int MT, int NT>
+__global__ void kb4(const float* __restrict__ w, float* __restrict__ out, int steps, int lds_floats, int wstride) {
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < lds_floats; i += blockDim.x) smem[i] = 0.001f * (i & 255);
+    __syncthreads();
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    const float* wp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wp[m] = w + (long)(wid * MT + m) * wstride + lane;
+    float ra[MT][8];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ra[m][u] = u < 4 ? wp[m][u * 64] : 0.25f;
+    const float4* xw = reinterpret_cast<const float4*>(smem) + (lane >> 5) * 44 + (lane & 31);
+    float4 bb[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { bb[0][n] = xw[n * 32]; bb[1][n] = bb[0][n]; }
+    const int ldmask = lds_floats / 8 - 1;
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float a[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = ra[m][u];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ra[m][(u + 4) & 7] = wp[m][(u + 4) * 64];
+            if ((u & 3) == 0) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bb[((u >> 2) + 1) & 1][n] = xw[(((s0 / 4 + (u >> 2) + 1) * 88) & ldmask) + n * 32];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 b4 = bb[(u >> 2) & 1][n];
+                    const float bv = (u & 3) == 0 ? b4.x : (u & 3) == 1 ? b4.y : (u & 3) == 2 ? b4.z : b4.w;
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv, acc[m][n], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wp[m] += 8 * 64;
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[m][n][r];
+    if (sum == 12345.678f) out[blockIdx.x * blockDim.x + tid] = sum;
+}
+
 template <int MT, int NT, int MODE>
 static void run(const char* name, int waves, int blocks_per_cu, int lds_bytes, const float* w, float* out, int wstride,
-                bool vec = false, int steps = 1152, int reps = 10) {
+                bool vec = false, int steps = 1152, int reps = 10, bool b4 = false) {
     const int cus = 256;
     const int grid = cus * blocks_per_cu;
-    auto kk = vec ? kv<MT, NT, MODE> : k<MT, NT, MODE>;
+    auto kk = b4 ? kb4<MT, NT> : (vec ? kv<MT, NT, MODE> : k<MT, NT, MODE>);
     CHECK(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -165,7 +228,7 @@ static void run(const char* name, int waves, int blocks_per_cu, int lds_bytes, c
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
     const double flops = (double)grid * waves * steps * MT * NT * 4096.0;
-    printf("%s%-34s MTxNT=%dx%d waves/blk=%d blk/CU=%d (%.1f waves/SIMD) lds=%3dKB  %7.3f ms  %6.1f TFLOP/s\n", vec ? "x4 " : "   ", name, MT, NT, waves,
+    printf("%s%-34s MTxNT=%dx%d waves/blk=%d blk/CU=%d (%.1f waves/SIMD) lds=%3dKB  %7.3f ms  %6.1f TFLOP/s\n", b4 ? "B4 " : (vec ? "x4 " : "   "), name, MT, NT, waves,
            blocks_per_cu, waves * blocks_per_cu / 4.0, lds_bytes / 1024, ms, flops / ms * 1e-9);
 }
 
@@ -179,6 +242,17 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&out, 1 << 26));
     CHECK(hipMemcpy(w, hw.data(), wn * 4, hipMemcpyHostToDevice));
     printf("nominal peak: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz = 157.3 TFLOP/s\n");
+    if (argc > 1 && argv[1][0] == 'b') {  // B-side 16-byte reads only
+        run<1, 3, 3>("mrf C=32 shape", 8, 1, 65536, w, out, wstride);
+        run<1, 3, 3>("mrf C=32 shape", 8, 1, 65536, w, out, wstride, false, 1152, 10, true);
+        run<2, 3, 3>("mrf C=64 shape", 8, 1, 65536, w, out, wstride);
+        run<2, 3, 3>("mrf C=64 shape", 8, 1, 65536, w, out, wstride, false, 1152, 10, true);
+        run<3, 1, 3>("wn_layer 4-wave shape", 4, 3, 49152, w, out, wstride);
+        run<3, 1, 3>("wn_layer 4-wave shape", 4, 3, 49152, w, out, wstride, false, 1152, 10, true);
+        run<2, 2, 3>("generic conv shape", 4, 3, 53248, w, out, wstride);
+        run<2, 2, 3>("generic conv shape", 4, 3, 53248, w, out, wstride, false, 1152, 10, true);
+        return 0;
+    }
     if (sustained) {  // ~0.3 s of back-to-back launches per line: what the clocks settle at
         printf("sustained (800 launches each)\n");
         run<2, 2, 0>("registers only", 4, 2, 1024, w, out, wstride, false, 1152, 800);
