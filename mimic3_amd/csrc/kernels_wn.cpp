@@ -280,20 +280,28 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     // LDS index of element (channel c, column col) of a tile with `ld` columns: see wn_mfma_b4
     auto pk = [](int c, int col, int ld) { return ((((c >> 3) * 2 + (c & 1)) * ld + col) << 2) + ((c >> 1) & 3); };
     if (!(a.ablate & 2)) {
-        // one float4 of LDS = four channels (8g + 2q + brow, q = 0..3) at one column: four row-coalesced global loads
-        for (int idx = tid; idx < (H / 4) * LDX; idx += NTH) {
-            const int gb = idx / LDX, col = idx - gb * LDX;  // gb = g * 2 + brow
+        // one float4 of LDS = four channels (8g + 2q + brow, q = 0..3) at one column.  A thread moves a 4 x 4 block: four
+        // 16-byte loads along time (one per channel), transposed in registers, four 16-byte LDS stores (one per column)
+        const int ld4 = LDX >> 2;
+        for (int idx = tid; idx < (H / 4) * ld4; idx += NTH) {
+            const int gb = idx / ld4, c4 = idx - gb * ld4;  // gb = g * 2 + brow
             const int c0 = (gb >> 1) * 8 + (gb & 1);
-            const int tt = ts + col;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (tt >= 0 && tt < len) {
-                const float* col_p = hb + tt;
-                v.x = col_p[(long)(c0 + 0) * a.h_ld];
-                v.y = col_p[(long)(c0 + 2) * a.h_ld];
-                v.z = col_p[(long)(c0 + 4) * a.h_ld];
-                v.w = col_p[(long)(c0 + 6) * a.h_ld];
+            const int tt = ts + 4 * c4;
+            float v[4][4];
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                const float* row = hb + (long)(c0 + 2 * q) * a.h_ld;
+                if (a.vec && tt >= 0 && tt + 3 < len) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(row + tt);
+                    v[q][0] = r4.x; v[q][1] = r4.y; v[q][2] = r4.z; v[q][3] = r4.w;
+                } else {
+                    MI355_UNROLL
+                    for (int j = 0; j < 4; ++j) v[q][j] = (tt + j >= 0 && tt + j < len) ? row[tt + j] : 0.0f;
+                }
             }
-            reinterpret_cast<float4*>(X)[idx] = v;
+            MI355_UNROLL
+            for (int j = 0; j < 4; ++j)
+                reinterpret_cast<float4*>(X)[gb * LDX + 4 * c4 + j] = make_float4(v[0][j], v[1][j], v[2][j], v[3][j]);
         }
     }
     __syncthreads();
