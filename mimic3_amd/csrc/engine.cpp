@@ -205,6 +205,14 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
         std::vector<float> pk(mfma_packed_floats(Cout, Cin, K), 0.0f);
         pack_conv_weights_mfma_mode(w.data(), Cout, Cin, K, epi == EPI_GATE ? EPI_GATE : EPI_STD, pk.data());
         c.packed = stage(pk.data(), pk.size());
+        if (key.rfind("dec.rb.", 0) == 0 && epi == EPI_STD && Cin % 8 == 0 && Cout % 32 == 0) {
+            // fused MRF stage: a lane's A fragments of four consecutive channel pairs side by side
+            std::vector<float> p4(pk.size());
+            const size_t recs = pk.size() / 64;  // (tile, tap, pair) records, pairs fastest
+            for (size_t r = 0; r < recs; ++r)
+                for (int l = 0; l < 64; ++l) p4[((r >> 2) * 64 + l) * 4 + (r & 3)] = pk[r * 64 + l];
+            c.packed4 = stage(p4.data(), p4.size());
+        }
     }
     return convs_[key] = c;
 }
@@ -823,12 +831,12 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.d1[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 0];
                     m.d2[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 1];
                 }
-                if (mrf_fused_supported(ch, nk, m.k, m.d1, m.d2)) {
+                if (mrf_fused_supported(ch, nk, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF) {
                     double flops = 0;
                     for (int j = 0; j < nk; ++j) {
                         for (int q = 0; q < 2; ++q) {
                             const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
-                            m.w[j][q] = P(w.packed);
+                            m.w[j][q] = P(w.packed4);
                             m.bias[j][q] = P(w.bias);
                         }
                         flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];

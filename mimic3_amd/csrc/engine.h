@@ -90,6 +90,7 @@ constexpr size_t NO_OFF = ~size_t(0);
 struct ConvW {
     size_t raw = NO_OFF;     // [Cout,Cin,K]
     size_t packed = NO_OFF;  // MFMA fragment order (absent when Cin is odd)
+    size_t packed4 = NO_OFF; // same records regrouped [tile][tap][4 pairs][lane][4] for 16-byte A loads (fused MRF stage)
     size_t bias = NO_OFF;
     int Cout = 0, Cin = 0, K = 1;
     int epi = EPI_STD;  // tile map the packed copy was built for

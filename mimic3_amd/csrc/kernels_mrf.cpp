@@ -29,48 +29,77 @@ namespace m355 {
 //     base plus a compile-time multiple of the row pitch (no per-step index arithmetic);
 //   * A fragments: 8-register ring, four steps ahead (L2 latency); B fragments: two statically indexed buffers,
 //     one step ahead — no register copies anywhere in the loop.
+// LDS index of element (channel c, column col) of a tile with `ld` columns: four channels of the same MFMA half
+// (c = 8g + 2q + brow, q = 0..3) sit side by side, so a lane's B fragments of four consecutive k-steps are ONE
+// ds_read_b128.  The A fragments are packed the same way ([tile][tap][group of 4 pairs][lane][4]): one
+// global_load_dwordx4 per four k-steps.  16-byte operand fetches are worth 5-9 % of the loop for these tile shapes
+// (tools/mfma_ceiling.hip, "x4" rows).
+__device__ __forceinline__ int pk(int c, int col, int ld) { return ((((c >> 3) * 2 + (c & 1)) * ld + col) << 2) + ((c >> 1) & 3); }
+
+__device__ __forceinline__ float f4c(const float4& v, int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
+
 template <int NTL, int NA, int CP>
-__device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float* __restrict__ wp, const float* __restrict__ xw,
+__device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float4* __restrict__ wp4, const float4* __restrict__ x4,
                                                 int tstride, int LD, int K, int dil, int ablate) {
     static_assert(NTL <= NA, "tile count");
-    static_assert(CP % 8 == 0, "channel pairs per tap must be a multiple of 8");
+    static_assert(CP % 16 == 0, "channel pairs per tap must be a multiple of 16");
     if (ablate & 1) return;
-    const int ld2 = 2 * LD;
-    float a_ring[8];
+    constexpr int NG = CP / 4;  // groups of four channel pairs per tap
+    // A: ring of four 16-byte registers, two groups (8 k-steps) ahead; B: two buffers, one group ahead
+    float4 ra[4];
+    ra[0] = wp4[0];
+    ra[1] = wp4[64];
+    float4 bb[2][NTL];
     MI355_UNROLL
-    for (int u = 0; u < 4; ++u) a_ring[u] = wp[u * 64];
-    float bb[2][NTL];
-    MI355_UNROLL
-    for (int i = 0; i < NTL; ++i) bb[0][i] = xw[i * tstride];
-    const float* wg = wp;
+    for (int i = 0; i < NTL; ++i) bb[0][i] = x4[i * tstride];
     for (int k = 0; k < K; ++k) {
-        // all CP / 8 groups of a tap unrolled: hipcc drains the vector-memory counter at every loop header it cannot
-        // see through, so the ring only keeps its distance inside straight-line code
+        const float4* wk = wp4 + (long)k * NG * 64;
+        const float4* xk = x4 + k * dil;
+        const bool last_tap = k == K - 1;
+        // all groups of a tap unrolled (hipcc drains the vector-memory counter at loop headers it cannot see through);
+        // every load is unconditional — at the very end the prefetches read the last group again
         MI355_UNROLL
-        for (int cp0 = 0; cp0 < CP; cp0 += 8) {
-            const float* base = xw + k * dil + cp0 * ld2;
-            const bool last = (k == K - 1) && (cp0 + 8 == CP);
-            // the very last group prefetches harmlessly from itself, so every load in the body is unconditional and the
-            // compiler's s_waitcnt counts stay exact (conditional loads make it drain the ring)
-            const float* nbase = last ? base : ((cp0 + 8 < CP) ? base + 8 * ld2 : xw + (k + 1) * dil);
-            const float* wg_hi = last ? wg - 8 * 64 : wg;
+        for (int g = 0; g < NG; ++g) {
+            const float4* wa = (last_tap && g + 2 >= NG) ? wk + (NG - 1) * 64 : wk + (g + 2) * 64;
+            ra[(g + 2) & 3] = *wa;
+            const float4* xb = (g + 1 < NG) ? xk + (g + 1) * 2 * LD : (last_tap ? xk + g * 2 * LD : xk + dil);
             MI355_UNROLL
-            for (int u = 0; u < 8; ++u) {
-                const float av = a_ring[u];
-                a_ring[(u + 4) & 7] = (u < 4) ? wg[(u + 4) * 64] : wg_hi[(u + 4) * 64];
-                if (u < 7) {
-                    MI355_UNROLL
-                    for (int i = 0; i < NTL; ++i) bb[(u + 1) & 1][i] = base[(u + 1) * ld2 + i * tstride];
-                } else {
-                    MI355_UNROLL
-                    for (int i = 0; i < NTL; ++i) bb[0][i] = nbase[i * tstride];
-                }
+            for (int i = 0; i < NTL; ++i) bb[(g + 1) & 1][i] = xb[i * tstride];
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) {
                 MI355_UNROLL
-                for (int i = 0; i < NTL; ++i) acc[i] = MFMA_32x32x2_F32(av, bb[u & 1][i], acc[i]);
-                SCHED_FENCE();
+                for (int i = 0; i < NTL; ++i) acc[i] = MFMA_32x32x2_F32(f4c(ra[g & 3], q), f4c(bb[g & 1][i], q), acc[i]);
             }
-            wg += 8 * 64;
+            SCHED_FENCE();
         }
+    }
+}
+
+// global [rows][x_ld] -> packed LDS tile (see pk): a thread moves a 4 x 4 block — four 16-byte loads along time (channels
+// 8g + 2q + brow), leaky-relu, register transpose, four 16-byte LDS stores (one per column).  512 threads.
+__device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
+                                              float slope, float* __restrict__ dst, int vec) {
+    const int ld4 = LD >> 2;
+    for (int idx = threadIdx.x; idx < (rows >> 2) * ld4; idx += 512) {
+        const int gb = idx / ld4, c4 = idx - gb * ld4;  // gb = g * 2 + brow
+        const int c0 = (gb >> 1) * 8 + (gb & 1);
+        const int tt = ts + 4 * c4;
+        float v[4][4];
+        MI355_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            const float* row = xb + (long)(c0 + 2 * q) * x_ld;
+            if (vec && tt >= 0 && tt + 3 < tend) {
+                const float4 r4 = *reinterpret_cast<const float4*>(row + tt);
+                v[q][0] = r4.x; v[q][1] = r4.y; v[q][2] = r4.z; v[q][3] = r4.w;
+            } else {
+                MI355_UNROLL
+                for (int j = 0; j < 4; ++j) v[q][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
+            }
+        }
+        MI355_UNROLL
+        for (int j = 0; j < 4; ++j)
+            reinterpret_cast<float4*>(dst)[gb * LD + 4 * c4 + j] =
+                make_float4(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope));
     }
 }
 
@@ -80,7 +109,7 @@ __device__ __forceinline__ float unlrelu(float v) { return v >= 0.0f ? v : v * 1
 // conv1 of a resblock, MFMA part, for a wave that owns NTL column tiles q = wt + WT*i of the extended range:
 // acc = x + bias + conv(lrelu(x)).  Reads only the X tile, so it may run before the barrier that releases X1.
 template <int NTL, int NA, int CP, int WT>
-__device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float* __restrict__ wp, const float* bs /*LDS*/,
+__device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float4* __restrict__ wp, const float* bs /*LDS*/,
                                                   const float* X, int LDX, int R, int r1, int r2, int K, int d1, int wm,
                                                   int wt, int brow, int bcol, int ablate) {
     MI355_UNROLL
@@ -89,17 +118,17 @@ __device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            acc[i][r] = unlrelu(X[co * LDX + (R - r2) + e]) + bs[co];
+            acc[i][r] = unlrelu(X[pk(co, (R - r2) + e, LDX)]) + bs[co];
         }
     }
-    const float* xw = X + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
+    const float4* xw = reinterpret_cast<const float4*>(X) + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
     mfma_conv_tiles<NTL, NA, CP>(acc, wp, xw, WT * 32, LDX, K, d1, ablate);
 }
 
 // conv2 for a wave that owns NTL output tiles p = wt + WT*i:  out += x1 + bias + conv(lrelu(x1)), accumulated
 // straight into the wave's persistent output registers (no epilogue).
 template <int NTL, int NA, int CP, int WT>
-__device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __restrict__ wp, const float* bs /*LDS*/,
+__device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float4* __restrict__ wp, const float* bs /*LDS*/,
                                           const float* X1, int LD1, int r2, int K, int d2, int wm, int wt, int brow, int bcol, int ablate) {
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
@@ -107,10 +136,10 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            out[i][r] += unlrelu(X1[co * LD1 + c0 + r2]) + bs[co];
+            out[i][r] += unlrelu(X1[pk(co, c0 + r2, LD1)]) + bs[co];
         }
     }
-    const float* xw = X1 + brow * LD1 + bcol + wt * 32;
+    const float4* xw = reinterpret_cast<const float4*>(X1) + brow * LD1 + bcol + wt * 32;
     mfma_conv_tiles<NTL, NA, CP>(out, wp, xw, WT * 32, LD1, K, d2, ablate);
 }
 
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
         BS[i] = a.bias[j][q][c];
     }
-    if (!(a.ablate & 2)) stage_tile<8, 3>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec);
+    if (!(a.ablate & 2)) stage_tile_pk(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec);
     __syncthreads();
 
     f32x16 out[NT2MAX];
@@ -163,7 +192,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * a.d2[j];
         const int n1 = (T_B + 2 * r2 + 31) / 32;  // conv1 column tiles: extended column e <-> t = t0 - r2 + e
         nt1 = n1 > wt ? (n1 - wt + WT - 1) / WT : 0;
-        const float* wp = a.w[j][0] + (long)wm * K * CP * 64 + lane;
+        const float4* wp = reinterpret_cast<const float4*>(a.w[j][0] + (long)wm * K * CP * 64) + lane;
         const float* bs = BS + (j * 2 + 0) * C;
         if (nt1 >= 3) mrf_conv1_compute<3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
         else if (nt1 == 2) mrf_conv1_compute<2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
@@ -185,14 +214,14 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                    X1[co * LD1 + e] = live ? fmaxf(acc1[i][r], 0.1f * acc1[i][r]) : 0.0f;
+                    X1[pk(co, e, LD1)] = live ? fmaxf(acc1[i][r], 0.1f * acc1[i][r]) : 0.0f;
                 }
             }
         }
         __syncthreads();
         // ---- conv2 into the output registers, then straight on to the next resblock's conv1
         {
-            const float* wp = a.w[j][1] + (long)wm * K * CP * 64 + lane;
+            const float4* wp = reinterpret_cast<const float4*>(a.w[j][1] + (long)wm * K * CP * 64) + lane;
             const float* bs = BS + (j * 2 + 1) * C;
             if (nt2 >= 2) mrf_conv2<2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
             else if (nt2 == 1) mrf_conv2<1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);

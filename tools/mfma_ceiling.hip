@@ -14,7 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int MT, int NT, int MODE>
-__global__ void k(const float* __restrict__ w, float* __restrict__ out, int steps, int lds_floats, int wstride) {
+__global__ __launch_bounds__(512) void k(const float* __restrict__ w, float* __restrict__ out, int steps, int lds_floats, int wstride) {
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < lds_floats; i += blockDim.x) smem[i] = 0.001f * (i & 255);
@@ -80,7 +80,7 @@ __global__ void k(const float* __restrict__ w, float* __restrict__ out, int step
 // Same loop with 16-byte operand fetches: one global_load_dwordx4 / ds_read_b128 brings the fragments of four
 // consecutive k-steps (weights packed [k-step group][lane][4], LDS tile packed [channel-pair group][column][4]).
 template <int MT, int NT, int MODE>
-__global__ void kv(const float* __restrict__ w, float* __restrict__ out, int steps, int lds_floats, int wstride) {
+__global__ __launch_bounds__(512) void kv(const float* __restrict__ w, float* __restrict__ out, int steps, int lds_floats, int wstride) {
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < lds_floats; i += blockDim.x) smem[i] = 0.001f * (i & 255);
@@ -148,7 +148,7 @@ __global__ void kv(const float* __restrict__ w, float* __restrict__ out, int ste
 // A fragments one dword per step through the 8-register ring (as in k), B fragments as one ds_read_b128 per four k-steps
 // (LDS tile packed [channel-pair group][column][4]), fetched one group ahead.
 template <int MT, int NT>
-__global__ void kb4(const float* __restrict__ w, float* __restrict__ out, int steps, int lds_floats, int wstride) {
+__global__ __launch_bounds__(512) void kb4(const float* __restrict__ w, float* __restrict__ out, int steps, int lds_floats, int wstride) {
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < lds_floats; i += blockDim.x) smem[i] = 0.001f * (i & 255);
@@ -251,6 +251,12 @@ int main(int argc, char** argv) {
         run<3, 1, 3>("wn_layer 4-wave shape", 4, 3, 49152, w, out, wstride, false, 1152, 10, true);
         run<2, 2, 3>("generic conv shape", 4, 3, 53248, w, out, wstride);
         run<2, 2, 3>("generic conv shape", 4, 3, 53248, w, out, wstride, false, 1152, 10, true);
+        run<2, 4, 3>("2x4 tiles", 4, 2, 65536, w, out, wstride);
+        run<2, 4, 3>("2x4 tiles", 4, 2, 65536, w, out, wstride, false, 1152, 10, true);
+        run<4, 2, 3>("4x2 tiles", 4, 2, 65536, w, out, wstride);
+        run<4, 2, 3>("4x2 tiles", 4, 2, 65536, w, out, wstride, false, 1152, 10, true);
+        run<2, 4, 3>("2x4 tiles, 8 waves", 8, 1, 65536, w, out, wstride);
+        run<2, 4, 3>("2x4 tiles, 8 waves", 8, 1, 65536, w, out, wstride, false, 1152, 10, true);
         return 0;
     }
     if (sustained) {  // ~0.3 s of back-to-back launches per line: what the clocks settle at
