@@ -301,7 +301,8 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
         LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     };
     if (a.C == 32) {
-        go(k_mrf_fused<1, 8, 16, 3, 2>);  // immediates cost this variant registers (spills): pitches stay run-time
+        if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608>);
+        else go(k_mrf_fused<1, 8, 16, 3, 2>);
     } else {
         if (a.ldx == 320 && a.ld1 == 288) go(k_mrf_fused<2, 4, 6, 3, 2, 320, 288>);
         else go(k_mrf_fused<2, 4, 6, 3, 2>);
