@@ -208,9 +208,7 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
         if (key.rfind("dec.rb.", 0) == 0 && epi == EPI_STD && Cin % 8 == 0 && Cout % 32 == 0) {
             // fused MRF stage: a lane's A fragments of four consecutive channel pairs side by side
             std::vector<float> p4(pk.size());
-            const size_t recs = pk.size() / 64;  // (tile, tap, pair) records, pairs fastest
-            for (size_t r = 0; r < recs; ++r)
-                for (int l = 0; l < 64; ++l) p4[((r >> 2) * 64 + l) * 4 + (r & 3)] = pk[r * 64 + l];
+            regroup_packed_x4(pk.data(), pk.size(), p4.data());
             c.packed4 = stage(p4.data(), p4.size());
         }
     }

@@ -149,6 +149,42 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ xb, long x_
     }
 }
 
+// ---- packed LDS tiles for 16-byte MFMA operand fetches -----------------------------------------------------------
+// Element (channel c, column col) of a tile with `ld` columns sits at pk(c, col, ld): the four channels 8g + 2q + brow
+// (q = 0..3) of one MFMA half are side by side, so a lane's B fragments of four consecutive k-steps are one
+// ds_read_b128 at float4 index (2g + brow) * ld + col.
+__device__ __forceinline__ int pk(int c, int col, int ld) { return ((((c >> 3) * 2 + (c & 1)) * ld + col) << 2) + ((c >> 1) & 3); }
+__device__ __forceinline__ float f4c(const float4& v, int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
+
+// global [rows][x_ld] -> packed LDS tile: a thread moves a 4 x 4 block — four 16-byte loads along time (channels
+// 8g + 2q + brow), leaky-relu, register transpose, four 16-byte LDS stores (one per column).  rows % 8 == 0, LD % 4 == 0.
+template <int NTH>
+__device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
+                                              float slope, float* __restrict__ dst, int vec) {
+    const int ld4 = LD >> 2;
+    for (int idx = threadIdx.x; idx < (rows >> 2) * ld4; idx += NTH) {
+        const int gb = idx / ld4, c4 = idx - gb * ld4;  // gb = g * 2 + brow
+        const int c0 = (gb >> 1) * 8 + (gb & 1);
+        const int tt = ts + 4 * c4;
+        float v[4][4];
+        MI355_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            const float* row = xb + (long)(c0 + 2 * q) * x_ld;
+            if (vec && tt >= 0 && tt + 3 < tend) {
+                const float4 r4 = *reinterpret_cast<const float4*>(row + tt);
+                v[q][0] = r4.x; v[q][1] = r4.y; v[q][2] = r4.z; v[q][3] = r4.w;
+            } else {
+                MI355_UNROLL
+                for (int j = 0; j < 4; ++j) v[q][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
+            }
+        }
+        MI355_UNROLL
+        for (int j = 0; j < 4; ++j)
+            reinterpret_cast<float4*>(dst)[gb * LD + 4 * c4 + j] =
+                make_float4(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope));
+    }
+}
+
 __device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
                                                float slope, float* __restrict__ dst, int vec) {
     stage_tile<4, 1>(xb, x_ld, rows, LD, ts, tend, slope, dst, vec);

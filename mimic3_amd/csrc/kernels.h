@@ -50,6 +50,7 @@ bool conv1d_mfma_supported(int Cin, int Cout, int K, int dil);
 // Host-side weight repack for the MFMA kernel: [Cout,Cin,K] -> [ceil(Cout/32)][K][Cin/2][64].
 size_t mfma_packed_floats(int Cout, int Cin, int K);
 void pack_conv_weights_mfma(const float* w, int Cout, int Cin, int K, float* out);
+void regroup_packed_x4(const float* packed, size_t n_floats, float* out);  // fused MRF stage weights (Cin % 8 == 0)
 // epi = EPI_GATE packs rows as (c, H + c) tile pairs (H = Cout / 2); otherwise identical to the above.
 void pack_conv_weights_mfma_mode(const float* w, int Cout, int Cin, int K, int epi, float* out);
 

@@ -277,6 +277,13 @@ void pack_conv_weights_mfma_mode(const float* w, int Cout, int Cin, int K, int e
                     out[(((size_t)tile * K + k) * cp_n + cp) * 64 + l] = co >= 0 ? w[((size_t)co * Cin + ci) * K + k] : 0.0f;
                 }
 }
+// regroup packed records (pairs fastest) so that a lane's fragments of four consecutive channel pairs are contiguous:
+// [tile][tap][group of 4 pairs][lane][4] (16-byte A loads of the fused MRF stage).  Needs Cin % 8 == 0.
+void regroup_packed_x4(const float* packed, size_t n_floats, float* out) {
+    const size_t recs = n_floats / 64;
+    for (size_t r = 0; r < recs; ++r)
+        for (int l = 0; l < 64; ++l) out[((r >> 2) * 64 + l) * 4 + (r & 3)] = packed[r * 64 + l];
+}
 void pack_conv_weights_mfma(const float* w, int Cout, int Cin, int K, float* out) {
     pack_conv_weights_mfma_mode(w, Cout, Cin, K, EPI_STD, out);
 }

@@ -34,9 +34,7 @@ namespace m355 {
 // ds_read_b128.  The A fragments are packed the same way ([tile][tap][group of 4 pairs][lane][4]): one
 // global_load_dwordx4 per four k-steps.  16-byte operand fetches are worth 5-9 % of the loop for these tile shapes
 // (tools/mfma_ceiling.hip, "x4" rows).
-__device__ __forceinline__ int pk(int c, int col, int ld) { return ((((c >> 3) * 2 + (c & 1)) * ld + col) << 2) + ((c >> 1) & 3); }
-
-__device__ __forceinline__ float f4c(const float4& v, int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
+// (pk, f4c, stage_tile_pk: hipx.h)
 
 template <int NTL, int NA, int CP>
 __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float4* __restrict__ wp4, const float4* __restrict__ x4,
@@ -72,34 +70,6 @@ __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float4*
             }
             SCHED_FENCE();
         }
-    }
-}
-
-// global [rows][x_ld] -> packed LDS tile (see pk): a thread moves a 4 x 4 block — four 16-byte loads along time (channels
-// 8g + 2q + brow), leaky-relu, register transpose, four 16-byte LDS stores (one per column).  512 threads.
-__device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
-                                              float slope, float* __restrict__ dst, int vec) {
-    const int ld4 = LD >> 2;
-    for (int idx = threadIdx.x; idx < (rows >> 2) * ld4; idx += 512) {
-        const int gb = idx / ld4, c4 = idx - gb * ld4;  // gb = g * 2 + brow
-        const int c0 = (gb >> 1) * 8 + (gb & 1);
-        const int tt = ts + 4 * c4;
-        float v[4][4];
-        MI355_UNROLL
-        for (int q = 0; q < 4; ++q) {
-            const float* row = xb + (long)(c0 + 2 * q) * x_ld;
-            if (vec && tt >= 0 && tt + 3 < tend) {
-                const float4 r4 = *reinterpret_cast<const float4*>(row + tt);
-                v[q][0] = r4.x; v[q][1] = r4.y; v[q][2] = r4.z; v[q][3] = r4.w;
-            } else {
-                MI355_UNROLL
-                for (int j = 0; j < 4; ++j) v[q][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
-            }
-        }
-        MI355_UNROLL
-        for (int j = 0; j < 4; ++j)
-            reinterpret_cast<float4*>(dst)[gb * LD + 4 * c4 + j] =
-                make_float4(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope));
     }
 }
 
@@ -175,7 +145,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
         BS[i] = a.bias[j][q][c];
     }
-    if (!(a.ablate & 2)) stage_tile_pk(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec);
+    if (!(a.ablate & 2)) stage_tile_pk<512>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec);
     __syncthreads();
 
     f32x16 out[NT2MAX];

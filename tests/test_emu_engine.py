@@ -25,6 +25,7 @@ CONV_CASES = [
     (2, 64, 29, 33, 1, 1),
     (1, 96, 96, 64, 5, 1),
     (2, 384, 40, 45, 3, 1),  # deep + short: split-K kernel (encoder FFN conv_2 shape class)
+    (1, 128, 64, 200, 5, 2),  # 64-channel chunks: packed LDS tile, 16-byte operand fetches
 ]
 
 
