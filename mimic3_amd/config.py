@@ -133,11 +133,11 @@ class VitsConfig:
         )
 
     @staticmethod
-    def tiny_wide(n_speakers: int = 1) -> "VitsConfig":
+    def tiny_wide(n_speakers: int = 1, initial_channel: int = 128) -> "VitsConfig":
         """Tiny encoder/flow with the *real* decoder widths of the last two stages (64 -> 32 channels, ResBlock2
         k = 3/5/7, dilations (1,2)/(2,6)/(3,12)) so that the fused multi-receptive-field kernel is exercised."""
         c = VitsConfig.tiny(n_speakers=n_speakers)
-        c.upsample_initial_channel = 128
+        c.upsample_initial_channel = initial_channel  # 256: stages of 128 and 64 channels, like the first two real ones
         c.resblock_kernel_sizes = (3, 5, 7)
         c.resblock_dilation_sizes = ((1, 2), (2, 6), (3, 12))
         return c

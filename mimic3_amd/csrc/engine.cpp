@@ -818,7 +818,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         const long sbs = (long)ch * T;
         const int* slen = d_slen_ + (long)(i + 1) * B;  // rows end at their own length (batched == unbatched)
         tap(S("dec.ups.%d", i).c_str(), d_bufA_, {B, ch, T});
-        bool fused = false;
+        int n_fused = 0;  // resblocks 0 .. n_fused-1 of this stage run in the fused kernel, the rest conv by conv
         if (!force_generic_ && !no_fused_mrf_ && c.resblock == 2 && nk <= MRF_MAX_RB) {
             MrfArgs m;
             bool two = true;
@@ -829,9 +829,12 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.d1[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 0];
                     m.d2[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 1];
                 }
-                if (mrf_fused_supported(ch, nk, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF) {
+                // the longest prefix of resblocks whose tiles fit LDS together (128 channels: only the narrow ones)
+                int p = nk;
+                while (p > 0 && !(mrf_fused_supported(ch, p, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF)) --p;
+                if (p > 0) {
                     double flops = 0;
-                    for (int j = 0; j < nk; ++j) {
+                    for (int j = 0; j < p; ++j) {
                         for (int q = 0; q < 2; ++q) {
                             const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
                             m.w[j][q] = P(w.packed4);
@@ -839,19 +842,19 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                         }
                         flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];
                     }
-                    m.nrb = nk;
+                    m.nrb = p;
+                    if (p < nk) m.out_scale = 1.0f / nk;
                     m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
                     m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
-                    ProfScope ps(prof_, i == 1 ? "dec.mrf_fused.s1" : (i == 2 ? "dec.mrf_fused.s2" : "dec.mrf_fused"), flops,
+                    ProfScope ps(prof_, i == 1 ? "dec.mrf_fused.s1" : (i == 2 ? "dec.mrf_fused.s2" : (i == 0 ? "dec.mrf_fused.s0" : "dec.mrf_fused")), flops,
                                  8.0 * B * (double)T * ch);
                     launch_mrf_fused(m, stream_);
-                    fused = true;
+                    n_fused = p;
                 }
             }
         }
-        if (!fused)
-        for (int j = 0; j < nk; ++j) {
+        for (int j = n_fused; j < nk; ++j) {
             const int n = i * nk + j;
             const int nd = c.resblock_n_dilations[j];
             const float* src = d_bufA_;

@@ -86,6 +86,8 @@ struct MrfArgs {
     const int* len = nullptr;  // [B] rows end at their own length
     int B = 1, C = 0, T = 0;
     int R = 0, ldx = 0, ld1 = 0, vec = 0;  // filled by the launcher (R = staging halo, rounded up to 4)
+    float out_scale = 0.0f;  // 0: y = mean of the nrb resblocks; > 0: y = out_scale * sum (a stage fused only in part:
+                             // the remaining resblocks are accumulated onto y by the conv-by-conv path)
     int ablate = 0;  // profiling only (MI355VITS_MRF_ABLATE): 1 = skip MFMA loops, 2 = skip staging, 4 = skip output
 };
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);

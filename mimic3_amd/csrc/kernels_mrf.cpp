@@ -133,8 +133,8 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     float* BS = X1 + C * LD1;      // [nrb][2][C] biases
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
     // waves w and w+4 share a SIMD: give them complementary tile counts (wt < WT/2 gets the extra tile)
-    const int wm = (WM == 1) ? 0 : ((wid >> 1) & 1);
-    const int wt = (WM == 1) ? wid : ((wid >> 2) * 2 + (wid & 1));
+    const int wm = (WM == 1) ? 0 : (WM == 2 ? ((wid >> 1) & 1) : (((wid & 3) >> 1) + 2 * (wid >> 2)));
+    const int wt = (WM == 1) ? wid : (WM == 2 ? ((wid >> 2) * 2 + (wid & 1)) : ((wid & 1) ^ (wid >> 2)));
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * T_B;
@@ -207,18 +207,20 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = out[i][r] / n;
+                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = a.out_scale > 0.0f ? out[i][r] * a.out_scale : out[i][r] / n;
             }
         }
     }
 }
 
 namespace {
-// geometry per channel count:  C = 32: 1 x 8 waves, T_B = 512 (16 tiles, 2 per wave);  C = 64: 2 x 4 waves, T_B = 192
+// geometry per channel count:  C = 32: 1 x 8 waves, T_B = 512 (16 tiles, 2 per wave);  C = 64: 2 x 4 waves, T_B = 192;
+// C = 128: 4 x 2 waves, T_B = 96
 struct Geo { int C, T_B, WT, NT1MAX; };
 inline bool geometry(int C, Geo* g) {
     if (C == 32) { *g = {32, 512, 8, 3}; return true; }
     if (C == 64) { *g = {64, 192, 4, 3}; return true; }
+    if (C == 128) { *g = {128, 96, 2, 3}; return true; }  // fits only the narrow resblocks (halo <= 16): see the engine
     return false;
 }
 constexpr size_t LDS_LIMIT = 160 * 1024;
@@ -273,6 +275,9 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     if (a.C == 32) {
         if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608>);
         else go(k_mrf_fused<1, 8, 16, 3, 2>);
+    } else if (a.C == 128) {
+        if (a.ldx == 160 && a.ld1 == 128) go(k_mrf_fused<4, 2, 3, 3, 2, 160, 128>);
+        else go(k_mrf_fused<4, 2, 3, 3, 2>);
     } else {
         if (a.ldx == 320 && a.ld1 == 288) go(k_mrf_fused<2, 4, 6, 3, 2, 320, 288>);
         else go(k_mrf_fused<2, 4, 6, 3, 2>);

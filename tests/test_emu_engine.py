@@ -131,6 +131,24 @@ def test_fused_mrf_stage_kernel(emu_lib):
         assert rel_rms(fused_audio[b, :L], plain_audio[b, :L]) < 1e-5
 
 
+def test_partly_fused_mrf_stage_with_128_channels(emu_lib):
+    """First decoder stage of the real voices (128 channels): the two narrow resblocks (k = 3, 5) run in the fused
+    kernel (4 x 2 waves, 96-column tiles), the wide one (k = 7, halo 45) conv by conv, accumulated onto the same output."""
+    import os
+
+    cfg = VitsConfig.tiny_wide(initial_channel=256)
+    w = W.synthetic_weights(cfg, seed=33, frames_per_id=3.0)
+    out, _ = check_parity(emu_lib, cfg, B=2, Tx=13, seed=33, weights=w)
+    os.environ["MI355VITS_NO_FUSED_MRF"] = "1"
+    try:
+        out2, _ = check_parity(emu_lib, cfg, B=2, Tx=13, seed=33, weights=w)
+    finally:
+        del os.environ["MI355VITS_NO_FUSED_MRF"]
+    for b in range(2):
+        L = int(out["lengths"][b])
+        assert rel_rms(out["audio"][b, :L], out2["audio"][b, :L]) < 1e-5
+
+
 @pytest.mark.parametrize("B,Tx", [(2, 70), (1, 150)])
 def test_attention_across_key_and_query_tiles(emu_lib, B, Tx):
     """Phoneme sequences longer than one 32-wide MFMA tile (and than 128: 8 key tiles in registers)."""
