@@ -152,8 +152,16 @@ def _tensor(buf) -> Tuple[str, Optional[np.ndarray]]:
     if dtype not in _DTYPES:
         raise OnnxImportError(f"tensor {name!r}: unsupported data_type {dtype}")
     dt = np.dtype(_DTYPES[dtype])
-    count = int(np.prod(dims)) if dims else 1
+    if any(d < 0 for d in dims):
+        raise OnnxImportError(f"tensor {name!r}: negative dimension in {dims}")
+    count = 1
+    for d in dims:
+        count *= d
+        if count > (1 << 40):
+            raise OnnxImportError(f"tensor {name!r}: implausible dims {dims}")
     if raw is not None:
+        if len(raw) != count * dt.itemsize:
+            raise OnnxImportError(f"tensor {name!r}: {len(raw)} bytes of raw_data for dims {dims} of {dt}")
         arr = np.frombuffer(raw, dtype=dt, count=count)
     elif floats:
         arr = np.frombuffer(b"".join(floats), dtype="<f4")
@@ -224,7 +232,17 @@ class OnnxModel:
 
 
 def parse_model(blob: bytes) -> OnnxModel:
-    """ModelProto bytes -> initialisers + nodes (graph order = execution order for torch exports)."""
+    """ModelProto bytes -> initialisers + nodes (graph order = execution order for torch exports).  Whatever is wrong
+    with the bytes, the only exception that leaves this function is OnnxImportError."""
+    try:
+        return _parse_model(blob)
+    except OnnxImportError:
+        raise
+    except (ValueError, IndexError, OverflowError, MemoryError, struct.error, TypeError) as e:  # incl. UnicodeDecodeError
+        raise OnnxImportError(f"not a valid ONNX protobuf: {type(e).__name__}: {e}") from None
+
+
+def _parse_model(blob: bytes) -> OnnxModel:
     view = memoryview(blob)
     graph = None
     producer = ""

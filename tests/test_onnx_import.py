@@ -211,3 +211,35 @@ def test_session_loads_the_onnx_file_directly(emu_lib, tmp_path, tiny_onnx):
     os.utime(d / "generator.m355", (1, 1))
     with pytest.raises(InvalidArgument, match="cannot load"):
         InferenceSession(str(d / "generator.onnx"), _library=emu_lib)
+
+
+# ------------------------------------------------------------------------------------------------ robustness
+def test_reader_never_raises_anything_but_import_errors_on_corrupted_files(tiny_onnx):
+    """Bit flips, truncations and random garbage: the reader either parses or raises OnnxImportError — never an
+    IndexError / struct.error / MemoryError escaping to the caller (who turns it into InvalidArgument)."""
+    _, _, blob = tiny_onnx
+    rng = np.random.default_rng(7)
+    head = bytearray(blob[:4096])
+    for trial in range(300):
+        b = bytearray(head)
+        mode = trial % 3
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif mode == 1:
+            b = b[: int(rng.integers(0, len(b)))]
+        else:
+            b = bytearray(rng.integers(0, 256, int(rng.integers(1, 512)), dtype=np.uint8).tobytes())
+        try:
+            m = OI.parse_model(bytes(b))
+            OI.map_tensors(m, VitsConfig.tiny())
+        except OI.OnnxImportError:
+            pass
+    # a flipped bit in the middle of the real file: still only OnnxImportError (or a clean parse of different numbers)
+    for _ in range(20):
+        b = bytearray(blob)
+        b[int(rng.integers(0, len(b)))] ^= 0x40
+        try:
+            OI.import_onnx_bytes(bytes(b))
+        except OI.OnnxImportError:
+            pass
