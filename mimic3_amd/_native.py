@@ -139,7 +139,7 @@ class NativeLibrary:
         return self.lib.mi355vits_version().decode()
 
     def create_error(self) -> str:
-        return (self.lib.mi355vits_last_error(None) or b"").decode()
+        return (self.lib.mi355vits_last_error(None) or b"").decode("utf-8", "replace")
 
     # ---- kernel unit-test hooks -------------------------------------------------------------
     def test_conv1d(self, x, w, bias=None, res=None, dilation=1, impl=1, in_len=None, out_len=None, in_slope=1.0,
@@ -234,7 +234,7 @@ class Engine:
 
     def _check(self, rc: int) -> None:
         if rc != 0:
-            raise NativeError(rc, (self.native.lib.mi355vits_last_error(self._h) or b"").decode())
+            raise NativeError(rc, (self.native.lib.mi355vits_last_error(self._h) or b"").decode("utf-8", "replace"))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -56,17 +56,25 @@ void WeightsFile::parse(const void* blob, size_t n) {
         r.pos += nl;
         const uint32_t nd = r.get<uint32_t>();
         if (nd > 8) throw EngineError(MI355VITS_ERR_FORMAT, "tensor rank too large");
-        for (uint32_t d = 0; d < nd; ++d) e.dims.push_back((int)r.get<uint32_t>());
+        for (uint32_t d = 0; d < nd; ++d) {
+            const uint32_t v = r.get<uint32_t>();
+            if (v > (1u << 28)) throw EngineError(MI355VITS_ERR_FORMAT, "implausible tensor dimension in " + e.name);
+            e.dims.push_back((int)v);
+        }
         e.off = r.get<uint64_t>();
         ents.push_back(std::move(e));
     }
     const uint64_t dbytes = r.get<uint64_t>();
     r.pos += (64 - r.pos % 64) % 64;
-    if (r.pos + dbytes > n) throw EngineError(MI355VITS_ERR_FORMAT, "weight container truncated (data section)");
+    if (r.pos > n || dbytes > n - r.pos) throw EngineError(MI355VITS_ERR_FORMAT, "weight container truncated (data section)");
     for (auto& e : ents) {
         size_t cnt = 1;
-        for (int d : e.dims) cnt *= (size_t)d;
-        if (e.off + cnt * 4 > dbytes) throw EngineError(MI355VITS_ERR_FORMAT, "tensor " + e.name + " out of bounds");
+        for (int d : e.dims) {
+            cnt *= (size_t)d;
+            if (cnt > (size_t(1) << 34)) throw EngineError(MI355VITS_ERR_FORMAT, "tensor " + e.name + " too large");
+        }
+        if ((e.off & 3) || e.off > dbytes || cnt * 4 > dbytes - e.off)
+            throw EngineError(MI355VITS_ERR_FORMAT, "tensor " + e.name + " out of bounds");
         HostTensor t;
         t.dims = e.dims;
         t.count = cnt;
@@ -276,6 +284,24 @@ static void validate_config(const mi355vits_config& c) {
     if (c.dp_n_flows < 2 || c.flow_n_flows < 1 || c.flow_wn_layers < 1) bad("flow depth");
     if (c.flow_wn_kernel % 2 == 0 || c.dp_kernel_size % 2 == 0) bad("flow / dp kernels must be odd");
     if (c.window_size < 0 || c.n_layers < 1 || c.kernel_size < 1) bad("encoder");
+    // plausibility caps: a corrupted header must not turn into absurd loops or allocations
+    if (c.num_symbols > (1 << 20) || c.n_speakers > (1 << 20) || c.hidden_channels > 8192 || c.inter_channels > 8192 ||
+        c.filter_channels < 1 || c.filter_channels > 32768 || c.upsample_initial_channel < 2 || c.upsample_initial_channel > 8192 ||
+        c.gin_channels < 0 || c.gin_channels > 8192)
+        bad("channel / symbol counts out of range");
+    if (c.n_layers > 64 || c.kernel_size > 63 || c.window_size > 15 || c.flow_n_flows > 32 || c.flow_wn_layers > 32 ||
+        c.flow_wn_kernel < 1 || c.flow_wn_kernel > 63 || c.flow_wn_dilation_rate < 1 || c.flow_wn_dilation_rate > 8 ||
+        c.dp_n_flows > 16 || c.dp_dds_layers < 1 || c.dp_dds_layers > 8 || c.dp_kernel_size < 1 || c.dp_kernel_size > 63 ||
+        !(c.dp_tail_bound > 0.0f) || c.hop_length > (1 << 16))
+        bad("depth / kernel sizes out of range");
+    for (int i = 0; i < c.n_upsamples; ++i)
+        if (c.upsample_rates[i] > 64 || c.upsample_kernel_sizes[i] > 256) bad("upsample stage out of range");
+    for (int j = 0; j < c.n_resblock_kernels; ++j) {
+        if (c.resblock_kernel_sizes[j] > 63) bad("resblock kernel size out of range");
+        for (int m = 0; m < c.resblock_n_dilations[j]; ++m)
+            if (c.resblock_dilations[j * MI355VITS_MAX_STAGES + m] < 1 || c.resblock_dilations[j * MI355VITS_MAX_STAGES + m] > 256)
+                bad("resblock dilation out of range");
+    }
 }
 
 Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device) {

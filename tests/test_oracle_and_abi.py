@@ -147,3 +147,17 @@ def test_plain_c_client_of_the_header(emu_lib, tmp_path):
     from tests.util import run_c_client
 
     run_c_client(emu_lib, tmp_path)
+
+
+def test_corrupted_containers_are_rejected_not_fatal(emu_lib):
+    """400 corrupted .m355 blobs (bit flips in header / config / tensor table, truncations, extreme field values, random
+    bytes behind the magic) through mi355vits_create_from_buffer: every one ends in an error code or a loadable voice.
+    Runs in a subprocess so that a crash would fail this test instead of killing pytest."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_container.py")], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-2000:])
+    assert "rejected" in p.stdout
