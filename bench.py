@@ -5,14 +5,19 @@ own timed region, mimic3_tts/voice.py:229-232).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --single-process        # one process, N devices (the unchanged mimic3-server's shape)
 
 A "step" is one pass of the hot path over one batch of synthetic phoneme ids.  Workload (weak scaling):
 every GPU synthesises ``--batch`` (default 32) independent utterances of 128 phoneme ids, durations forced
 to 6 frames/id -> 768 latent frames = 196,608 samples = 8.916 s per utterance (SURVEY.md §8d "unit S");
-8 GPUs x 32 = the batch-256 configuration of BASELINE.json.  Inputs are 1 KiB of ids per utterance; they
-and the int16 result stay in HBM inside the timed region (PCIe-inclusive numbers: DESIGN.md).
-Batch-1 latency / RTF on the reference's golden-utterance shape (180 ids -> 991 frames) is measured in
-the same run and reported under "latency_b1".
+8 GPUs x 32 = the batch-256 configuration of BASELINE.json.
+
+Timed region = what the reference times around ``run`` + int16: phoneme ids start in host memory (1 KiB per
+utterance), the int16 result ENDS in host memory (pinned buffers recycled by the library, D2H inside the
+region): ``value`` is host-to-host.  ``device_only`` in the JSON is the same loop with the int16 result left
+in HBM (compute-side number).  Batch-1 latency / RTF on the reference's golden-utterance shape (180 ids ->
+991 frames) is measured in the same run ("latency_b1"), and BASELINE.json configs[2] (en_US/vctk_low,
+32 x 128 ids, sid = b mod 109) as "vctk_low_b32" with its own roofline.
 
 The JSON line also carries
   "roofline"     — dominant kernel group, algorithmic FLOPs / launch time measured with HIP events on the
@@ -23,9 +28,11 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
+import itertools
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -43,71 +50,39 @@ def make_batch(B, Tx, base):
     return ids, np.full(B, Tx, np.int64)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
-    ap.add_argument("--tx", type=int, default=128)
-    ap.add_argument("--frames-per-id", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "3")),
-                    help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg (profiling runs: keeps per-kernel "
-                    "averages pure batch-32)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU-baseline sample")
-    args = ap.parse_args()
+class Workload:
+    """One voice on one or more devices: ``streams`` engine handles per device, steps dealt to them in turn."""
 
-    import torch
+    def __init__(self, cfg, weights, devices, streams, B, Tx, fpi, rank, world, multispeaker_sid=False):
+        from mimic3_amd import weights as W
+        from mimic3_amd._native import Engine
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback for the measured path")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # RCCL; used for the barrier and the max-over-ranks only
+        self.cfg, self.B, self.Tx, self.fpi, self.rank, self.world = cfg, B, Tx, fpi, rank, world
+        blob = W.pack(cfg, weights)
+        self.engines = [Engine(blob, device=d) for d in devices for _ in range(max(1, streams))]
+        self.n_devices = len(devices)
+        self.ids, self.lengths = make_batch(B, Tx, rank * B)
+        self.forced = np.full((B, Tx), fpi, np.int32)
+        self.scales = np.array([0.667, 1.0, 0.8], np.float32)
+        self.sid = (np.arange(B) % cfg.n_speakers).astype(np.int64) if multispeaker_sid else None
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    def step(self, i, e=None, device_only=False):
+        e = e or self.engines[0]
+        return e.run(self.ids, self.lengths, self.scales, self.sid, forced_durations=self.forced, seed=1,
+                     utterance_base=self.rank * self.B + i * self.world * self.B, want_float=False, want_pcm16=True,
+                     device_only=device_only)
 
-    from mimic3_amd import weights as W
-    from mimic3_amd._native import Engine
-    from mimic3_amd.config import VitsConfig
-
-    cfg = VitsConfig.apope_low()
-    weights = W.synthetic_weights(cfg, seed=1234)
-    blob = W.pack(cfg, weights)
-    eng = Engine(blob, device=local_rank)
-    engines = [eng] + [Engine(blob, device=local_rank) for _ in range(max(1, args.streams) - 1)]
-
-    B, Tx, fpi = args.batch, args.tx, args.frames_per_id
-    ids, lengths = make_batch(B, Tx, rank * B)
-    forced = np.full((B, Tx), fpi, np.int32)
-    scales = np.array([0.667, 1.0, 0.8], np.float32)
-
-    def step(i, e=None):
-        return (e or eng).run(ids, lengths, scales, forced_durations=forced, seed=1,
-                              utterance_base=rank * B + i * world * B, want_float=False, want_pcm16=True, device_only=True)
-
-    def run_steps(n):
-        """n steps; with --streams S > 1, S host threads each drive one engine handle (own HIP stream and workspace)
+    def run_steps(self, n, device_only=False):
+        """n steps; with S > 1 handles, S host threads each drive one engine handle (own HIP stream and workspace)
         and take step numbers from a shared counter, so the small-kernel front half of one batch overlaps the
-        matrix-core back half of another.  Every step is a complete, independent run()."""
+        matrix-core back half of another.  Every step is a complete, independent run() whose int16 result is in
+        host memory when it returns (unless device_only)."""
+        engines = self.engines
         if len(engines) == 1:
             last = None
             for i in range(n):
-                last = step(i)
+                last = self.step(i, device_only=device_only)
             return last
-        import itertools
-        import threading
-
         counter = itertools.count()
         outs = [None] * len(engines)
         errs = []
@@ -118,7 +93,7 @@ def main():
                     i = next(counter)
                     if i >= n:
                         return
-                    outs[k] = step(i, engines[k])
+                    outs[k] = self.step(i, engines[k], device_only)
             except Exception as ex:  # noqa: BLE001 - re-raised below
                 errs.append(ex)
 
@@ -129,32 +104,168 @@ def main():
             raise errs[0]
         return next((o for o in outs if o is not None), None)
 
+    def size_workspaces(self):
+        for e in self.engines:  # every handle sizes its workspace on first use: never inside the timed region
+            self.step(0, e)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+
+def kernel_table(eng, step, nsteps):
+    """Per-kernel HIP-event table of `nsteps` profiled steps on one handle."""
+    eng.profile_enable(True)
+    eng.profile_reset()
+    for i in range(nsteps):
+        step(i)
+    rep = eng.profile_report()
+    eng.profile_enable(False)
+    eng.profile_reset()
+    tot_ms = sum(v["ms"] for v in rep.values())
+    table = []
+    for name, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
+        sec = v["ms"] * 1e-3
+        table.append({
+            "kernel": name, "launches_per_step": v["calls"] // nsteps, "ms_per_step": v["ms"] / nsteps,
+            "share": v["ms"] / tot_ms if tot_ms else 0.0,
+            "tflops": v["flops"] / sec / 1e12 if sec > 0 else 0.0,
+            "gbs_algorithmic": v["bytes"] / sec / 1e9 if sec > 0 else 0.0,
+        })
+    return rep, table, tot_ms
+
+
+def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice):
+    dom = table[0]
+    drec = rep[dom["kernel"]]
+    dsec = drec["ms"] * 1e-3
+    traffic = _pmc_traffic(dom["kernel"], workload_key, voice)
+    return {
+        "kernel": dom["kernel"],
+        "bound": "mfma",
+        "achieved": drec["flops"] / dsec / 1e12,
+        "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
+        "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+        "traffic_detail": traffic,
+        "algorithmic_flops_per_launch": drec["flops"] / drec["calls"],
+        "algorithmic_bytes_per_launch": drec["bytes"] / drec["calls"],
+        "avg_launch_us": drec["ms"] * 1e3 / drec["calls"],
+        "launches": drec["calls"],
+        "hbm_algorithmic_gbs": drec["bytes"] / dsec / 1e9,
+        "hbm_frac": drec["bytes"] / dsec / 1e9 / PEAK_HBM_GBS,
+        "note": "fp32 Conv1d is compute-bound on MI355X (AI >= 24 FLOP/B vs ridge 19.7): peak = 157.3 TFLOP/s fp32 "
+                "matrix-core rate; hbm_* give the same launches against the 8 TB/s HBM roof as BASELINE asks; traffic = "
+                "rocprofv3 PMC passes of this workload committed under profiles/ (counters cannot be read in-process)",
+        "whole_step": {
+            "tflops": sum(v["flops"] for v in rep.values()) / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
+            "hbm_algorithmic_gbs": sum(v["bytes"] for v in rep.values()) / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
+            "kernel_ms_per_step": tot_ms / nsteps,
+        },
+    }
+
+
+def print_table(title, table):
+    print(title, file=sys.stderr)
+    for row in table:
+        print(f"  {row['kernel']:22s} {row['launches_per_step']:4d} launches  {row['ms_per_step']:9.3f} ms/step "
+              f"{100 * row['share']:5.1f}%  {row['tflops']:7.2f} TFLOP/s  {row['gbs_algorithmic']:8.1f} GB/s", file=sys.stderr)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of about 3 s)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--tx", type=int, default=128)
+    ap.add_argument("--frames-per-id", type=int, default=6)
+    ap.add_argument("--voice", choices=["apope_low", "vctk_low"], default="apope_low",
+                    help="headline voice (BASELINE metric: apope_low; vctk_low is measured as an extra leg either way)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "3")),
+                    help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus devices from this one process (threads), no torch.distributed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg (profiling runs: keeps per-kernel "
+                    "averages pure batch-32)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the device-only and vctk_low legs")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU-baseline sample")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    single = args.single_process and world == 1
+    if not single and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node "
+                         f"{args.gpus}, or pass --single-process")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback for the measured path")
+    if single and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--single-process --gpus {args.gpus}: only {torch.cuda.device_count()} devices visible")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL; used for the barrier and the max-over-ranks only
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from mimic3_amd import weights as W
+    from mimic3_amd.config import VitsConfig
+
+    voices = {"apope_low": VitsConfig.apope_low, "vctk_low": VitsConfig.vctk_low}
+    cfg = voices[args.voice]()
+    weights = W.synthetic_weights(cfg, seed=1234)
+    devices = list(range(args.gpus)) if single else [local_rank]
+    n_gpus = args.gpus if single else world
+    B, Tx, fpi = args.batch, args.tx, args.frames_per_id
+    # single-process: every step of every device is one batch of B utterances; the job's step = n_gpus batches
+    wl = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker)
+    eng = wl.engines[0]
+
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if single:
+            for d in devices:
+                torch.cuda.synchronize(d)
+        else:
+            torch.cuda.synchronize()
 
-    for e in engines:  # every handle sizes its workspace on first use: never inside the timed region
-        step(0, e)
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    samples_per_step = int(out["lengths"].sum()) * world
+    def timed(w, steps, warmup, device_only=False):
+        w.run_steps(warmup, device_only)
+        barrier()
+        t0 = time.perf_counter()
+        out = w.run_steps(steps, device_only)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    wl.size_workspaces()
+    # in single-process mode K "steps" = K batches per device = K * n_gpus engine calls
+    calls = args.steps * (n_gpus if single else 1)
+    elapsed, out = timed(wl, calls, args.warmup * (n_gpus if single else 1))
+    samples_per_call = int(out["lengths"].sum())
+    samples_per_step = samples_per_call * n_gpus
     value = samples_per_step * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
     result = {
-        "metric": "22.05 kHz audio samples/sec/node (en_UK/apope_low VITS hot path: run + int16)",
+        "metric": f"22.05 kHz audio samples/sec/node (en_{'UK/apope_low' if args.voice == 'apope_low' else 'US/vctk_low'} "
+                  "VITS hot path: run + int16, host ids in -> host int16 out)",
         "value": value,
         "unit": "samples/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -162,17 +273,32 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded random-init weights of the en_UK/apope_low shapes, seeded phoneme ids)",
+        "data": f"synthetic (seeded random-init weights of the {args.voice} shapes, seeded phoneme ids)",
         "config": {
-            "workload": f"en_UK/apope_low, {B} utterances/GPU x {Tx} phoneme ids, forced {fpi} frames/id "
-                        f"({Tx * fpi} frames = {Tx * fpi * cfg.hop_length} samples each); 8 GPUs = BASELINE batch 256",
-            "global_batch": B * world, "phonemes": Tx, "frames": Tx * fpi, "parallelism": f"batch-shard x{world}",
-            "streams_per_gpu": len(engines),
+            "workload": f"{'en_UK/apope_low' if args.voice == 'apope_low' else 'en_US/vctk_low'}, {B} utterances/GPU x {Tx} "
+                        f"phoneme ids, forced {fpi} frames/id ({Tx * fpi} frames = {Tx * fpi * cfg.hop_length} samples each); "
+                        "8 GPUs = BASELINE batch 256",
+            "global_batch": B * n_gpus, "phonemes": Tx, "frames": Tx * fpi,
+            "parallelism": f"batch-shard x{n_gpus}" + (" (one process, one host thread per engine handle)" if single else ""),
+            "streams_per_gpu": max(1, args.streams),
             "scales": [0.667, 1.0, 0.8],
+            "timed_region": "host-to-host: ids H2D + run + int16 + D2H of int16 into recycled pinned buffers",
         },
         "rtf": elapsed / args.steps / (samples_per_step / SAMPLE_RATE),
         "x_realtime": (samples_per_step / SAMPLE_RATE) / (elapsed / args.steps),
+        "timed_region_s": elapsed,
     }
+
+    if not args.no_extra:
+        # same loop, int16 result left in HBM: the compute-side number (round 1's headline definition)
+        n_dev = max(10, calls // 4)
+        el_d, _ = timed(wl, n_dev, 3, device_only=True)
+        if rank == 0:
+            steps_d = n_dev / (n_gpus if single else 1)
+            result["device_only"] = {
+                "value": samples_per_step * steps_d / el_d, "unit": "samples/s", "ms_per_step": el_d / steps_d * 1e3,
+                "steps": steps_d, "note": "int16 result left in HBM (no D2H inside the timed region)",
+            }
 
     if rank == 0 and not args.no_b1:
         # ---- configs[1]: batch 1, golden-utterance shape (991 frames = 253,696 samples = 11.505 s)
@@ -180,137 +306,138 @@ def main():
         ids1 = np.random.default_rng(99).integers(1, 50, (1, Txg)).astype(np.int64)
         f1 = np.full((1, Txg), 5, np.int32)
         f1[0, :91] = 6
+        sid1 = np.zeros(1, np.int64) if cfg.is_multispeaker else None
+
+        def b1():
+            return eng.run(ids1, [Txg], wl.scales, sid1, forced_durations=f1, want_float=False, want_pcm16=True)  # incl. D2H
+
         for _ in range(3):
-            eng.run(ids1, [Txg], scales, forced_durations=f1, want_float=False, want_pcm16=True)
+            b1()
         lat = []
-        for _ in range(10):
+        for _ in range(20):
             t1 = time.perf_counter()
-            o1 = eng.run(ids1, [Txg], scales, forced_durations=f1, want_float=False, want_pcm16=True)  # incl. D2H of int16
+            o1 = b1()
             lat.append(time.perf_counter() - t1)
         n1 = int(o1["lengths"][0])
         med = float(np.median(lat))
+        dev_ms = eng.last_run_ms()
         if not args.no_roofline:
-            eng.profile_enable(True)
-            eng.profile_reset()
-            for _ in range(3):
-                eng.run(ids1, [Txg], scales, forced_durations=f1, want_float=False, want_pcm16=True)
-            rep1 = eng.profile_report()
-            eng.profile_enable(False)
-            eng.profile_reset()
-            rows1 = sorted(({"kernel": k, "launches": v["calls"] // 3, "ms": v["ms"] / 3} for k, v in rep1.items()),
-                           key=lambda r: -r["ms"])
+            rep1, rows1, tot1 = kernel_table(eng, lambda i: b1(), 3)
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_b1.json"), "w") as f:
                 json.dump(rows1, f, indent=1)
             print("batch-1 golden shape, per-kernel (HIP events): total %.3f ms over %d launches" %
-                  (sum(r["ms"] for r in rows1), sum(r["launches"] for r in rows1)), file=sys.stderr)
+                  (tot1 / 3, sum(r["launches_per_step"] for r in rows1)), file=sys.stderr)
             for r in rows1[:10]:
-                print(f"  {r['kernel']:22s} {r['launches']:4d} launches {r['ms']:8.3f} ms", file=sys.stderr)
+                print(f"  {r['kernel']:22s} {r['launches_per_step']:4d} launches {r['ms_per_step']:8.3f} ms", file=sys.stderr)
         result["latency_b1"] = {
-            "workload": "en_UK/apope_low batch 1, 180 ids -> 991 frames = 253,696 samples (golden-utterance shape), "
+            "workload": f"{args.voice} batch 1, 180 ids -> 991 frames = 253,696 samples (golden-utterance shape), "
                         "host ids in -> host int16 out (PCIe included)",
             "ms_median": med * 1e3, "ms_min": float(min(lat)) * 1e3, "rtf": med / (n1 / SAMPLE_RATE),
-            "x_realtime": (n1 / SAMPLE_RATE) / med, "device_ms": eng.last_run_ms(),
+            "x_realtime": (n1 / SAMPLE_RATE) / med, "device_ms": dev_ms,
         }
 
     if rank == 0 and not args.no_roofline:
-        eng.profile_enable(True)
-        eng.profile_reset()
-        for i in range(max(1, min(args.steps, 3))):
-            step(i)
-        rep = eng.profile_report()
-        eng.profile_enable(False)
-        nsteps = max(1, min(args.steps, 3))
-        tot_ms = sum(v["ms"] for v in rep.values())
-        table = []
-        for name, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
-            sec = v["ms"] * 1e-3
-            table.append({
-                "kernel": name, "launches_per_step": v["calls"] // nsteps, "ms_per_step": v["ms"] / nsteps,
-                "share": v["ms"] / tot_ms if tot_ms else 0.0,
-                "tflops": v["flops"] / sec / 1e12 if sec > 0 else 0.0,
-                "gbs_algorithmic": v["bytes"] / sec / 1e9 if sec > 0 else 0.0,
-            })
-        dom = table[0]
-        drec = rep[dom["kernel"]]
-        dsec = drec["ms"] * 1e-3
-        result["roofline"] = {
-            "kernel": dom["kernel"],
-            "bound": "mfma",
-            "achieved": drec["flops"] / dsec / 1e12,
-            "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
-            "traffic": (_pmc_traffic(dom["kernel"], B, Tx, fpi) or {}).get("hbm_bytes_per_launch"),
-            "traffic_detail": _pmc_traffic(dom["kernel"], B, Tx, fpi),
-            "avg_launch_us": drec["ms"] * 1e3 / drec["calls"],
-            "launches": drec["calls"],
-            "hbm_algorithmic_gbs": drec["bytes"] / dsec / 1e9,
-            "hbm_frac": drec["bytes"] / dsec / 1e9 / PEAK_HBM_GBS,
-            "note": "fp32 Conv1d is compute-bound on MI355X (AI >= 24 FLOP/B vs ridge 19.7): peak = 157.3 TFLOP/s fp32 "
-                    "matrix-core rate; hbm_* give the same launches against the 8 TB/s HBM roof as BASELINE asks",
-            "whole_step": {
-                "tflops": sum(v["flops"] for v in rep.values()) / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
-                "hbm_algorithmic_gbs": sum(v["bytes"] for v in rep.values()) / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
-                "kernel_ms_per_step": tot_ms / nsteps,
-            },
-        }
+        nsteps = 3
+        rep, table, tot_ms = kernel_table(eng, lambda i: wl.step(i, device_only=True), nsteps)
+        result["roofline"] = roofline_of(rep, table, tot_ms, nsteps, [B, Tx, fpi], args.voice)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w") as f:
             json.dump(table, f, indent=1)
-        print("per-kernel (HIP events):", file=sys.stderr)
-        for row in table:
-            print(f"  {row['kernel']:22s} {row['launches_per_step']:4d} launches  {row['ms_per_step']:9.3f} ms/step "
-                  f"{100 * row['share']:5.1f}%  {row['tflops']:7.2f} TFLOP/s  {row['gbs_algorithmic']:8.1f} GB/s", file=sys.stderr)
+        print_table("per-kernel (HIP events):", table)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.vits_oracle import VitsOracle, audio_float_to_int16
-
-        torch.set_num_threads(min(os.cpu_count() or 1, 32))  # beyond ~32 threads the small ops only get slower
-        ora = VitsOracle(cfg, weights)
-        nb = 1
-        ids_c, len_c = ids[:nb], lengths[:nb]
-        rng = np.random.default_rng(0)
-        nw = rng.standard_normal((nb, 2, Tx)).astype(np.float32)
-        nz = rng.standard_normal((nb, cfg.inter_channels, Tx * fpi)).astype(np.float32)
-
-        def cpu_once():
-            r = ora.infer(ids_c, len_c, scales, noise_w=nw, noise_z=nz, forced_durations=forced[:nb])
-            return [audio_float_to_int16(r["audio"][b, 0, : int(r["audio_lengths"][b])]) for b in range(nb)]
-
-        cpu_once()
-        times = []
-        t_begin = time.perf_counter()
-        while len(times) < 3 or (time.perf_counter() - t_begin < args.cpu_seconds and len(times) < 500):
-            t1 = time.perf_counter()
-            pcm = cpu_once()
-            times.append(time.perf_counter() - t1)
-        n_cpu = sum(len(p) for p in pcm)
-        medc = float(np.median(times))
-        result["cpu_baseline"] = {
-            "value": n_cpu / medc, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"PyTorch-CPU fp32 oracle (onnxruntime unavailable), {nb} utterance x {Tx} ids x {fpi} frames/id "
-                      f"= {n_cpu} samples, median of {len(times)} runs after 1 warm-up, run + int16",
-            "ms_median": medc * 1e3, "x_realtime": (n_cpu / SAMPLE_RATE) / medc,
-            "cpu": _cpu_model(), "torch": torch.__version__,
+    if rank == 0 and n_gpus == 1 and not args.no_extra and args.voice == "apope_low":
+        # ---- BASELINE.json configs[2]: en_US/vctk_low multi-speaker, batch 32 x 128 phonemes, one MI355X
+        vcfg = VitsConfig.vctk_low()
+        vw = Workload(vcfg, W.synthetic_weights(vcfg, seed=1234), devices, args.streams, 32, 128, fpi, 0, 1,
+                      multispeaker_sid=True)
+        vw.size_workspaces()
+        vsteps = max(20, args.steps // 3)
+        el_v, out_v = timed(vw, vsteps, 5)
+        sps = int(out_v["lengths"].sum())
+        extra = {
+            "workload": f"en_US/vctk_low (109 speakers, gin 512), 32 utterances x 128 phoneme ids, sid = b mod 109, forced "
+                        f"{fpi} frames/id; host-to-host",
+            "value": sps * vsteps / el_v, "unit": "samples/s", "steps": vsteps, "ms_per_step": el_v / vsteps * 1e3,
+            "x_realtime": (sps / SAMPLE_RATE) / (el_v / vsteps), "dtype": "f32",
         }
+        if not args.no_roofline:
+            repv, tablev, totv = kernel_table(vw.engines[0], lambda i: vw.step(i, device_only=True), 3)
+            extra["roofline"] = roofline_of(repv, tablev, totv, 3, [32, 128, fpi], "vctk_low")
+            with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_vctk.json"), "w") as f:
+                json.dump(tablev, f, indent=1)
+            print_table("vctk_low b32, per-kernel (HIP events):", tablev[:12])
+        result["extra"] = {"vctk_low_b32": extra}
+        vw.close()
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, weights, wl, args.cpu_seconds)
 
     if rank == 0:
         print(json.dumps(result))
-    eng.close()
+    wl.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _pmc_traffic(kernel, B, Tx, fpi):
+def cpu_baseline(cfg, weights, wl, budget_s):
+    """The PyTorch-CPU oracle on this host's cores over a bounded sample of the same workload: (a) one utterance per
+    call on <= 32 threads (the reference's own call shape: B = 1 per sentence), (b) eight utterances per call on all
+    cores; `value` is the better of the two."""
+    import torch
+
+    from oracle.vits_oracle import VitsOracle, audio_float_to_int16
+
+    ora = VitsOracle(cfg, weights)
+    Tx, fpi = wl.Tx, wl.fpi
+    rng = np.random.default_rng(0)
+    ncpu = os.cpu_count() or 1
+
+    def leg(nb, threads, budget):
+        torch.set_num_threads(threads)
+        ids_c, len_c = wl.ids[:nb], wl.lengths[:nb]
+        sid_c = None if wl.sid is None else wl.sid[:nb]
+        nw = rng.standard_normal((nb, 2, Tx)).astype(np.float32)
+        nz = rng.standard_normal((nb, cfg.inter_channels, Tx * fpi)).astype(np.float32)
+
+        def once():
+            r = ora.infer(ids_c, len_c, wl.scales, sid=sid_c, noise_w=nw, noise_z=nz, forced_durations=wl.forced[:nb],
+                          stage_rows=())
+            return [audio_float_to_int16(r["audio"][b, 0, : int(r["audio_lengths"][b])]) for b in range(nb)]
+
+        once()
+        times = []
+        t_begin = time.perf_counter()
+        while len(times) < 3 or (time.perf_counter() - t_begin < budget and len(times) < 500):
+            t1 = time.perf_counter()
+            pcm = once()
+            times.append(time.perf_counter() - t1)
+        n = sum(len(p) for p in pcm)
+        med = float(np.median(times))
+        return {"utterances_per_call": nb, "threads": threads, "samples": n, "runs": len(times), "ms_median": med * 1e3,
+                "samples_per_s": n / med}
+
+    legs = [leg(1, min(ncpu, 32), budget_s * 0.5), leg(min(8, wl.B), ncpu, budget_s * 0.5)]
+    best = max(legs, key=lambda l: l["samples_per_s"])
+    return {
+        "value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
+        "sample": f"PyTorch-CPU fp32 oracle (onnxruntime unavailable), {best['utterances_per_call']} utterance(s) x {Tx} ids x "
+                  f"{fpi} frames/id = {best['samples']} samples per call, median of {best['runs']} calls after 1 warm-up, "
+                  "run + int16",
+        "ms_median": best["ms_median"], "x_realtime": best["samples_per_s"] / SAMPLE_RATE,
+        "legs": legs, "host_cpus": ncpu, "cpu": _cpu_model(), "torch": torch.__version__,
+    }
+
+
+def _pmc_traffic(kernel, workload_key, voice="apope_low"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), valid for
     the workload they were collected on; None otherwise (counters cannot be read from inside this process)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
         e = t.get(kernel)
-        if e and e["workload"] == [B, Tx, fpi]:
+        if e and e["workload"] == list(workload_key) and e.get("voice", "apope_low") == voice:
             return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
                     "source": e["source"]}
     except (OSError, ValueError, KeyError):

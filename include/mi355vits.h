@@ -118,10 +118,17 @@ typedef struct mi355vits_result {
 } mi355vits_result;
 
 const char* mi355vits_version(void);
+/* Number of HIP devices this process can use (0 when there is none): sizes the in-process device round-robin of a
+ * session serving mimic3_http's worker threads (mimic3_http/__main__.py:53-61 starts them in ONE process). */
+int mi355vits_device_count(void);
 
 /* Load a voice from an .m355 container (mimic3_amd/weights.py) onto HIP device `device`. */
 int mi355vits_create(const char* weights_path, int device, mi355vits_handle* out);
 int mi355vits_create_from_buffer(const void* blob, size_t blob_bytes, int device, mi355vits_handle* out);
+/* Another execution lane for the voice of `src`, on the same device: own HIP stream and workspace, SHARED weight
+ * replica (the weights are freed with the last lane).  The reference shares one session between the server's worker
+ * threads (voice.py:277-292, mimic3_http/__main__.py:53-61); lanes are how those concurrent `run` calls overlap. */
+int mi355vits_clone(mi355vits_handle src, mi355vits_handle* out);
 void mi355vits_destroy(mi355vits_handle h);
 int mi355vits_get_config(mi355vits_handle h, mi355vits_config* out);
 
@@ -131,6 +138,12 @@ int mi355vits_get_config(mi355vits_handle h, mi355vits_config* out);
 int mi355vits_run(mi355vits_handle h, const mi355vits_run_args* args, mi355vits_result* out);
 int mi355vits_fetch(mi355vits_handle h, uint32_t want_flags, mi355vits_result* out);
 void mi355vits_free_result(mi355vits_result* r);
+/* Device pointers of the last run's results on this handle (valid until its next run; the engine's stream has been
+ * synchronised when this returns): int16 [batch, row_stride] and/or float [batch, row_stride] in HBM, plus the valid
+ * sample counts [batch] (int32, device).  For the optional device-side result gather over RCCL (north star; SURVEY.md
+ * §8e) — the data never visits the host.  Pass NULL for what is not wanted. */
+int mi355vits_device_result(mi355vits_handle h, const int16_t** pcm, const float** audio, int64_t* row_stride,
+                            int32_t* batch, const int32_t** device_lengths);
 
 /* Message of the last error on this handle (or, with h == NULL, of the last failed create on the
  * calling thread).  Valid until the next call on the same handle / thread. */

@@ -26,7 +26,8 @@ DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libmi355vits.so")
 
 # every symbol include/mi355vits.h declares
 EXPORTED_SYMBOLS = (
-    "mi355vits_version", "mi355vits_create", "mi355vits_create_from_buffer", "mi355vits_destroy",
+    "mi355vits_version", "mi355vits_device_count", "mi355vits_create", "mi355vits_create_from_buffer", "mi355vits_clone", "mi355vits_destroy",
+    "mi355vits_device_result",
     "mi355vits_get_config", "mi355vits_run", "mi355vits_fetch", "mi355vits_free_result",
     "mi355vits_last_error", "mi355vits_profile_enable", "mi355vits_profile_reset",
     "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_list_taps",
@@ -107,6 +108,10 @@ class NativeLibrary:
         L.mi355vits_version.restype = ctypes.c_char_p
         L.mi355vits_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(H)]
         L.mi355vits_create_from_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(H)]
+        L.mi355vits_clone.argtypes = [H, ctypes.POINTER(H)]
+        L.mi355vits_device_result.argtypes = [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32),
+                                              ctypes.POINTER(ctypes.c_void_p)]
         L.mi355vits_destroy.argtypes = [H]
         L.mi355vits_destroy.restype = None
         L.mi355vits_get_config.argtypes = [H, ctypes.POINTER(CVitsConfig)]
@@ -137,6 +142,9 @@ class NativeLibrary:
 
     def version(self) -> str:
         return self.lib.mi355vits_version().decode()
+
+    def device_count(self) -> int:
+        return int(self.lib.mi355vits_device_count())
 
     def create_error(self) -> str:
         return (self.lib.mi355vits_last_error(None) or b"").decode("utf-8", "replace")
@@ -211,15 +219,43 @@ def default_library() -> NativeLibrary:
         return _default
 
 
+class _ResultHolder:
+    """Keeps one ``mi355vits_result`` alive for the numpy views made of it; releases it when they are gone."""
+
+    def __init__(self, native: "NativeLibrary", r: Result):
+        self._native = native
+        self._r = Result()
+        ctypes.memmove(ctypes.byref(self._r), ctypes.byref(r), ctypes.sizeof(Result))
+
+    def view(self, ptr, ctype, dtype, B: int, L: int) -> np.ndarray:
+        n = int(B) * int(L)
+        buf = (ctype * n).from_address(ctypes.addressof(ptr.contents))
+        buf._holder = self  # the array's base chain (memoryview -> ctypes array) keeps the holder alive
+        return np.frombuffer(buf, dtype=dtype, count=n).reshape(B, L)
+
+    def __del__(self):
+        try:
+            self._native.lib.mi355vits_free_result(ctypes.byref(self._r))
+        except Exception:
+            pass
+
+
 class Engine:
     """A voice loaded on one GPU (wraps ``mi355vits_handle``)."""
 
     def __init__(self, weights, device: int = 0, library: Optional[NativeLibrary] = None):
-        """``weights``: path to an ``.m355`` container, or its bytes."""
-        self.native = library or default_library()
+        """``weights``: path to an ``.m355`` container, its bytes, or another ``Engine`` — then this is a further lane
+        on that engine's device sharing its weight replica (``mi355vits_clone``; ``device`` is ignored)."""
+        self.native = weights.native if isinstance(weights, Engine) else (library or default_library())
         self._h = ctypes.c_void_p()
         L = self.native.lib
-        if isinstance(weights, (bytes, bytearray, memoryview)):
+        if isinstance(weights, Engine):
+            rc = L.mi355vits_clone(weights._h, ctypes.byref(self._h))
+            if rc != 0:
+                self._h = ctypes.c_void_p()
+                raise NativeError(rc, (L.mi355vits_last_error(weights._h) or b"").decode("utf-8", "replace"))
+            device = weights.device
+        elif isinstance(weights, (bytes, bytearray, memoryview)):
             buf = bytes(weights)
             rc = L.mi355vits_create_from_buffer(buf, len(buf), device, ctypes.byref(self._h))
         else:
@@ -302,6 +338,20 @@ class Engine:
         del keep
         return self._take(r)
 
+    def clone(self) -> "Engine":
+        """Another lane on this engine's device: own stream + workspace, shared weights."""
+        return Engine(self)
+
+    def device_result(self) -> Dict[str, object]:
+        """Device pointers of the last run's results (``mi355vits_device_result``): ``{"pcm": ptr, "audio": ptr,
+        "row_stride": L, "batch": B, "lengths": ptr, "device": d}`` — valid until the next run on this handle."""
+        pcm, audio, lens = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        rs, b = ctypes.c_int64(), ctypes.c_int32()
+        self._check(self.native.lib.mi355vits_device_result(self._h, ctypes.byref(pcm), ctypes.byref(audio), ctypes.byref(rs),
+                                                           ctypes.byref(b), ctypes.byref(lens)))
+        return {"pcm": pcm.value, "audio": audio.value, "row_stride": int(rs.value), "batch": int(b.value),
+                "lengths": lens.value, "device": self.device}
+
     def fetch(self, want_float: bool = True, want_pcm16: bool = False) -> Dict[str, np.ndarray]:
         r = Result()
         flags = (WANT_FLOAT if want_float else 0) | (WANT_PCM16 if want_pcm16 else 0)
@@ -309,20 +359,29 @@ class Engine:
         return self._take(r)
 
     def _take(self, r: Result) -> Dict[str, np.ndarray]:
+        """Result struct -> numpy.  The waveform arrays are *views of the callee's pinned buffers* that own them: the
+        buffers go back to the library (``mi355vits_free_result`` -> pinned pool) when the last array referring to
+        them is garbage-collected.  No host-side copy of the audio, no aliasing between calls (a buffer is handed out
+        exclusively until released) — "a new ndarray owned by Python", as ``onnx_model.run`` returns."""
+        B, L = r.batch, r.l_max
         try:
-            B, L = r.batch, r.l_max
             out: Dict[str, np.ndarray] = {
                 "lengths": np.ctypeslib.as_array(r.lengths, shape=(B,)).copy(),
                 "peaks": np.ctypeslib.as_array(r.peaks, shape=(B,)).copy(),
                 "l_max": np.int64(L), "ty_max": np.int64(r.ty_max),
             }
-            if r.audio:
-                out["audio"] = np.ctypeslib.as_array(r.audio, shape=(B, L)).copy()
-            if r.pcm:
-                out["pcm"] = np.ctypeslib.as_array(r.pcm, shape=(B, L)).copy()
-            return out
-        finally:
+        except BaseException:
             self.native.lib.mi355vits_free_result(ctypes.byref(r))
+            raise
+        if not r.audio and not r.pcm:
+            self.native.lib.mi355vits_free_result(ctypes.byref(r))
+            return out
+        holder = _ResultHolder(self.native, r)
+        if r.audio:
+            out["audio"] = holder.view(r.audio, ctypes.c_float, np.float32, B, L)
+        if r.pcm:
+            out["pcm"] = holder.view(r.pcm, ctypes.c_int16, np.int16, B, L)
+        return out
 
     # ---- profiling / debugging ------------------------------------------------------------------
     def last_run_ms(self) -> float:

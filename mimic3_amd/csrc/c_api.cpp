@@ -38,9 +38,9 @@ int guarded(mi355vits_handle h, F&& fn) {
 }
 
 int create_common(WeightsFile& wf, int device, mi355vits_handle* out) {
-    auto* h = new mi355vits_engine();
-    h->eng.reset(new Engine(wf, device));
-    *out = h;
+    std::unique_ptr<mi355vits_engine> h(new mi355vits_engine());
+    h->eng.reset(new Engine(wf, device));  // may throw: `h` is released by the unique_ptr
+    *out = h.release();
     return MI355VITS_OK;
 }
 }  // namespace
@@ -62,6 +62,12 @@ const char* mi355vits_version(void) {
 #else
     return "mi355vits 0.1.0 (gfx950)";
 #endif
+}
+
+int mi355vits_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 0) return 0;
+    return n;
 }
 
 int mi355vits_create(const char* weights_path, int device, mi355vits_handle* out) {
@@ -89,6 +95,30 @@ int mi355vits_create_from_buffer(const void* blob, size_t blob_bytes, int device
     });
 }
 
+int mi355vits_clone(mi355vits_handle src, mi355vits_handle* out) {
+    if (out) *out = nullptr;
+    if (!src) return MI355VITS_ERR_INVALID;
+    return guarded(src, [&] {
+        if (!out) throw EngineError(MI355VITS_ERR_INVALID, "out must not be null");
+        std::unique_ptr<mi355vits_engine> h(new mi355vits_engine());
+        h->eng.reset(new Engine(*src->eng));
+        *out = h.release();
+    });
+}
+
+int mi355vits_device_result(mi355vits_handle h, const int16_t** pcm, const float** audio, int64_t* row_stride,
+                            int32_t* batch, const int32_t** device_lengths) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    return guarded(h, [&] {
+        long rs = 0;
+        int b = 0;
+        h->eng->device_buffers(pcm, audio, &rs, &b, device_lengths);
+        if (row_stride) *row_stride = rs;
+        if (batch) *batch = b;
+    });
+}
+
 void mi355vits_destroy(mi355vits_handle h) {
     if (!h) return;
     try {
@@ -107,6 +137,7 @@ int mi355vits_get_config(mi355vits_handle h, mi355vits_config* out) {
 }
 
 int mi355vits_run(mi355vits_handle h, const mi355vits_run_args* args, mi355vits_result* out) {
+    if (out) memset(out, 0, sizeof(*out));  // before anything can fail: free_result below must never see garbage
     if (!h) return MI355VITS_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->eng->mu);
     int rc = guarded(h, [&] {
@@ -118,6 +149,7 @@ int mi355vits_run(mi355vits_handle h, const mi355vits_run_args* args, mi355vits_
 }
 
 int mi355vits_fetch(mi355vits_handle h, uint32_t want_flags, mi355vits_result* out) {
+    if (out) memset(out, 0, sizeof(*out));
     if (!h) return MI355VITS_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->eng->mu);
     int rc = guarded(h, [&] { h->eng->fetch(want_flags, out); });

@@ -220,7 +220,7 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             c.packed4 = stage(p4.data(), p4.size());
         }
     }
-    return convs_[key] = c;
+    return model_->convs[key] = c;
 }
 
 const ConvW& Engine::add_conv(const WeightsFile& wf, const std::string& key, const std::string& tensor, int Cout, int Cin,
@@ -237,16 +237,16 @@ const ConvW& Engine::add_conv(const WeightsFile& wf, const std::string& key, con
 
 void Engine::add_vec(const WeightsFile& wf, const std::string& name, std::initializer_list<int> dims) {
     const HostTensor& t = wf.get(name, dims);
-    vecs_[name] = stage(t.data, t.count);
+    model_->vecs[name] = stage(t.data, t.count);
 }
 const float* Engine::vec(const std::string& name) const {
-    auto it = vecs_.find(name);
-    if (it == vecs_.end()) throw EngineError(MI355VITS_ERR_INTERNAL, "unknown tensor: " + name);
-    return dev_weights_ + it->second;
+    auto it = model_->vecs.find(name);
+    if (it == model_->vecs.end()) throw EngineError(MI355VITS_ERR_INTERNAL, "unknown tensor: " + name);
+    return model_->dev_weights + it->second;
 }
 const ConvW& Engine::cw(const std::string& key) const {
-    auto it = convs_.find(key);
-    if (it == convs_.end()) throw EngineError(MI355VITS_ERR_INTERNAL, "unknown conv: " + key);
+    auto it = model_->convs.find(key);
+    if (it == model_->convs.end()) throw EngineError(MI355VITS_ERR_INTERNAL, "unknown conv: " + key);
     return it->second;
 }
 
@@ -305,7 +305,33 @@ static void validate_config(const mi355vits_config& c) {
 }
 
 Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device) {
-    validate_config(cfg_);
+    // a throwing constructor never runs the destructor: stream, events and the weight arena are released here
+    try {
+        construct(wf, device);
+    } catch (...) {
+        release();
+        throw;
+    }
+}
+
+Model::~Model() {
+    if (dev_weights) {
+        (void)hipSetDevice(device);
+        (void)hipFree(dev_weights);
+    }
+}
+
+Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
+    try {
+        open_device(device_);
+        model_ = lane0.model_;
+    } catch (...) {
+        release();
+        throw;
+    }
+}
+
+void Engine::open_device(int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         throw EngineError(MI355VITS_ERR_DEVICE, "no HIP device available (the MI355X engine has no CPU fallback)");
@@ -321,6 +347,13 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
     no_fused_wn_ = nw && nw[0] == '1';
     const char* nf = getenv("MI355VITS_NO_FUSED_MRF");
     no_fused_mrf_ = nf && nf[0] == '1';
+}
+
+void Engine::construct(const WeightsFile& wf, int device) {
+    validate_config(cfg_);
+    open_device(device);
+    model_ = std::make_shared<Model>();
+    model_->device = device;
 
     const mi355vits_config& c = cfg_;
     const int H = c.hidden_channels, F = c.filter_channels, I = c.inter_channels, half = I / 2;
@@ -375,8 +408,8 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
     {
         const HostTensor& m = wf.get("dp.flows.0.m", {2, 1});
         const HostTensor& l = wf.get("dp.flows.0.logs", {2, 1});
-        ea_m_[0] = m.data[0]; ea_m_[1] = m.data[1];
-        ea_logs_[0] = l.data[0]; ea_logs_[1] = l.data[1];
+        model_->ea_m[0] = m.data[0]; model_->ea_m[1] = m.data[1];
+        model_->ea_logs[0] = l.data[0]; model_->ea_logs[1] = l.data[1];
     }
     for (int j = 1; j < c.dp_n_flows; ++j) {
         const std::string p = S("dp.flows.%d", 1 + 2 * j);
@@ -423,7 +456,7 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
             add_conv_data(S("flow.%d.post", j), wv, &bv, half, H, 1);
         }
     }
-    flow_reversed_out_ = (c.flow_n_flows % 2) == 1;
+    model_->flow_reversed_out = (c.flow_n_flows % 2) == 1;
 
     // ---- HiFi-GAN decoder
     const int C0 = c.upsample_initial_channel;
@@ -433,7 +466,7 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
         std::vector<float> wv(w.count), bv(b.data, b.data + b.count);
         for (int co = 0; co < C0; ++co)
             for (int ci = 0; ci < I; ++ci)
-                memcpy(wv.data() + ((size_t)co * I + ci) * 7, w.data + ((size_t)co * I + (flow_reversed_out_ ? I - 1 - ci : ci)) * 7,
+                memcpy(wv.data() + ((size_t)co * I + ci) * 7, w.data + ((size_t)co * I + (model_->flow_reversed_out ? I - 1 - ci : ci)) * 7,
                        sizeof(float) * 7);
         add_conv_data("dec.conv_pre", wv, &bv, C0, I, 7);
     }
@@ -475,19 +508,26 @@ Engine::Engine(const WeightsFile& wf, int device) : cfg_(wf.cfg), device_(device
     void* p = nullptr;
     if (hipMalloc(&p, host_stage_.size() * sizeof(float) + 256) != hipSuccess)
         throw EngineError(MI355VITS_ERR_NOMEM, "out of device memory (weights)");
-    dev_weights_ = static_cast<float*>(p);
-    HIP_CHECK(hipMemcpy(dev_weights_, host_stage_.data(), host_stage_.size() * sizeof(float), hipMemcpyHostToDevice));
+    model_->dev_weights = static_cast<float*>(p);
+    model_->bytes = host_stage_.size() * sizeof(float);
+    HIP_CHECK(hipMemcpy(model_->dev_weights, host_stage_.data(), host_stage_.size() * sizeof(float), hipMemcpyHostToDevice));
     std::vector<float>().swap(host_stage_);
 }
 
-Engine::~Engine() {
+void Engine::release() noexcept {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (dev_weights_) (void)hipFree(dev_weights_);
+    for (auto& t : taps_) (void)hipFree(t.dev);
+    taps_.clear();
+    model_.reset();  // the replica is freed with its last lane
     if (ev_start_) (void)hipEventDestroy(ev_start_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
+    ev_start_ = ev_end_ = nullptr;
     if (stream_) (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
 }
+
+Engine::~Engine() { release(); }
 
 // =================================================================================================
 // launch helpers
@@ -716,7 +756,7 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
     {
         ProfScope ps(prof_, "durations");
         // logical channel 0 uses EA parameters [0]
-        launch_durations(d_z2_, ch0, ea_m_[0], ea_logs_[0], d_len_, d_forced_, B, Tx, args.scales[1], d_logw_, d_wceil_,
+        launch_durations(d_z2_, ch0, model_->ea_m[0], model_->ea_logs[0], d_len_, d_forced_, B, Tx, args.scales[1], d_logw_, d_wceil_,
                          d_cum_, d_ylen_, stream_);
     }
     tap("logw", d_logw_, {B, 1, Tx});
@@ -938,9 +978,74 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
 // one synthesis call
 // =================================================================================================
 namespace {
+// Pinned host buffers for results, recycled process-wide: hipHostMalloc costs milliseconds for a 12 MB block (page
+// pinning + IOMMU mapping), more than the D2H itself, so a buffer released by mi355vits_free_result goes back on a
+// free list and the next call of any handle takes the smallest one that fits.  Buffers are handed out exclusively
+// (a result stays valid until its free_result, whatever runs meanwhile); at most POOL_KEEP_BYTES stay cached.
+class PinnedPool {
+  public:
+    static PinnedPool& get() {
+        static PinnedPool* p = new PinnedPool();  // never destroyed: no hipHostFree after the runtime has shut down
+        return *p;
+    }
+    void* take(size_t bytes, size_t* cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = free_.lower_bound(bytes);
+            // a block more than twice as large as needed is left for a caller that needs it
+            if (it != free_.end() && it->first <= 2 * bytes + (1 << 16)) {
+                void* p = it->second;
+                *cap = it->first;
+                cached_ -= it->first;
+                free_.erase(it);
+                return p;
+            }
+        }
+        const size_t want = ((bytes + (1 << 16) - 1) >> 16) << 16;  // 64 KiB granules: nearby sizes share blocks
+        void* p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            trim(0);
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess)
+                throw EngineError(MI355VITS_ERR_NOMEM, "out of pinned host memory (result buffer)");
+        }
+        *cap = want;
+        return p;
+    }
+    void give(void* p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            free_.emplace(cap, p);
+            cached_ += cap;
+        }
+        trim(POOL_KEEP_BYTES);
+    }
+
+  private:
+    static constexpr size_t POOL_KEEP_BYTES = size_t(1) << 30;
+    void trim(size_t keep) {
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (cached_ > keep && !free_.empty()) {
+                auto it = std::prev(free_.end());
+                cached_ -= it->first;
+                drop.push_back(it->second);
+                free_.erase(it);
+            }
+        }
+        for (void* p : drop) (void)hipHostFree(p);
+    }
+    std::mutex mu_;
+    std::multimap<size_t, void*> free_;
+    size_t cached_ = 0;
+};
+
 struct ResultOwner {
     void* audio = nullptr;
+    size_t audio_cap = 0;
     void* pcm = nullptr;
+    size_t pcm_cap = 0;
     void* lengths = nullptr;
     void* peaks = nullptr;
 };
@@ -1057,7 +1162,7 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     HIP_CHECK(hipStreamSynchronize(stream_));
     int Ty = 1;
     for (int b = 0; b < B; ++b) {
-        if (h_ylen_[b] < 1 || h_ylen_[b] > (1 << 22)) throw EngineError(MI355VITS_ERR_INVALID, "predicted duration out of range (bad weights or length_scale?)");
+        if (h_ylen_[b] < 1 || h_ylen_[b] > DURATION_FRAME_CAP) throw EngineError(MI355VITS_ERR_INVALID, "predicted duration out of range (bad weights or length_scale?)");
         Ty = std::max(Ty, h_ylen_[b]);
     }
     if (args.noise_z && args.scales[0] != 0.0f && args.noise_z_frames < Ty)
@@ -1160,7 +1265,7 @@ void Engine::copy_out(uint32_t want, mi355vits_result* out) {
     HIP_CHECK(hipMemcpyAsync(pk.data(), d_peaks_, sizeof(unsigned) * B, hipMemcpyDeviceToHost, stream_));
     const bool dev_only = (want & MI355VITS_DEVICE_ONLY) != 0;
     if (!dev_only && (want & MI355VITS_WANT_FLOAT)) {
-        HIP_CHECK(hipHostMalloc(&own->audio, sizeof(float) * (size_t)B * L_ + 16, hipHostMallocDefault));
+        own->audio = PinnedPool::get().take(sizeof(float) * (size_t)B * L_ + 16, &own->audio_cap);
         out->audio = static_cast<float*>(own->audio);
         HIP_CHECK(hipMemcpyAsync(out->audio, d_audio_, sizeof(float) * (size_t)B * L_, hipMemcpyDeviceToHost, stream_));
     }
@@ -1169,12 +1274,27 @@ void Engine::copy_out(uint32_t want, mi355vits_result* out) {
             launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B, (int)L_, d_pcm_, L_, stream_, 1.0);
             have_pcm_ = true;
         }
-        HIP_CHECK(hipHostMalloc(&own->pcm, sizeof(int16_t) * (size_t)B * L_ + 16, hipHostMallocDefault));
+        own->pcm = PinnedPool::get().take(sizeof(int16_t) * (size_t)B * L_ + 16, &own->pcm_cap);
         out->pcm = static_cast<int16_t*>(own->pcm);
         HIP_CHECK(hipMemcpyAsync(out->pcm, d_pcm_, sizeof(int16_t) * (size_t)B * L_, hipMemcpyDeviceToHost, stream_));
     }
     HIP_CHECK(hipStreamSynchronize(stream_));
     for (int b = 0; b < B; ++b) memcpy(&out->peaks[b], &pk[b], 4);
+}
+
+void Engine::device_buffers(const int16_t** pcm, const float** audio, long* row_stride, int* batch, const int** dev_lengths) {
+    if (!have_result_) throw EngineError(MI355VITS_ERR_INVALID, "device_buffers: no completed run on this handle");
+    HIP_CHECK(hipSetDevice(device_));
+    if (pcm && !have_pcm_) {
+        launch_pcm16(d_audio_, L_, d_peaks_, d_alen_, B_, (int)L_, d_pcm_, L_, stream_, 1.0);
+        have_pcm_ = true;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));  // the caller reads them from another stream (RCCL)
+    if (pcm) *pcm = d_pcm_;
+    if (audio) *audio = d_audio_;
+    if (row_stride) *row_stride = L_;
+    if (batch) *batch = B_;
+    if (dev_lengths) *dev_lengths = d_alen_;
 }
 
 void Engine::fetch(uint32_t want, mi355vits_result* out) {
@@ -1188,8 +1308,8 @@ void Engine::fetch(uint32_t want, mi355vits_result* out) {
 void free_result_impl(mi355vits_result* r) {
     if (!r || !r->owner_) return;
     auto* own = static_cast<ResultOwner*>(r->owner_);
-    if (own->audio) (void)hipHostFree(own->audio);
-    if (own->pcm) (void)hipHostFree(own->pcm);
+    PinnedPool::get().give(own->audio, own->audio_cap);
+    PinnedPool::get().give(own->pcm, own->pcm_cap);
     free(own->lengths);
     free(own->peaks);
     delete own;

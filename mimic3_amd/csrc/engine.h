@@ -96,11 +96,29 @@ struct ConvW {
     int epi = EPI_STD;  // tile map the packed copy was built for
 };
 
+// ---------------------------------------------------------------- one weight replica on one device
+// Uploaded once per (voice, device); every engine handle ("lane") created on that device through mi355vits_clone shares
+// it, so N lanes cost N workspaces but ONE copy of the weights.
+struct Model {
+    int device = 0;
+    float* dev_weights = nullptr;
+    std::unordered_map<std::string, ConvW> convs;
+    std::unordered_map<std::string, size_t> vecs;
+    float ea_m[2] = {0, 0}, ea_logs[2] = {0, 0};
+    bool flow_reversed_out = false;
+    size_t bytes = 0;
+    ~Model();
+};
+
 // ---------------------------------------------------------------- the engine
 class Engine {
   public:
     Engine(const WeightsFile& wf, int device);
+    explicit Engine(const Engine& lane0);  // another lane on lane0's device, sharing its weight replica
     ~Engine();
+    const std::shared_ptr<Model>& model() const { return model_; }
+    // device pointers of the last run's results (valid until the next run on this handle); for device-side gathers
+    void device_buffers(const int16_t** pcm, const float** audio, long* row_stride, int* batch, const int** dev_lengths);
     void run(const mi355vits_run_args& args, mi355vits_result* out);
     void fetch(uint32_t want, mi355vits_result* out);
     const mi355vits_config& config() const { return cfg_; }
@@ -112,6 +130,9 @@ class Engine {
     std::mutex mu;
 
   private:
+    void construct(const WeightsFile& wf, int device);
+    void open_device(int device);
+    void release() noexcept;
     // weight staging
     size_t stage(const float* p, size_t n);
     const ConvW& add_conv(const WeightsFile& wf, const std::string& key, const std::string& tensor, int Cout, int Cin,
@@ -120,7 +141,7 @@ class Engine {
                                int Cout, int Cin, int K, int epi = EPI_STD);
     void add_vec(const WeightsFile& wf, const std::string& name, std::initializer_list<int> dims);
     const float* vec(const std::string& name) const;
-    const float* P(size_t off) const { return off == NO_OFF ? nullptr : dev_weights_ + off; }
+    const float* P(size_t off) const { return off == NO_OFF ? nullptr : model_->dev_weights + off; }
     const ConvW& cw(const std::string& key) const;
 
     // launch helpers
@@ -143,11 +164,7 @@ class Engine {
     Profiler prof_;
 
     std::vector<float> host_stage_;
-    float* dev_weights_ = nullptr;
-    std::unordered_map<std::string, ConvW> convs_;
-    std::unordered_map<std::string, size_t> vecs_;
-    float ea_m_[2] = {0, 0}, ea_logs_[2] = {0, 0};
-    bool flow_reversed_out_ = false;
+    std::shared_ptr<Model> model_;
 
     DeviceArena arena_a_, arena_b_, arena_taps_;
     std::vector<Tap> taps_;

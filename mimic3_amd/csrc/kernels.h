@@ -158,6 +158,8 @@ void launch_spline_inverse(float* z, int ch_x0, const float* theta, const int* l
 // z init: z[b,c,t] = noise * noise_w (Philox or injected)
 void launch_sdp_noise(float* z, const float* injected, int B, int T, float noise_w, unsigned long long seed,
                       unsigned long long utt_base, hipStream_t s);
+// most latent frames one utterance may have (4.2 M frames = 13.5 h of audio); larger / non-finite predictions are an error
+constexpr int DURATION_FRAME_CAP = 1 << 22;
 // EA^-1 on channel `ch` -> logw; durations: w = ceil(exp(logw)*mask*ls) (or forced); cum = inclusive scan;
 // ylen = max(1, sum)
 void launch_durations(const float* z, int ch, float ea_m, float ea_logs, const int* len, const int* forced, int B,

@@ -380,8 +380,13 @@ __global__ __launch_bounds__(256) void k_durations(const float* z, int ch, float
         const float lw = (z[((long)b * 2 + ch) * T + t] - ea_m) * es * m;
         logw[(long)b * T + t] = lw;
         float w = expf(lw) * m * length_scale;
-        int wc = (int)ceilf(w);
-        if (forced) wc = t < L ? forced[(long)b * T + t] : 0;
+        // inf / NaN / absurd durations (bad weights, huge length_scale) must not reach the float -> int cast (UB):
+        // they become one over-the-cap count, which the host turns into ERR_INVALID before sizing anything
+        int wc = (w < (float)DURATION_FRAME_CAP) ? (int)ceilf(w) : DURATION_FRAME_CAP + 1;
+        if (forced) {
+            wc = t < L ? forced[(long)b * T + t] : 0;
+            if (wc < 0 || wc > DURATION_FRAME_CAP) wc = DURATION_FRAME_CAP + 1;
+        }
         w_ceil[(long)b * T + t] = wc;
     }
     __syncthreads();
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(256) void k_durations(const float* z, int ch, float
         int acc = 0;
         for (int t = 0; t < T; ++t) {
             acc += w_ceil[(long)b * T + t];
+            if (acc > 2 * DURATION_FRAME_CAP) acc = 2 * DURATION_FRAME_CAP;  // saturate: no int overflow over long rows
             cum[(long)b * T + t] = acc;
         }
         ylen[b] = acc < 1 ? 1 : acc;

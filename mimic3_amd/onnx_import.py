@@ -664,11 +664,16 @@ def onnx_to_m355_bytes(blob: bytes, declared: Optional[VitsConfig] = None, where
 
 def convert(onnx_path: str, out_path: Optional[str] = None, config_path: Optional[str] = None) -> str:
     """``generator.onnx`` -> ``generator.m355`` beside it (or ``out_path``).  Returns the path written."""
-    cfg, tensors = import_onnx(onnx_path, config_path)
+    import hashlib
+
+    with open(onnx_path, "rb") as f:
+        blob = f.read()
+    cfg, tensors = import_onnx_bytes(blob, load_voice_config(onnx_path, config_path), onnx_path)
     if out_path is None:
         out_path = os.path.splitext(onnx_path)[0] + ".m355"
     tmp = out_path + ".tmp%d" % os.getpid()
-    W.save(tmp, cfg, tensors)
+    # the trailer names the .onnx this container came from: the session uses the container only while they match
+    W.save(tmp, cfg, tensors, source=W.source_record(len(blob), hashlib.sha256(blob).digest()))
     os.replace(tmp, out_path)
     return out_path
 

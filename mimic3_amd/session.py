@@ -10,7 +10,8 @@ through the C ABI (``include/mi355vits.h``).  There is no CPU execution path her
 
 Voice files: the reference passes ``<voice_dir>/generator.onnx`` (``voice.py:273``).  The engine reads the
 voice from ``generator.m355`` beside it (weights + hyper-parameters, written by ``mimic3_amd.weights.save`` or
-``python -m mimic3_amd.onnx_import``) when that exists and is not older than the ``.onnx``; otherwise the ONNX
+``python -m mimic3_amd.onnx_import``) when that exists and belongs to the ``.onnx`` (the ``.onnx`` is absent or an
+empty placeholder, or the container's trailer records exactly this file's size and sha256); otherwise the ONNX
 initialisers are converted in memory at load time.  A path that already ends in ``.m355`` is used as is.
 """
 from __future__ import annotations
@@ -59,6 +60,13 @@ class SessionOptions:
         # half of one request overlaps the matrix-core half of another (+10 % throughput at batch 32).
         # Results do not depend on the lane.  Also MI355VITS_LANES.
         self.lanes: int = max(1, int(os.environ.get("MI355VITS_LANES", "1") or 1))
+        # in-process multi-GPU (SURVEY.md §8f N2 "device round-robin"): the unchanged mimic3-server runs its
+        # --num-threads synthesis workers in ONE process on ONE shared session (mimic3_http/__main__.py:53-61,
+        # voice.py:277-292), so using the 8 GPUs of a node behind it means this session owns all of them.
+        # A list of device indices, or "all"; `lanes` is then per device, the weights are uploaded once per device and
+        # shared by its lanes, and every call goes to the least-loaded device.  None = one device (device_id /
+        # provider options / MI355VITS_DEVICE / LOCAL_RANK).  Also MI355VITS_DEVICES="0,1,2,3" or "all".
+        self.devices: Union[None, str, Sequence[int]] = os.environ.get("MI355VITS_DEVICES") or None
 
 
 class NodeArg:
@@ -86,7 +94,7 @@ def resolve_voice_file(path: Union[str, os.PathLike]) -> Union[str, bytes]:
             raise FileNotFoundError(f"{p} not found")
         return p
     cand = os.path.splitext(p)[0] + ".m355"
-    if os.path.isfile(cand) and (not os.path.isfile(p) or os.path.getmtime(cand) >= os.path.getmtime(p)):
+    if os.path.isfile(cand) and _container_belongs_to(cand, p):
         return cand
     if not os.path.isfile(p):
         raise FileNotFoundError(f"neither {p} nor {cand} found (see INTEGRATION.md)")
@@ -97,6 +105,29 @@ def resolve_voice_file(path: Union[str, os.PathLike]) -> Union[str, bytes]:
         return onnx_import.onnx_to_m355_bytes(blob, onnx_import.load_voice_config(p), p)
     except onnx_import.OnnxImportError as e:
         raise InvalidArgument(f"cannot load {p}: {e}") from e
+
+
+def _container_belongs_to(m355_path: str, onnx_path: str) -> bool:
+    """Explicit rule (no timestamps): the container stands in for ``onnx_path`` when that file is absent or an empty
+    placeholder, or when the container's trailer (``weights.source_record``) names exactly that file — same size and
+    same sha256.  A re-downloaded / replaced ``.onnx`` therefore falls back to in-memory conversion."""
+    if not os.path.isfile(onnx_path):
+        return True
+    size = os.path.getsize(onnx_path)
+    if size == 0:
+        return True
+    from . import weights as W
+
+    rec = W.read_source_record(m355_path)
+    if rec is None or rec[0] != size:
+        return False
+    import hashlib
+
+    h = hashlib.sha256()
+    with open(onnx_path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 22), b""):
+            h.update(chunk)
+    return h.digest() == rec[1]
 
 
 def _model_bytes(blob: bytes) -> bytes:
@@ -130,34 +161,86 @@ def _device_from_providers(providers, provider_options, sess_options) -> int:
     return dev
 
 
+def _resolve_devices(spec, default_device: int, library=None) -> List[int]:
+    """``SessionOptions.devices`` -> list of device indices (``None``: the single default device)."""
+    if spec is None or spec == "" or spec == []:
+        return [int(default_device)]
+    lib = library or _native.default_library()
+    n = lib.device_count()
+    if isinstance(spec, str):
+        if spec.strip().lower() == "all":
+            if n < 1:
+                raise RuntimeError("no HIP device available (the MI355X engine has no CPU fallback)")
+            return list(range(n))
+        try:
+            spec = [int(t) for t in spec.replace(";", ",").split(",") if t.strip() != ""]
+        except ValueError:
+            raise InvalidArgument(f"bad device list {spec!r} (expected e.g. '0,1,2,3' or 'all')") from None
+    devs = [int(d) for d in spec]
+    if not devs or len(set(devs)) != len(devs) or any(d < 0 or d >= n for d in devs):
+        raise InvalidArgument(f"bad device list {devs!r}: {n} device(s) visible")
+    return devs
+
+
 class _LanePool:
     """Engine handles shared by the caller threads, first come first served.  A released handle is handed straight to
     the longest-waiting caller (no barging): with plain lock / queue semantics a worker that has just finished can
-    grab the handle again before the notified waiter wakes up, and some callers starve for seconds under load."""
+    grab the handle again before the notified waiter wakes up, and some callers starve for seconds under load.
+    With several devices a caller gets a free lane on the device that has the fewest calls in flight (ties: the device
+    used least recently), so concurrent requests spread over the GPUs before they stack up on one."""
 
     def __init__(self, engines):
         from collections import deque
 
-        self._free = deque(engines)
+        self._free = list(engines)
         self._waiters = deque()
         self._lock = threading.Lock()
         self.size = len(engines)
+        self._busy: Dict[int, int] = {}
+        self._last_use: Dict[int, int] = {}
+        self._tick = 0
+        for e in engines:
+            self._busy.setdefault(e.device, 0)
+            self._last_use.setdefault(e.device, -1)
+        self.calls_per_device: Dict[int, int] = {d: 0 for d in self._busy}
+
+    def _take(self, eng):
+        self._tick += 1
+        self._busy[eng.device] += 1
+        self._last_use[eng.device] = self._tick
+        self.calls_per_device[eng.device] += 1
+        return eng
 
     def acquire(self):
         with self._lock:
             if self._free and not self._waiters:
-                return self._free.popleft()
+                best = min(range(len(self._free)), key=lambda i: (self._busy[self._free[i].device],
+                                                                    self._last_use[self._free[i].device], i))
+                return self._take(self._free.pop(best))
             slot = [None]
             ev = threading.Event()
             self._waiters.append((ev, slot))
-        ev.wait()
+        try:
+            ev.wait()
+        except BaseException:
+            # interrupted while queued: leave the queue, or give back the lane that was handed over meanwhile
+            with self._lock:
+                if slot[0] is None:
+                    try:
+                        self._waiters.remove((ev, slot))
+                    except ValueError:
+                        pass
+                    raise
+            self.release(slot[0])
+            raise
         return slot[0]
 
     def release(self, eng) -> None:
         with self._lock:
+            self._busy[eng.device] -= 1
             if self._waiters:
                 ev, slot = self._waiters.popleft()
-                slot[0] = eng
+                slot[0] = self._take(eng)
                 ev.set()
             else:
                 self._free.append(eng)
@@ -175,8 +258,10 @@ class _MicroBatcher:
 
     def __init__(self, session: "InferenceSession", window_s: float, max_batch: int):
         import queue
+        import weakref
 
-        self._session = session
+        # weak: the dispatcher thread must not keep a session (and its engines' HBM) alive after its last user is gone
+        self._session_ref = weakref.ref(session)
         self._window = window_s
         self._max = max(1, int(max_batch))
         self._q: "queue.Queue" = queue.Queue()
@@ -246,7 +331,11 @@ class _MicroBatcher:
                 lens[b] = n
             sid = None if group[0][3] is None else np.array([int(g[3][0]) for g in group], np.int64)
             kw = dict(group[0][4])
-            out = self._session._engine_run(ids, lens, group[0][2], sid, **kw)
+            session = self._session_ref()
+            if session is None:
+                raise RuntimeError("session closed")
+            out = session._engine_run(ids, lens, group[0][2], sid, **kw)
+            del session
             with self._count_lock:
                 self.batches += 1
                 self.requests += B
@@ -271,6 +360,20 @@ class _MicroBatcher:
 
     def close(self):
         self._q.put(None)
+        if self._thread is not threading.current_thread():
+            self._thread.join(timeout=5.0)
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)
+        # requests still queued get an error instead of hanging
+        import queue
+
+        while True:
+            try:
+                it = self._q.get_nowait()
+            except queue.Empty:
+                break
+            if it is not None and not it[5].done():
+                it[5].set_exception(RuntimeError("session closed"))
 
 
 class InferenceSession:
@@ -291,7 +394,22 @@ class InferenceSession:
             weights = resolve_voice_file(path_or_bytes)
             self._model_path = weights if isinstance(weights, str) else os.fspath(path_or_bytes)
         lanes = max(1, int(getattr(self._sess_options, "lanes", 1) or 1))
-        self._engines = [_native.Engine(weights, device=device, library=library) for _ in range(lanes)]
+        devices = _resolve_devices(getattr(self._sess_options, "devices", None), device, library)
+        # one weight upload per device; further lanes of a device share it (mi355vits_clone).  Lane-major order:
+        # consecutive handles sit on different devices.
+        firsts = []
+        try:
+            for d in devices:
+                firsts.append(_native.Engine(weights, device=d, library=library))
+            self._engines = list(firsts)
+            for _ in range(lanes - 1):
+                self._engines.extend(f.clone() for f in firsts)
+        except BaseException:
+            for e in firsts:
+                e.close()
+            raise
+        self.devices = list(devices)
+        self._closed = False
         self._engine = self._engines[0]
         self._free_lanes = _LanePool(self._engines)
         self.config: VitsConfig = self._engine.config
@@ -377,6 +495,8 @@ class InferenceSession:
         return out
 
     def _engine_run(self, ids, lengths, scales, sid, **kw) -> Dict[str, np.ndarray]:
+        if self._closed:
+            raise RuntimeError("session is closed")
         with self._lock:
             base = self._utterances
             self._utterances += ids.shape[0]
@@ -393,3 +513,26 @@ class InferenceSession:
     @property
     def engine(self) -> _native.Engine:
         return self._engine
+
+    def close(self) -> None:
+        """Stop the micro-batch dispatcher and release every lane (weights and workspaces in HBM).  Idempotent; also
+        runs when the session is garbage-collected."""
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        if self._batcher is not None:
+            self._batcher.close()
+        for e in self._engines:
+            e.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

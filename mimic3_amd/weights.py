@@ -20,6 +20,9 @@ Container layout (little endian), parsed by ``csrc/weights_file.cpp``::
     uint64   data_bytes
     pad to 64-byte file offset
     byte     data[data_bytes]        # float32
+    optional trailer (ignored by the engine; read by ``mimic3_amd.session.resolve_voice_file``):
+        char   tag[8] = "M355SRC1" ; uint64 source_bytes ; byte source_sha256[32]
+        — size and sha256 of the ``generator.onnx`` this container was converted from
 """
 from __future__ import annotations
 
@@ -36,6 +39,8 @@ from .config import CVitsConfig, VitsConfig
 
 MAGIC = b"M355VITS"
 VERSION = 1
+SOURCE_TAG = b"M355SRC1"
+SOURCE_TRAILER_BYTES = 8 + 8 + 32
 
 
 def tensor_specs(cfg: VitsConfig) -> "OrderedDict[str, Tuple[int, ...]]":
@@ -195,8 +200,29 @@ def check_weights(cfg: VitsConfig, weights: Dict[str, np.ndarray]) -> None:
             raise ValueError(f"tensor {n}: expected shape {shape}, got {got}")
 
 
-def pack(cfg: VitsConfig, weights: Dict[str, np.ndarray]) -> bytes:
-    """Serialise config + tensors into the ``.m355`` container."""
+def source_record(size: int, sha256_digest: bytes) -> bytes:
+    """Trailer naming the ``generator.onnx`` a container was converted from (size + sha256)."""
+    if len(sha256_digest) != 32:
+        raise ValueError("sha256 digest must be 32 bytes")
+    return SOURCE_TAG + struct.pack("<Q", int(size)) + bytes(sha256_digest)
+
+
+def read_source_record(path) -> "Tuple[int, bytes] | None":
+    """(size, sha256) of the source ``.onnx`` recorded in the container's trailer, or None if it has none."""
+    with open(path, "rb") as f:
+        f.seek(0, 2)
+        n = f.tell()
+        if n < SOURCE_TRAILER_BYTES + 8:
+            return None
+        f.seek(n - SOURCE_TRAILER_BYTES)
+        t = f.read(SOURCE_TRAILER_BYTES)
+    if t[:8] != SOURCE_TAG:
+        return None
+    return struct.unpack("<Q", t[8:16])[0], t[16:48]
+
+
+def pack(cfg: VitsConfig, weights: Dict[str, np.ndarray], source: "bytes | None" = None) -> bytes:
+    """Serialise config + tensors into the ``.m355`` container (``source``: optional :func:`source_record`)."""
     check_weights(cfg, weights)
     specs = tensor_specs(cfg)
     c = cfg.to_c()
@@ -226,7 +252,7 @@ def pack(cfg: VitsConfig, weights: Dict[str, np.ndarray]) -> bytes:
     data = bytearray(offset)
     for off, arr in blobs:
         data[off:off + arr.nbytes] = arr.tobytes()
-    return hb + b"\0" * pad + bytes(data)
+    return hb + b"\0" * pad + bytes(data) + (source or b"")
 
 
 def unpack(blob: bytes) -> Tuple[VitsConfig, Dict[str, np.ndarray]]:
@@ -270,9 +296,9 @@ def unpack(blob: bytes) -> Tuple[VitsConfig, Dict[str, np.ndarray]]:
     return cfg, weights
 
 
-def save(path, cfg: VitsConfig, weights: Dict[str, np.ndarray]) -> None:
+def save(path, cfg: VitsConfig, weights: Dict[str, np.ndarray], source: "bytes | None" = None) -> None:
     with open(path, "wb") as f:
-        f.write(pack(cfg, weights))
+        f.write(pack(cfg, weights, source))
 
 
 def load(path) -> Tuple[VitsConfig, Dict[str, np.ndarray]]:

@@ -326,6 +326,7 @@ class VitsOracle:
         noise_z: Optional[np.ndarray] = None,
         forced_durations: Optional[np.ndarray] = None,
         batch_semantics: str = "per_row",
+        stage_rows=None,
     ) -> Dict[str, np.ndarray]:
         """Restates ``onnx_model.run(None, {"input","input_lengths","scales"[,"sid"]})``
         (feed built at ``voice.py:180-218``; scales = [noise_scale, length_scale, noise_w]).
@@ -339,6 +340,9 @@ class VitsOracle:
         ``"per_row"`` (default) decodes every row over its own frames only, i.e. a batch equals B separate
         B = 1 calls — the contract of the drop-in.  ``"upstream"`` keeps the unmasked batch
         decode (used to cross-check against HF ``VitsModel``).
+        ``stage_rows``: rows whose per-stage decoder tensors (``dec.conv_pre``, ``dec.ups.i``, ``dec.mrf.i``) are
+        kept under ``"stages"`` as ``{row: {name: [C, T_row]}}`` (``per_row`` only; default: all rows, packed into
+        padded ``[B, C, T]`` arrays under the stage names as before) — at batch 32 x 768 frames the full set is 2.6 GB.
         Returns every intermediate the parity tests compare.
         """
         cfg = self.cfg
@@ -388,10 +392,15 @@ class VitsOracle:
         elif batch_semantics == "per_row":
             audio = torch.zeros(B, 1, Ty * cfg.upsample_factor, dtype=self.dtype)
             stages = {}
+            row_stages = {}
             for b in range(B):
                 nb = int(y_len[b])
                 ab, sb = self.decoder(zm[b:b + 1, :, :nb], None if g is None else g[b:b + 1], return_stages=True)
                 audio[b, :, : ab.shape[-1]] = ab[0]
+                if stage_rows is not None:
+                    if b in stage_rows:
+                        row_stages[b] = {k: v[0].detach().cpu().numpy() for k, v in sb.items()}
+                    continue
                 for k, v in sb.items():
                     if k not in stages:
                         f = v.shape[-1] // nb
@@ -406,6 +415,8 @@ class VitsOracle:
         out.update(stages)
         res = {k: v.detach().cpu().numpy() for k, v in out.items()}
         res["audio_lengths"] = (y_len * cfg.upsample_factor).numpy()
+        if stage_rows is not None and batch_semantics == "per_row" and B > 1:
+            res["stages"] = row_stages
         return res
 
 

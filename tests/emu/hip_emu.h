@@ -58,7 +58,13 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// MI355_EMU_DEVICES=N makes the CPU model report N identical "devices" (multi-device host logic tests)
+static inline hipError_t hipGetDeviceCount(int* n) {
+    const char* e = getenv("MI355_EMU_DEVICES");
+    const int v = e ? atoi(e) : 1;
+    *n = v >= 1 && v <= 64 ? v : 1;
+    return hipSuccess;
+}
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) {
     *p = nullptr;

@@ -124,18 +124,50 @@ def test_full_size_properties_b8_forced(gpu_lib):
     eng.close()
 
 
-def test_golden_shape_utterance(gpu_lib):
-    """Shape of the reference's golden utterance (tests/apope_sample_*.wav: 991 frames = 253,696 samples)."""
+def test_golden_shape_utterance_matches_oracle(gpu_lib):
+    """Shape of the reference's golden utterance (tests/apope_sample_*.wav: 991 frames = 253,696 samples) — the
+    bench's batch-1 latency workload (bench.py "latency_b1"), stochastic scales with injected noise, vs the oracle:
+    durations, encoder / prior / flow taps, every decoder stage, waveform, int16 (tests/samples_match.py criterion)."""
     cfg = VitsConfig.apope_low()
-    eng = Engine(W.pack(cfg, W.synthetic_weights(cfg, seed=1234)))
     Tx = 180
     ids = np.random.default_rng(99).integers(1, 50, (1, Tx)).astype(np.int64)
     forced = np.full((1, Tx), 5, np.int32)
     forced[0, :91] = 6  # 91*6 + 89*5 = 991 frames
-    out = eng.run(ids, [Tx], [0, 1, 0], forced_durations=forced, want_pcm16=True)
+    out, _ = check_parity(gpu_lib, cfg, ids=ids, forced=forced, noise=True, seed=99,
+                          weights=W.synthetic_weights(cfg, seed=1234))
     assert int(out["lengths"][0]) == 253696
     assert np.abs(out["pcm"]).max() >= 32766
-    eng.close()
+
+
+def _bench_batch(B, Tx, base=0):
+    from bench import make_batch  # the very ids bench.py times
+
+    return make_batch(B, Tx, base)
+
+
+def test_bench_workload_apope_low_b32_matches_oracle(gpu_lib):
+    """THE benchmarked configuration (bench.py default: en_UK/apope_low, 32 utterances x 128 ids, forced 6 frames/id,
+    scales [0.667, 1, 0.8]) against the oracle with both Gaussian draws injected: every row's waveform, int16, the
+    taps, and the decoder stages of three rows."""
+    cfg = VitsConfig.apope_low()
+    B, Tx = 32, 128
+    ids, lengths = _bench_batch(B, Tx)
+    forced = np.full((B, Tx), 6, np.int32)
+    out, _ = check_parity(gpu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=5,
+                          weights=W.synthetic_weights(cfg, seed=1234), stage_rows=(0, 13, 31))
+    assert list(out["lengths"]) == [768 * 256] * B
+
+
+def test_bench_workload_vctk_low_b32_matches_oracle(gpu_lib):
+    """BASELINE.json configs[2]: en_US/vctk_low (109 speakers, gin 512), 32 x 128 ids, sid = b mod 109 — the
+    `bench.py` "vctk_low_b32" line's workload — vs the oracle, injected noise."""
+    cfg = VitsConfig.vctk_low()
+    B, Tx = 32, 128
+    ids, lengths = _bench_batch(B, Tx)
+    forced = np.full((B, Tx), 6, np.int32)
+    sid = (np.arange(B) % cfg.n_speakers).astype(np.int64)
+    check_parity(gpu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=6, sid=sid,
+                 weights=W.synthetic_weights(cfg, seed=1234), stage_rows=(1, 30))
 
 
 def test_default_modelconfig_graph_matches_oracle(gpu_lib):

@@ -114,3 +114,62 @@ def test_fused_volume_on_the_device_equals_audioop_mul():
         rows, _ = sess.run_pcm16(feed, volume=vol)
         for r, b0 in zip(rows, base):
             assert np.array_equal(r, np.frombuffer(audioop.mul(b0.tobytes(), 2, vol / 100.0), dtype=np.int16))
+
+
+def test_lanes_share_one_weight_replica_and_devices_option(tmp_path):
+    """mi355vits_clone: lanes of one device share the weight upload (HBM use grows by workspaces only); the
+    multi-device option on a one-GPU box degenerates to devices == [0]; results do not depend on the lane."""
+    import torch
+
+    cfg = VitsConfig.vctk_low()
+    blob = W.pack(cfg, W.synthetic_weights(cfg, seed=8, frames_per_id=2.0))
+    so = SessionOptions()
+    so.devices = "all"
+    so.lanes = 3
+    so.seed = 11
+    free0 = torch.cuda.mem_get_info(0)[0]
+    sess = InferenceSession(blob, sess_options=so)
+    used = free0 - torch.cuda.mem_get_info(0)[0]
+    n_dev = torch.cuda.device_count()
+    assert sess.devices == list(range(n_dev)) and len(sess._engines) == 3 * n_dev
+    # 76.5 MB of weights (x ~2.4 with the packed copies) once per device, not once per lane
+    assert used < n_dev * 400e6, used
+    feed = {"input": np.random.default_rng(1).integers(1, 50, (2, 20)).astype(np.int64), "input_lengths": np.array([20, 13]),
+            "scales": np.array([0.0, 1.0, 0.0], np.float32), "sid": np.array([5, 77])}
+    outs = [sess._engines[k].run(feed["input"], feed["input_lengths"], feed["scales"], feed["sid"])["audio"] for k in range(len(sess._engines))]
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    sess.close()
+
+
+def test_device_side_gather_over_rccl_world_1():
+    """The optional result gather on the real stack: the engine's int16 result is wrapped in place (HBM) as a torch
+    tensor and moved with one RCCL gather — world_size 1 here (one GPU per box), so this checks the device-pointer
+    plumbing and the collective's dtype/shape handling; world_size 2 runs over gloo in the CPU suite."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from mimic3_amd import sharding
+    from mimic3_amd._native import Engine
+
+    cfg = VitsConfig.tiny()
+    eng = Engine(W.pack(cfg, W.synthetic_weights(cfg, seed=5)))
+    ids = np.random.default_rng(0).integers(1, 20, (3, 9)).astype(np.int64)
+    lens = np.array([9, 4, 7], np.int64)
+    ref = eng.run(ids, lens, [0.667, 1.0, 0.8], seed=3, want_float=False, want_pcm16=True)
+    eng.run(ids, lens, [0.667, 1.0, 0.8], seed=3, want_float=False, want_pcm16=True, device_only=True)
+    blk, ln = sharding.device_pcm_block(eng)
+    assert blk.is_cuda and blk.dtype == torch.int16 and tuple(blk.shape) == ref["pcm"].shape
+    assert np.array_equal(ln.numpy(), ref["lengths"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        full = sharding.gather_pcm(blk, ln, np.arange(3), 3)
+    finally:
+        dist.destroy_process_group()
+    for b in range(3):
+        assert np.array_equal(full[b], ref["pcm"][b, : int(ref["lengths"][b])])
+    eng.close()

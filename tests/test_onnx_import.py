@@ -200,17 +200,27 @@ def test_session_loads_the_onnx_file_directly(emu_lib, tmp_path, tiny_onnx):
     assert from_onnx.shape == ref.shape and from_onnx.shape[-1] > 0
     np.testing.assert_allclose(from_onnx, ref, rtol=0, atol=1e-5)  # weights equal to 2e-6 (weight-norm refold)
     np.testing.assert_array_equal(from_onnx, from_bytes)
-    # a converted container beside the model wins, unless it is older than the model
+    # a container WITHOUT a source record beside a real .onnx is ignored (nothing says it belongs to that file) ...
     W.save(str(d / "generator.m355"), cfg, w)
-    os.utime(d / "generator.onnx", (1, 1))
     s = InferenceSession(str(d / "generator.onnx"), _library=emu_lib)
-    assert s._model_path.endswith(".m355")
-    np.testing.assert_array_equal(s.run(None, feed)[0], ref)
+    assert s._model_path.endswith(".onnx")
+    # ... the one `python -m mimic3_amd.onnx_import` writes records the .onnx's size + sha256 and wins — whatever the
+    # file timestamps say (the rule is explicit, no mtime comparison) ...
+    assert OI.main([str(d / "generator.onnx")]) == 0
+    for stamp in ((1, 1), None):
+        os.utime(d / "generator.m355", stamp)
+        s = InferenceSession(str(d / "generator.onnx"), _library=emu_lib)
+        assert s._model_path.endswith(".m355")
+        np.testing.assert_array_equal(s.run(None, feed)[0], from_onnx)
+    # ... until the .onnx is replaced: the record no longer matches, so the (now broken) .onnx is what gets loaded
     (d / "generator.onnx").write_bytes(b"garbage")
-    os.utime(d / "generator.onnx", None)
-    os.utime(d / "generator.m355", (1, 1))
     with pytest.raises(InvalidArgument, match="cannot load"):
         InferenceSession(str(d / "generator.onnx"), _library=emu_lib)
+    # an empty placeholder .onnx (or none at all) always defers to the container
+    (d / "generator.onnx").write_bytes(b"")
+    assert InferenceSession(str(d / "generator.onnx"), _library=emu_lib)._model_path.endswith(".m355")
+    os.remove(d / "generator.onnx")
+    assert InferenceSession(str(d / "generator.onnx"), _library=emu_lib)._model_path.endswith(".m355")
 
 
 # ------------------------------------------------------------------------------------------------ robustness

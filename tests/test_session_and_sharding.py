@@ -215,41 +215,61 @@ def test_shard_bounds_and_balance():
 
 
 def _rank_main(rank, world, port, blob, tmpdir):
-    """One process per (emulated) GPU: shard the feed, synthesise locally, gather on rank 0 with gloo."""
+    """One process per (emulated) GPU: shard the feed, synthesise locally with the int16 result left in the engine's
+    buffer, gather the padded int16 blocks + lengths on rank 0 with ONE tensor gather (gloo here, RCCL on the GPUs)."""
     import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
     from mimic3_amd import build
-    from mimic3_amd._native import NativeLibrary
-    from mimic3_amd.session import InferenceSession as IS
+    from mimic3_amd._native import Engine, NativeLibrary
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = NativeLibrary(build.EMU_LIB)
-    so = SessionOptions()
-    so.seed = 1234
-    sess = IS(blob, sess_options=so, _library=lib)
+    eng = Engine(blob, library=lib)
     rng = np.random.default_rng(0)
     B, Tx = 5, 9
     ids = rng.integers(1, 20, (B, Tx)).astype(np.int64)
     lens = np.array([9, 4, 7, 9, 5], np.int64)
-    feed = {"input": ids, "input_lengths": lens, "scales": np.array([0.0, 1.0, 0.0], np.float32)}
-    local, rows = sharding.shard_feed(feed, world, rank)
-    out = sess.run(None, local)[0] if len(rows) else np.zeros((0, 1, 0), np.float32)
-    auds = [out[i, 0, : int(sess.last_lengths[i])] for i in range(len(rows))]
-    full = sharding.gather_results(auds, rows, B)
+    feed = {"input": ids, "input_lengths": lens, "scales": np.array([0.667, 1.0, 0.8], np.float32)}
+    local, rows = sharding.shard_feed(feed, world, rank, balance=True)
+    # Philox noise is keyed by the GLOBAL utterance index: rows are run one call each so that any split gives the
+    # same audio (a contiguous shard would pass utterance_base = first row instead)
+    blocks, lengths = [], []
+    for i, g in enumerate(rows):
+        eng.run(local["input"][i:i + 1], local["input_lengths"][i:i + 1], local["scales"], seed=1234, utterance_base=int(g),
+                want_float=False, want_pcm16=True, device_only=True)
+        blk, ln = sharding.device_pcm_block(eng)   # aliases the engine's result buffer: no host copy on the GPU path
+        blocks.append(blk.clone())
+        lengths.append(int(ln[0]))
+    import torch
+
+    L = max([b.shape[1] for b in blocks] + [1])
+    block = torch.zeros((len(blocks), L), dtype=torch.int16)
+    for i, b in enumerate(blocks):
+        block[i, : b.shape[1]] = b[0]
+    full = sharding.gather_pcm(block, lengths, rows, B)
+    assert (full is None) == (rank != 0)
     if rank == 0:
         np.savez(os.path.join(tmpdir, "gathered.npz"), **{f"a{i}": a for i, a in enumerate(full)})
+    # the ragged-list front end packs and calls the same collective
+    again = sharding.gather_results([np.asarray(block[i, : lengths[i]]) for i in range(len(rows))], rows, B)
+    if rank == 0:
+        assert all(np.array_equal(a, b) for a, b in zip(full, again))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_shard_and_gather_matches_single_process(emu_lib, tmp_path):
-    """world_size = 2 over gloo on CPU: the N > 1 path (shard -> per-rank engine -> optional gather)."""
+    """world_size = 2 over gloo on CPU: the N > 1 path (shard -> per-rank engine -> optional tensor gather of padded
+    int16 blocks).  Stochastic scales: the Philox draws depend on the global utterance index only, so the two-rank
+    result is bitwise the single-process one."""
     import socket
 
     import torch.multiprocessing as mp
+
+    from mimic3_amd._native import Engine
 
     cfg = VitsConfig.tiny()
     blob = W.pack(cfg, W.synthetic_weights(cfg, seed=5))
@@ -258,14 +278,164 @@ def test_two_rank_shard_and_gather_matches_single_process(emu_lib, tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_rank_main, args=(2, port, blob, str(tmp_path)), nprocs=2, join=True)
     got = np.load(tmp_path / "gathered.npz")
-    sess = InferenceSession(blob, _library=emu_lib)
+    eng = Engine(blob, library=emu_lib)
     rng = np.random.default_rng(0)
     ids = rng.integers(1, 20, (5, 9)).astype(np.int64)
     lens = np.array([9, 4, 7, 9, 5], np.int64)
-    ref = sess.run(None, {"input": ids, "input_lengths": lens, "scales": np.array([0.0, 1.0, 0.0], np.float32)})[0]
+    ref = eng.run(ids, lens, [0.667, 1.0, 0.8], seed=1234, utterance_base=0, want_float=False, want_pcm16=True)
     for b in range(5):
-        L = int(sess.last_lengths[b])
-        assert np.array_equal(got[f"a{b}"], ref[b, 0, :L])
+        L = int(ref["lengths"][b])
+        assert got[f"a{b}"].dtype == np.int16 and np.array_equal(got[f"a{b}"], ref["pcm"][b, :L])
+    eng.close()
+
+
+def test_in_process_multi_device_session_round_robin(tmp_path):
+    """SURVEY §8f N2 "device round-robin": ONE session (what the unchanged mimic3-server shares between its worker
+    threads, mimic3_http/__main__.py:53-61) over several devices — one weight replica per device, lanes spread over
+    them, every call on the least-loaded device, results independent of the device.  Runs on the CPU model of the
+    kernels with two emulated devices (MI355_EMU_DEVICES=2), in a subprocess so the setting cannot leak."""
+    import subprocess
+    import textwrap
+
+    code = textwrap.dedent("""
+        import os, sys, threading
+        import numpy as np
+        sys.path.insert(0, %r)
+        from mimic3_amd import build, weights as W
+        from mimic3_amd._native import NativeLibrary
+        from mimic3_amd.config import VitsConfig
+        from mimic3_amd.session import InferenceSession, InvalidArgument, SessionOptions
+
+        lib = NativeLibrary(build.EMU_LIB)
+        assert lib.device_count() == 2
+        cfg = VitsConfig.tiny()
+        blob = W.pack(cfg, W.synthetic_weights(cfg, seed=9))
+        feed = lambda n: {"input": np.arange(1, n + 1, dtype=np.int64)[None, :] %% 19 + 1, "input_lengths": np.array([n]),
+                          "scales": np.array([0, 1, 0], np.float32)}
+        one = InferenceSession(blob, _library=lib)
+        assert one.devices == [0]
+        so = SessionOptions(); so.devices = "all"; so.lanes = 2
+        multi = InferenceSession(blob, sess_options=so, _library=lib)
+        assert multi.devices == [0, 1] and [e.device for e in multi._engines] == [0, 1, 0, 1]
+        # sequential calls alternate devices (ties broken by least-recently-used) ...
+        for n in (5, 6, 7, 8):
+            assert np.array_equal(multi.run(None, feed(n))[0], one.run(None, feed(n))[0])
+        assert multi._free_lanes.calls_per_device == {0: 2, 1: 2}, multi._free_lanes.calls_per_device
+        # ... and concurrent ones spread: 4 lanes, 8 threads, nobody starves, both devices used
+        outs = {}
+        def work(k):
+            outs[k] = multi.run_pcm16(feed(4 + k %% 5))[0][0]
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        for k in range(8):
+            assert np.array_equal(outs[k], one.run_pcm16(feed(4 + k %% 5))[0][0])
+        c = multi._free_lanes.calls_per_device
+        assert c[0] + c[1] == 12 and min(c.values()) >= 4, c
+        # device list given explicitly / via the environment; bad lists are InvalidArgument
+        so2 = SessionOptions(); so2.devices = [1]
+        s2 = InferenceSession(blob, sess_options=so2, _library=lib)
+        assert s2.devices == [1] and s2._engines[0].device == 1
+        os.environ["MI355VITS_DEVICES"] = "1,0"
+        assert InferenceSession(blob, _library=lib).devices == [1, 0]
+        del os.environ["MI355VITS_DEVICES"]
+        for bad in ([0, 0], [2], "0,x"):
+            so3 = SessionOptions(); so3.devices = bad
+            try:
+                InferenceSession(blob, sess_options=so3, _library=lib)
+            except InvalidArgument:
+                pass
+            else:
+                raise AssertionError(bad)
+        # micro-batching on top: batches are dealt to the devices' lanes
+        so4 = SessionOptions(); so4.devices = "all"; so4.micro_batch_window_ms = 20.0
+        mb = InferenceSession(blob, sess_options=so4, _library=lib)
+        res = {}
+        def w2(k):
+            res[k] = mb.run_pcm16(feed(3 + k))[0][0]
+        ts = [threading.Thread(target=w2, args=(k,)) for k in range(6)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        for k in range(6):
+            assert np.array_equal(res[k], one.run_pcm16(feed(3 + k))[0][0])
+        for s in (one, multi, s2, mb):
+            s.close()
+        print("ok")
+    """ % ROOT)
+    env = dict(os.environ, MI355_EMU_DEVICES="2")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stdout + p.stderr
+
+
+def test_session_close_releases_engines_and_dispatcher(emu_lib):
+    """a session with micro-batching must be collectable — close() (also run by __del__) stops the
+    dispatcher thread, fails queued requests instead of hanging them, and destroys every lane."""
+    import gc
+    import threading
+    import weakref
+
+    cfg = VitsConfig.tiny()
+    blob = W.pack(cfg, W.synthetic_weights(cfg, seed=9))
+    so = SessionOptions()
+    so.micro_batch_window_ms = 1.0
+    so.lanes = 2
+    before = {t.name for t in threading.enumerate()}
+    sess = InferenceSession(blob, sess_options=so, _library=emu_lib)
+    feed = {"input": np.array([[3, 7, 1]], np.int64), "input_lengths": np.array([3]), "scales": np.array([0, 1, 0], np.float32)}
+    assert sess.run(None, feed)[0].shape[0] == 1
+    ref = weakref.ref(sess)
+    thread = sess._batcher._thread
+    del sess
+    gc.collect()
+    assert ref() is None, "the dispatcher thread kept the session alive"
+    thread.join(timeout=5.0)
+    assert not thread.is_alive()
+    # explicit close: idempotent, later calls raise
+    s2 = InferenceSession(blob, _library=emu_lib)
+    s2.close()
+    s2.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        s2.run(None, feed)
+    assert {t.name for t in threading.enumerate() if t.name.startswith("mi355vits-microbatch")} <= before
+
+
+def test_lane_pool_waiter_interrupted_does_not_swallow_a_lane():
+    """a caller interrupted while queued for a lane leaves the queue; a lane handed to it meanwhile goes
+    back to the pool."""
+    import threading
+
+    from mimic3_amd.session import _LanePool
+
+    class E:
+        device = 0
+
+    e = E()
+    pool = _LanePool([e])
+    assert pool.acquire() is e
+    got = []
+
+    class Boom(BaseException):
+        pass
+
+    def waiter():
+        real_event = threading.Event
+
+        class Ev(real_event):
+            def wait(self, timeout=None):  # interrupted as soon as it starts waiting
+                raise Boom()
+
+        threading.Event = Ev
+        try:
+            pool.acquire()
+        except Boom:
+            got.append("interrupted")
+        finally:
+            threading.Event = real_event
+
+    t = threading.Thread(target=waiter)
+    t.start()
+    t.join()
+    assert got == ["interrupted"] and len(pool._waiters) == 0
+    pool.release(e)
+    assert pool.idle() == 1 and pool.acquire() is e
 
 
 def test_fused_volume_equals_audioop_mul_and_wav_helpers(emu_lib):

@@ -32,28 +32,68 @@ def make_inputs(cfg: VitsConfig, B: int, Tx: int, seed: int = 0, ragged: bool = 
     return ids, lengths, sid
 
 
+def decoder_stage_names(cfg: VitsConfig):
+    names = ["dec.conv_pre"]
+    for i in range(len(cfg.upsample_rates)):
+        names += [f"dec.ups.{i}", f"dec.mrf.{i}"]
+    return names
+
+
+def check_decoder_stages(eng: Engine, cfg: VitsConfig, o1, rows=None):
+    """Per-stage decoder taps (conv_pre, every upsampler, every MRF stage) against the oracle's, over each row's own
+    frames: a compensating error between two stages cannot hide behind the end-to-end tolerance."""
+    y_len = o1["y_lengths"]
+    B = len(y_len)
+    rows = range(B) if rows is None else rows
+    worst = {}
+    for name in decoder_stage_names(cfg):
+        got = eng.tap(name)
+        for b in rows:
+            if "stages" in o1:
+                ref = o1["stages"][b][name]
+            else:
+                ref = o1[name][b]
+            f = got.shape[2] // int(o1["z"].shape[2])  # samples per latent frame at this stage
+            n = int(y_len[b]) * f
+            assert ref.shape[0] == got.shape[1] and ref.shape[1] >= n, (name, ref.shape, got.shape)
+            e = rel_rms(got[b, :, :n], ref[:, :n])
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e < REL_RMS_TOL, (name, b, e)
+    return worst
+
+
 def check_parity(lib, cfg: VitsConfig, B=2, Tx=9, seed=0, scales=(0.0, 1.0, 0.0), noise=False, forced=None,
-                 frames_per_id=2.5, taps=True, ragged=True, weights=None):
-    """Run engine and oracle on identical inputs; assert durations equal and waveforms within tolerance.
+                 frames_per_id=2.5, taps=True, ragged=True, weights=None, ids=None, lengths=None, sid=None,
+                 stage_rows=None, engine=None):
+    """Run engine and oracle on identical inputs; assert durations equal, every tapped intermediate (encoder output,
+    prior statistics, z_p, z, and the decoder's conv_pre / upsampler / MRF stages) and the waveforms within tolerance.
     Returns (engine output dict, oracle dict)."""
     w = weights if weights is not None else W.synthetic_weights(cfg, seed=seed + 100, frames_per_id=frames_per_id)
-    eng = Engine(W.pack(cfg, w), library=lib)
-    ids, lengths, sid = make_inputs(cfg, B, Tx, seed, ragged)
+    eng = engine if engine is not None else Engine(W.pack(cfg, w), library=lib)
+    if ids is None:
+        ids, lengths, sid_r = make_inputs(cfg, B, Tx, seed, ragged)
+        sid = sid if sid is not None else sid_r
+    else:
+        ids = np.asarray(ids, np.int64)
+        B, Tx = ids.shape
+        lengths = np.full(B, Tx, np.int64) if lengths is None else np.asarray(lengths, np.int64)
     rng = np.random.default_rng(seed + 7)
     kw = {}
+    ora = VitsOracle(cfg, w)
+    okw = dict(sid=sid, forced_durations=forced)
+    if stage_rows is not None and B > 1:
+        okw["stage_rows"] = list(stage_rows)
     if noise:
         scales = (0.667, scales[1], 0.8)
         kw["noise_w"] = rng.standard_normal((B, 2, Tx)).astype(np.float32)
-    ora = VitsOracle(cfg, w)
-    o1 = ora.infer(ids, lengths, scales, sid=sid, noise_w=kw.get("noise_w"),
-                   noise_z=None if not noise else np.zeros((B, cfg.inter_channels, 1), np.float32) , forced_durations=forced) \
-        if not noise else None
-    if noise:
-        # the frame count is needed to size noise_z: a first oracle pass with the duration noise only
-        pre = ora.infer(ids, lengths, (0.0, scales[1], scales[2]), sid=sid, noise_w=kw["noise_w"], forced_durations=forced)
-        Ty = int(pre["y_lengths"].max())
-        kw["noise_z"] = rng.standard_normal((B, cfg.inter_channels, Ty)).astype(np.float32)
-        o1 = ora.infer(ids, lengths, scales, sid=sid, noise_w=kw["noise_w"], noise_z=kw["noise_z"], forced_durations=forced)
+        if forced is not None:
+            Ty = int(np.max(np.sum(np.asarray(forced) * (np.arange(Tx)[None, :] < np.asarray(lengths)[:, None]), axis=1)))
+        else:
+            # the frame count is needed to size noise_z: a first oracle pass with the duration noise only
+            pre = ora.infer(ids, lengths, (0.0, scales[1], scales[2]), sid=sid, noise_w=kw["noise_w"], forced_durations=forced)
+            Ty = int(pre["y_lengths"].max())
+        kw["noise_z"] = rng.standard_normal((B, cfg.inter_channels, max(1, Ty))).astype(np.float32)
+    o1 = ora.infer(ids, lengths, scales, noise_w=kw.get("noise_w"), noise_z=kw.get("noise_z"), **okw)
     out = eng.run(ids, lengths, scales, sid, forced_durations=forced, want_pcm16=True, debug_taps=taps, **kw)
     assert np.array_equal(out["lengths"], o1["audio_lengths"]), (out["lengths"], o1["audio_lengths"])
     if taps:
@@ -69,6 +109,7 @@ def check_parity(lib, cfg: VitsConfig, B=2, Tx=9, seed=0, scales=(0.0, 1.0, 0.0)
                 ym = (np.arange(got.shape[2])[None, :] < o1["y_lengths"][:, None])[:, None, :]
                 got, ref = got * ym, ref * ym
             assert rel_rms(got, ref) < REL_RMS_TOL, (name, rel_rms(got, ref))
+        out["stage_errors"] = check_decoder_stages(eng, cfg, o1, rows=stage_rows)
     for b in range(B):
         L = int(out["lengths"][b])
         a, r = out["audio"][b, :L], o1["audio"][b, 0, :L]
@@ -81,7 +122,8 @@ def check_parity(lib, cfg: VitsConfig, B=2, Tx=9, seed=0, scales=(0.0, 1.0, 0.0)
         d = np.abs(out["pcm"][b, :L].astype(np.int32) - ref16.astype(np.int32))
         assert (d > 0).mean() <= INT16_DIFF_FRACTION_TOL and d.max() <= INT16_MAX_LSB, ((d > 0).mean(), d.max())
         assert np.all(out["pcm"][b, L:] == 0)
-    eng.close()
+    if engine is None:
+        eng.close()
     return out, o1
 
 
