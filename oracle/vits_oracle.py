@@ -389,6 +389,8 @@ class VitsOracle:
         zm = z * y_mask
         if batch_semantics == "upstream" or B == 1:
             audio, stages = self.decoder(zm, g, return_stages=True)  # [B,1,L]
+            if stage_rows is not None and 0 not in stage_rows:
+                stages = {}
         elif batch_semantics == "per_row":
             audio = torch.zeros(B, 1, Ty * cfg.upsample_factor, dtype=self.dtype)
             stages = {}

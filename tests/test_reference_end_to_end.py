@@ -1,9 +1,12 @@
 """Config 1 of BASELINE.json ("reference plumbing, no GPU") and SURVEY.md §8f N3: the reference's own, unmodified
 ``mimic3_tts`` package (imported from /root/reference) synthesises through the MI355X engine's ``onnxruntime`` shim.
 
-Only runs where /root/reference exists (this container; skipped on the GPU box).  Third-party packages the reference
-imports but that are not installed here are replaced by the test-only stand-ins in tests/refshim/.  The engine behind
-the shim is the CPU model of the kernels (tests/emu) — same sources as the product library.
+Only runs where the reference checkout exists: ``$MIMIC3_REFERENCE_DIR`` (default /root/reference — this container;
+the GPU box has no copy, and the reference's sources are never vendored into this repository, so there these tests
+skip with that reason).  Third-party packages the reference imports but that are not installed here are replaced by
+the test-only stand-ins in tests/refshim/.  Two engines behind the shim: the CPU model of the kernels (tests/emu, same
+sources as the product library) in the ``-m "not gpu"`` suite, and — ``-m gpu`` variant at the bottom — the HIP library
+itself on an MI355X, for whichever machine has both a GPU and the reference tree.
 """
 import importlib
 import io
@@ -21,12 +24,13 @@ from mimic3_amd.config import VitsConfig
 from oracle.vits_oracle import VitsOracle, audio_float_to_int16
 from tests.onnx_fixture import export_onnx
 
-REFERENCE = "/root/reference"
+REFERENCE = os.environ.get("MIMIC3_REFERENCE_DIR", "/root/reference")
 REFSHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refshim")
 SYMBOLS = ["_", "#", "a", "b", "c", "d", "e", "f", "g", "h", "i", "k", "l", "m", "n", "o", "r", "s", "t", "u"]
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "mimic3_tts")),
-                                reason="the reference checkout is only present in the build container")
+                                reason="no reference checkout here (set MIMIC3_REFERENCE_DIR; the GPU lease only receives "
+                                       "this repository and the reference's sources are never copied into it)")
 
 
 def _write_voice(root, cfg, weights, name="tiny_low", lang="en_UK", speakers=None):
@@ -46,25 +50,43 @@ def _write_voice(root, cfg, weights, name="tiny_low", lang="en_UK", speakers=Non
     return d
 
 
-@pytest.fixture
-def reference(emu_lib, monkeypatch, tmp_path):
-    """Import the unmodified reference with the shim registered as `onnxruntime` (INTEGRATION.md option A)."""
+def _import_reference(monkeypatch, tmp_path, library):
+    """Import the unmodified reference with the shim registered as `onnxruntime` (INTEGRATION.md option A);
+    ``library``: the CPU model of the kernels, or None for the product's own HIP library."""
     monkeypatch.syspath_prepend(REFSHIM)
     monkeypatch.syspath_prepend(REFERENCE)
     monkeypatch.setenv("XDG_DATA_HOME", str(tmp_path / "xdg"))
     monkeypatch.setenv("XDG_DATA_DIRS", str(tmp_path / "xdg-dirs"))
-    monkeypatch.setattr(_native, "default_library", lambda: emu_lib)  # no GPU in this container: CPU model of the kernels
+    if library is not None:
+        monkeypatch.setattr(_native, "default_library", lambda: library)  # no GPU in this container
     import mimic3_amd.onnxruntime_shim as shim
 
     monkeypatch.setitem(sys.modules, "onnxruntime", shim.install())
     before = set(sys.modules)
     mimic3_tts = importlib.import_module("mimic3_tts")
-    yield mimic3_tts
-    mimic3_tts.voice.Mimic3Voice._SHARED_MODELS.clear()
-    for m in set(sys.modules) - before:
-        if m.split(".")[0] in ("mimic3_tts", "opentts_abc", "dataclasses_json", "xdgenvpy", "gruut_ipa", "phonemes2ids",
-                               "gruut", "epitran", "espeak_phonemizer"):
-            sys.modules.pop(m, None)
+
+    def cleanup():
+        mimic3_tts.voice.Mimic3Voice._SHARED_MODELS.clear()
+        for m in set(sys.modules) - before:
+            if m.split(".")[0] in ("mimic3_tts", "opentts_abc", "dataclasses_json", "xdgenvpy", "gruut_ipa", "phonemes2ids",
+                                   "gruut", "epitran", "espeak_phonemizer"):
+                sys.modules.pop(m, None)
+
+    return mimic3_tts, cleanup
+
+
+@pytest.fixture
+def reference(emu_lib, monkeypatch, tmp_path):
+    mod, cleanup = _import_reference(monkeypatch, tmp_path, emu_lib)
+    yield mod
+    cleanup()
+
+
+@pytest.fixture
+def reference_on_gpu(monkeypatch, tmp_path):
+    mod, cleanup = _import_reference(monkeypatch, tmp_path, None)
+    yield mod
+    cleanup()
 
 
 def _expected_ids(text):
@@ -78,6 +100,20 @@ def _expected_ids(text):
 
 
 def test_unmodified_reference_speaks_through_the_engine(reference, tmp_path):
+    _speaks_through_the_engine(reference, tmp_path)
+
+
+@pytest.mark.gpu
+def test_unmodified_reference_speaks_through_the_hip_library(reference_on_gpu, tmp_path):
+    """N3 on the device: the same unmodified ``mimic3_tts`` run, the session behind it being libmi355vits.so on an
+    MI355X (needs a machine with both a GPU and the reference checkout: MIMIC3_REFERENCE_DIR)."""
+    from mimic3_amd._native import default_library
+
+    assert "gfx950" in default_library().version()
+    _speaks_through_the_engine(reference_on_gpu, tmp_path)
+
+
+def _speaks_through_the_engine(reference, tmp_path):
     cfg = VitsConfig.tiny()
     assert cfg.num_symbols == len(SYMBOLS)
     w = W.synthetic_weights(cfg, seed=21, frames_per_id=3.0)
