@@ -130,6 +130,17 @@ int mi355vits_create_from_buffer(const void* blob, size_t blob_bytes, int device
  * threads (voice.py:277-292, mimic3_http/__main__.py:53-61); lanes are how those concurrent `run` calls overlap. */
 int mi355vits_clone(mi355vits_handle src, mi355vits_handle* out);
 void mi355vits_destroy(mi355vits_handle h);
+/* Which matrix-core path the dense Conv1d stacks take on this handle (default: environment MI355VITS_MATH, else F32):
+ *   MI355VITS_MATH_F32     v_mfma_f32_32x32x2_f32 — f32 operands, bit-exact f32 FMA chains;
+ *   MI355VITS_MATH_BF16X3  the f32 operands split exactly into three bf16 terms each (x = h + m + l) and the six leading
+ *                          partial products on v_mfma_f32_32x32x16_bf16 with f32 accumulation: every retained product is
+ *                          exact, the dropped ones are below 2^-24 relative — f32-grade results (parity tolerances
+ *                          unchanged) at 6/16 of the f32 MFMA's time.  What onnxruntime's f32 kernels compute, to rounding.
+ * Results of the two differ at f32 rounding level (like two f32 BLAS builds); each is deterministic. */
+#define MI355VITS_MATH_F32 0
+#define MI355VITS_MATH_BF16X3 1
+int mi355vits_set_math(mi355vits_handle h, int mode);
+int mi355vits_get_math(mi355vits_handle h);
 int mi355vits_get_config(mi355vits_handle h, mi355vits_config* out);
 
 /* One synthesis call.  `out` is filled with callee-allocated (pinned) host buffers; release

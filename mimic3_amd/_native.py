@@ -27,7 +27,7 @@ DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libmi355vits.so")
 # every symbol include/mi355vits.h declares
 EXPORTED_SYMBOLS = (
     "mi355vits_version", "mi355vits_device_count", "mi355vits_create", "mi355vits_create_from_buffer", "mi355vits_clone", "mi355vits_destroy",
-    "mi355vits_device_result",
+    "mi355vits_device_result", "mi355vits_set_math", "mi355vits_get_math",
     "mi355vits_get_config", "mi355vits_run", "mi355vits_fetch", "mi355vits_free_result",
     "mi355vits_last_error", "mi355vits_profile_enable", "mi355vits_profile_reset",
     "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_list_taps",
@@ -112,6 +112,8 @@ class NativeLibrary:
         L.mi355vits_device_result.argtypes = [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                               ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32),
                                               ctypes.POINTER(ctypes.c_void_p)]
+        L.mi355vits_set_math.argtypes = [H, ctypes.c_int]
+        L.mi355vits_get_math.argtypes = [H]
         L.mi355vits_destroy.argtypes = [H]
         L.mi355vits_destroy.restype = None
         L.mi355vits_get_config.argtypes = [H, ctypes.POINTER(CVitsConfig)]
@@ -337,6 +339,17 @@ class Engine:
         self._check(self.native.lib.mi355vits_run(self._h, ctypes.byref(a), ctypes.byref(r)))
         del keep
         return self._take(r)
+
+    MATH_MODES = {"f32": 0, "bf16x3": 1}
+
+    def set_math(self, mode) -> None:
+        """``"f32"`` (f32 MFMA) or ``"bf16x3"`` (f32 operands split 3 x bf16, six bf16-MFMA products, f32 accumulate)."""
+        self._check(self.native.lib.mi355vits_set_math(self._h, self.MATH_MODES.get(mode, mode)))
+
+    @property
+    def math(self) -> str:
+        m = int(self.native.lib.mi355vits_get_math(self._h))
+        return {v: k for k, v in self.MATH_MODES.items()}.get(m, str(m))
 
     def clone(self) -> "Engine":
         """Another lane on this engine's device: own stream + workspace, shared weights."""

@@ -128,6 +128,17 @@ void mi355vits_destroy(mi355vits_handle h) {
     delete h;
 }
 
+int mi355vits_set_math(mi355vits_handle h, int mode) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    return guarded(h, [&] { h->eng->set_math(mode); });
+}
+int mi355vits_get_math(mi355vits_handle h) {
+    if (!h) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    return h->eng->math();
+}
+
 int mi355vits_get_config(mi355vits_handle h, mi355vits_config* out) {
     if (!h) return MI355VITS_ERR_INVALID;
     return guarded(h, [&] {

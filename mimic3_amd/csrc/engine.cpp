@@ -219,6 +219,13 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             regroup_packed_x4(pk.data(), pk.size(), p4.data());
             c.packed4 = stage(p4.data(), p4.size());
         }
+        if (key.rfind("dec.rb.", 0) == 0 && epi == EPI_STD && Cin % 16 == 0 && Cout % 32 == 0) {
+            // the same weights as three bf16 planes for the split-operand path (MATH_BF16X3)
+            std::vector<uint32_t> b3(bf16x3_packed_words(Cout, Cin, K));
+            pack_conv_weights_bf16x3(w.data(), Cout, Cin, K, b3.data());
+            static_assert(sizeof(uint32_t) == sizeof(float), "bit patterns travel in the float arena");
+            c.packed_b3 = stage(reinterpret_cast<const float*>(b3.data()), b3.size());
+        }
     }
     return model_->convs[key] = c;
 }
@@ -325,6 +332,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
     try {
         open_device(device_);
         model_ = lane0.model_;
+        math_ = lane0.math_;
     } catch (...) {
         release();
         throw;
@@ -347,6 +355,17 @@ void Engine::open_device(int device) {
     no_fused_wn_ = nw && nw[0] == '1';
     const char* nf = getenv("MI355VITS_NO_FUSED_MRF");
     no_fused_mrf_ = nf && nf[0] == '1';
+    const char* mm = getenv("MI355VITS_MATH");
+    if (mm && mm[0]) {
+        if (!strcmp(mm, "bf16x3")) math_ = MATH_BF16X3;
+        else if (!strcmp(mm, "f32")) math_ = MATH_F32;
+        else throw EngineError(MI355VITS_ERR_INVALID, std::string("MI355VITS_MATH: unknown mode '") + mm + "' (f32 | bf16x3)");
+    }
+}
+
+void Engine::set_math(int mode) {
+    if (mode != MATH_F32 && mode != MATH_BF16X3) throw EngineError(MI355VITS_ERR_INVALID, "unknown math mode");
+    math_ = mode;
 }
 
 void Engine::construct(const WeightsFile& wf, int device) {
@@ -900,10 +919,14 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 while (p > 0 && !(mrf_fused_supported(ch, p, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF)) --p;
                 if (p > 0) {
                     double flops = 0;
+                    bool b3 = math_ == MATH_BF16X3;
+                    for (int j = 0; j < p; ++j)
+                        for (int q = 0; q < 2; ++q) b3 = b3 && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3 != NO_OFF;
+                    m.math = b3 ? MATH_BF16X3 : MATH_F32;
                     for (int j = 0; j < p; ++j) {
                         for (int q = 0; q < 2; ++q) {
                             const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
-                            m.w[j][q] = P(w.packed4);
+                            m.w[j][q] = P(b3 ? w.packed_b3 : w.packed4);
                             m.bias[j][q] = P(w.bias);
                         }
                         flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];

@@ -91,6 +91,7 @@ struct ConvW {
     size_t raw = NO_OFF;     // [Cout,Cin,K]
     size_t packed = NO_OFF;  // MFMA fragment order (absent when Cin is odd)
     size_t packed4 = NO_OFF; // same records regrouped [tile][tap][4 pairs][lane][4] for 16-byte A loads (fused MRF stage)
+    size_t packed_b3 = NO_OFF;  // three bf16 planes in bf16-MFMA fragment order (pack_conv_weights_bf16x3), 32-bit words
     size_t bias = NO_OFF;
     int Cout = 0, Cin = 0, K = 1;
     int epi = EPI_STD;  // tile map the packed copy was built for
@@ -122,6 +123,8 @@ class Engine {
     void run(const mi355vits_run_args& args, mi355vits_result* out);
     void fetch(uint32_t want, mi355vits_result* out);
     const mi355vits_config& config() const { return cfg_; }
+    void set_math(int mode);
+    int math() const { return math_; }
     Profiler& profiler() { return prof_; }
     float last_run_ms();
     long get_tap(const std::string& name, float* out, size_t cap, int64_t dims[4]);
@@ -159,6 +162,7 @@ class Engine {
     hipEvent_t ev_start_ = nullptr, ev_end_ = nullptr;
     bool timed_ = false;
     bool force_generic_ = false;
+    int math_ = MATH_F32;        // which matrix-core path the dense convs take (include/mi355vits.h: MI355VITS_MATH_*)
     bool no_fused_wn_ = false;   // MI355VITS_NO_FUSED_WN=1: in-layer + res/skip as two launches (A/B + fallback)
     bool no_fused_mrf_ = false;  // MI355VITS_NO_FUSED_MRF=1: conv-by-conv resblocks (A/B + fallback)
     Profiler prof_;

@@ -12,6 +12,8 @@ typedef hipemu_f32x16 f32x16;
 typedef hipemu_f32x4 f32x4;
 #define MFMA_32x32x2_F32(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
 #define MFMA_16x16x4_F32(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
+#define MFMA_32x32x16_BF16(a, b, c) hipemu_mfma_32x32x16_bf16((a), (b), (c))
+#define CVT_PK_BF16_F32(lo, hi) hipemu_cvt_pk_bf16_f32((lo), (hi))
 #define LAUNCH_KERNEL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((kernel), (grid), (block), (size_t)(shmem), __VA_ARGS__)
 #define DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu::tl_worker->dyn_smem)
@@ -27,6 +29,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA_32x32x2_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA_16x16x4_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_32x32x16_bf16: a / b = eight bf16 per lane (four VGPRs, passed as uint4 bit patterns), f32 accumulate.
+// Lane l holds row (A) / column (B) l & 31 and the eight k-slots of half l >> 5; products are exact, sums are f32.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+#define MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), (c), 0, 0, 0)
+// v_cvt_pk_bf16_f32: two f32 -> two bf16 (round to nearest even) in one register, `lo` in bits [15:0]
+__device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+#define CVT_PK_BF16_F32(lo, hi) cvt_pk_bf16_f32((lo), (hi))
 #define LAUNCH_KERNEL(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
 // All LDS scratch lives in the dynamic region, base 16-byte aligned (cdna guide, Guideline 17).
@@ -183,6 +198,27 @@ __device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long
             reinterpret_cast<float4*>(dst)[gb * LD + 4 * c4 + j] =
                 make_float4(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope));
     }
+}
+
+// ---- f32 operands on the bf16 matrix cores ---------------------------------------------------------------------------
+// x = h + m + l exactly, each a bf16 (8-bit significand): h = rne(x), m = rne(x - h), l = rne(x - h - m); both
+// subtractions are exact in f32.  With both operands of a product split this way, the six leading partial products
+// (hh, hm, mh, mm, hl, lh) carry everything down to 2^-24 relative — the f32 rounding level — and the bf16 MFMA forms
+// each product exactly and sums in f32: f32-grade results at 6/16 of the f32 MFMA's time (MI355X: bf16 MFMA = 16x f32).
+// One pair of elements -> one packed register per plane: 3 cvt_pk + 4 bit ops + 4 subtractions.
+__device__ __forceinline__ void split3_pk(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    h = CVT_PK_BF16_F32(a0, a1);
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    m = CVT_PK_BF16_F32(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = CVT_PK_BF16_F32(s0, s1);
+}
+// eight k-slots of one lane (two packed-tile float4: channels 16G + brow + 2e | 16G + 8 + brow + 2e) -> three planes
+__device__ __forceinline__ void split3_x8(const float4& lo4, const float4& hi4, uint4& h, uint4& m, uint4& l) {
+    split3_pk(lo4.x, lo4.y, h.x, m.x, l.x);
+    split3_pk(lo4.z, lo4.w, h.y, m.y, l.y);
+    split3_pk(hi4.x, hi4.y, h.z, m.z, l.z);
+    split3_pk(hi4.z, hi4.w, h.w, m.w, l.w);
 }
 
 __device__ __forceinline__ void stage_tile_256(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,

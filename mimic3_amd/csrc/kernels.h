@@ -51,6 +51,13 @@ bool conv1d_mfma_supported(int Cin, int Cout, int K, int dil);
 size_t mfma_packed_floats(int Cout, int Cin, int K);
 void pack_conv_weights_mfma(const float* w, int Cout, int Cin, int K, float* out);
 void regroup_packed_x4(const float* packed, size_t n_floats, float* out);  // fused MRF stage weights (Cin % 8 == 0)
+// f32 weights split into three bf16 planes (w = h + m + l exactly, each rounded to nearest) in the A-fragment order of
+// v_mfma_f32_32x32x16_bf16: [Cout/32][K][Cin/16][plane h,m,l][64 lanes][8 bf16]; lane l = (half l >> 5, row l & 31)
+// holds the k-slots e < 4: channel 16G + half + 2e, e >= 4: 16G + 8 + half + 2(e - 4) — the channels a lane's two
+// ds_read_b128 of a packed activation tile deliver.  Needs Cin % 16 == 0 and Cout % 32 == 0; sizes in 32-bit words.
+enum MathMode { MATH_F32 = 0, MATH_BF16X3 = 1 };
+size_t bf16x3_packed_words(int Cout, int Cin, int K);
+void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out);
 // epi = EPI_GATE packs rows as (c, H + c) tile pairs (H = Cout / 2); otherwise identical to the above.
 void pack_conv_weights_mfma_mode(const float* w, int Cout, int Cin, int K, int epi, float* out);
 
@@ -79,7 +86,8 @@ constexpr int MRF_MAX_RB = 4;
 struct MrfArgs {
     const float* x = nullptr; long x_bs = 0; int x_ld = 0;
     float* y = nullptr; long y_bs = 0; int y_ld = 0;
-    const float* w[MRF_MAX_RB][2] = {};     // MFMA-packed [C/32][K][C/2][64]
+    const float* w[MRF_MAX_RB][2] = {};     // math 0: MFMA-packed x4 [C/32][K][C/8][64][4]; math 1: pack_conv_weights_bf16x3
+    int math = 0;                           // MATH_F32 / MATH_BF16X3 (which matrix-core path; the weights must match)
     const float* bias[MRF_MAX_RB][2] = {};
     int k[MRF_MAX_RB] = {}, d1[MRF_MAX_RB] = {}, d2[MRF_MAX_RB] = {};
     int nrb = 0;

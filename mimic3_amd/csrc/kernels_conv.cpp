@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <cstring>
+
 #include "kernels.h"
 
 namespace m355 {
@@ -284,6 +286,46 @@ void regroup_packed_x4(const float* packed, size_t n_floats, float* out) {
     for (size_t r = 0; r < recs; ++r)
         for (int l = 0; l < 64; ++l) out[((r >> 2) * 64 + l) * 4 + (r & 3)] = packed[r * 64 + l];
 }
+size_t bf16x3_packed_words(int Cout, int Cin, int K) { return (size_t)(Cout / 32) * K * (Cin / 16) * 3 * 64 * 4; }
+
+static inline uint32_t bf16_rne_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+static inline float bf16_bits_to_float(uint32_t b) {
+    const uint32_t u = b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out) {
+    const int ng = Cin / 16;
+    for (int tile = 0; tile < Cout / 32; ++tile)
+        for (int k = 0; k < K; ++k)
+            for (int g = 0; g < ng; ++g)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = tile * 32 + (l & 31), half = l >> 5;
+                    uint32_t plane[3][8];
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 16 * g + (e < 4 ? 0 : 8) + half + 2 * (e & 3);
+                        const float v = w[((size_t)co * Cin + ci) * K + k];
+                        const uint32_t h = bf16_rne_bits(v);
+                        const float r1 = v - bf16_bits_to_float(h);
+                        const uint32_t m = bf16_rne_bits(r1);
+                        const float r2 = r1 - bf16_bits_to_float(m);
+                        plane[0][e] = h; plane[1][e] = m; plane[2][e] = bf16_rne_bits(r2);
+                    }
+                    for (int p = 0; p < 3; ++p) {
+                        uint32_t* o = out + (((((size_t)tile * K + k) * ng + g) * 3 + p) * 64 + l) * 4;
+                        for (int j = 0; j < 4; ++j) o[j] = plane[p][2 * j] | (plane[p][2 * j + 1] << 16);
+                    }
+                }
+}
+
 void pack_conv_weights_mfma(const float* w, int Cout, int Cin, int K, float* out) {
     pack_conv_weights_mfma_mode(w, Cout, Cin, K, EPI_STD, out);
 }

@@ -73,13 +73,82 @@ __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float4*
     }
 }
 
+// The same share of a conv with the f32 operands split into three bf16 planes each (hipx.h: split3) and the six leading
+// partial products on the bf16 matrix cores — f32-grade results at 6/16 of the f32 MFMA's time.  The LDS tiles are the
+// same packed f32 tiles: a lane's eight k-slots of a 16-channel group are two ds_read_b128 (channels 16G + brow + 2e and
+// 16G + 8 + brow + 2e), split in registers; the weights come pre-split ([tile][tap][16-ch group][plane][lane] x 16 B,
+// pack_conv_weights_bf16x3).  A planes and the raw B floats are fetched one group ahead.
+template <int NTL, int NA, int CP>
+__device__ __forceinline__ void mfma_conv_tiles_b3(f32x16 (&acc)[NA], const uint4* __restrict__ wp, const float4* __restrict__ x4,
+                                                   int tstride, int LD, int K, int dil, int ablate) {
+    static_assert(NTL <= NA, "tile count");
+    static_assert(CP % 16 == 0, "channel pairs per tap must be a multiple of 16");
+    if (ablate & 1) return;
+    constexpr int NG = CP / 8;  // 16-channel groups per tap (even)
+    uint4 ra[2][3];
+    MI355_UNROLL
+    for (int p = 0; p < 3; ++p) ra[0][p] = wp[p * 64];
+    float4 xb[2][NTL][2];
+    MI355_UNROLL
+    for (int i = 0; i < NTL; ++i) {
+        xb[0][i][0] = x4[i * tstride];
+        xb[0][i][1] = x4[i * tstride + 2 * LD];
+    }
+    for (int k = 0; k < K; ++k) {
+        const uint4* wk = wp + (long)k * NG * 192;
+        const float4* xk = x4 + k * dil;
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            // next group's operands (the very last iteration re-reads its own: every load stays unconditional)
+            const uint4* wa = (last_tap && g + 1 >= NG) ? wk + g * 192 : wk + (g + 1) * 192;
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) ra[(g + 1) & 1][p] = wa[p * 64];
+            const float4* xn = (g + 1 < NG) ? xk + (g + 1) * 4 * LD : (last_tap ? xk + g * 4 * LD : xk + dil);
+            MI355_UNROLL
+            for (int i = 0; i < NTL; ++i) {
+                xb[(g + 1) & 1][i][0] = xn[i * tstride];
+                xb[(g + 1) & 1][i][1] = xn[i * tstride + 2 * LD];
+            }
+            SCHED_FENCE();  // the prefetches stay ahead of this group's arithmetic (hipcc would sink them to their use)
+            const uint4 ah = ra[g & 1][0], am = ra[g & 1][1], al = ra[g & 1][2];
+            MI355_UNROLL
+            for (int i = 0; i < NTL; ++i) {
+                uint4 bh, bm, bl;
+                split3_x8(xb[g & 1][i][0], xb[g & 1][i][1], bh, bm, bl);
+                // small terms first
+                acc[i] = MFMA_32x32x16_BF16(al, bh, acc[i]);
+                acc[i] = MFMA_32x32x16_BF16(ah, bl, acc[i]);
+                acc[i] = MFMA_32x32x16_BF16(am, bm, acc[i]);
+                acc[i] = MFMA_32x32x16_BF16(am, bh, acc[i]);
+                acc[i] = MFMA_32x32x16_BF16(ah, bm, acc[i]);
+                acc[i] = MFMA_32x32x16_BF16(ah, bh, acc[i]);
+            }
+            SCHED_FENCE();
+        }
+    }
+}
+
+// weight fragments of row tile `wm` of a conv, lane offset included, and the matching inner loop
+template <int MATH, int NTL, int NA, int CP>
+__device__ __forceinline__ void conv_tiles(f32x16 (&acc)[NA], const float* __restrict__ w, int wm, int lane, const float4* __restrict__ x4,
+                                           int tstride, int LD, int K, int dil, int ablate) {
+    if constexpr (MATH == 1) {
+        const uint4* wp = reinterpret_cast<const uint4*>(w) + (long)wm * K * (CP / 8) * 192 + lane;
+        mfma_conv_tiles_b3<NTL, NA, CP>(acc, wp, x4, tstride, LD, K, dil, ablate);
+    } else {
+        const float4* wp = reinterpret_cast<const float4*>(w + (long)wm * K * CP * 64) + lane;
+        mfma_conv_tiles<NTL, NA, CP>(acc, wp, x4, tstride, LD, K, dil, ablate);
+    }
+}
+
 // inverse of leaky-relu(0.1) up to one rounding: the LDS tiles keep activated values, the residual needs the raw one
 __device__ __forceinline__ float unlrelu(float v) { return v >= 0.0f ? v : v * 10.0f; }
 
 // conv1 of a resblock, MFMA part, for a wave that owns NTL column tiles q = wt + WT*i of the extended range:
 // acc = x + bias + conv(lrelu(x)).  Reads only the X tile, so it may run before the barrier that releases X1.
-template <int NTL, int NA, int CP, int WT>
-__device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float4* __restrict__ wp, const float* bs /*LDS*/,
+template <int MATH, int NTL, int NA, int CP, int WT>
+__device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float* __restrict__ w, const float* bs /*LDS*/,
                                                   const float* X, int LDX, int R, int r1, int r2, int K, int d1, int wm,
                                                   int wt, int brow, int bcol, int ablate) {
     MI355_UNROLL
@@ -92,13 +161,13 @@ __device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float
         }
     }
     const float4* xw = reinterpret_cast<const float4*>(X) + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
-    mfma_conv_tiles<NTL, NA, CP>(acc, wp, xw, WT * 32, LDX, K, d1, ablate);
+    conv_tiles<MATH, NTL, NA, CP>(acc, w, wm, brow * 32 + bcol, xw, WT * 32, LDX, K, d1, ablate);
 }
 
 // conv2 for a wave that owns NTL output tiles p = wt + WT*i:  out += x1 + bias + conv(lrelu(x1)), accumulated
 // straight into the wave's persistent output registers (no epilogue).
-template <int NTL, int NA, int CP, int WT>
-__device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float4* __restrict__ wp, const float* bs /*LDS*/,
+template <int MATH, int NTL, int NA, int CP, int WT>
+__device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __restrict__ w, const float* bs /*LDS*/,
                                           const float* X1, int LD1, int r2, int K, int d2, int wm, int wt, int brow, int bcol, int ablate) {
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
@@ -110,7 +179,7 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float4* __res
         }
     }
     const float4* xw = reinterpret_cast<const float4*>(X1) + brow * LD1 + bcol + wt * 32;
-    mfma_conv_tiles<NTL, NA, CP>(out, wp, xw, WT * 32, LD1, K, d2, ablate);
+    conv_tiles<MATH, NTL, NA, CP>(out, w, wm, brow * 32 + bcol, xw, WT * 32, LD1, K, d2, ablate);
 }
 
 // WM x WT = 8 waves (two per SIMD).  Output tile T_B = 32 * N2 columns; column tiles of both convs are dealt
@@ -119,7 +188,8 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float4* __res
 // finishes its conv2 share early flows straight into the next MFMA stream instead of idling at a barrier.
 // LDXC / LD1C: row pitches of the two LDS tiles when known at compile time (the "_low" voices' stage shapes): every
 // ds_read of an unrolled k-step group then carries its offset as an immediate; 0 = take them from the arguments.
-template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0>
+// MATH: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f32 operands split 3 x bf16, six products on the bf16 MFMA.
+template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0, int MATH = 0>
 __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 8, "8 waves per workgroup");
     static_assert(NT1MAX == 3 && NT2MAX == 2, "static dispatch below");
@@ -162,11 +232,11 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * a.d2[j];
         const int n1 = (T_B + 2 * r2 + 31) / 32;  // conv1 column tiles: extended column e <-> t = t0 - r2 + e
         nt1 = n1 > wt ? (n1 - wt + WT - 1) / WT : 0;
-        const float4* wp = reinterpret_cast<const float4*>(a.w[j][0] + (long)wm * K * CP * 64) + lane;
+        const float* wp = a.w[j][0];
         const float* bs = BS + (j * 2 + 0) * C;
-        if (nt1 >= 3) mrf_conv1_compute<3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
-        else if (nt1 == 2) mrf_conv1_compute<2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
-        else if (nt1 == 1) mrf_conv1_compute<1, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
+        if (nt1 >= 3) mrf_conv1_compute<MATH, 3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
+        else if (nt1 == 2) mrf_conv1_compute<MATH, 2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
+        else if (nt1 == 1) mrf_conv1_compute<MATH, 1, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
     };
 
     conv1_compute(0);
@@ -191,10 +261,10 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         __syncthreads();
         // ---- conv2 into the output registers, then straight on to the next resblock's conv1
         {
-            const float4* wp = reinterpret_cast<const float4*>(a.w[j][1] + (long)wm * K * CP * 64) + lane;
+            const float* wp = a.w[j][1];
             const float* bs = BS + (j * 2 + 1) * C;
-            if (nt2 >= 2) mrf_conv2<2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
-            else if (nt2 == 1) mrf_conv2<1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
+            if (nt2 >= 2) mrf_conv2<MATH, 2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
+            else if (nt2 == 1) mrf_conv2<MATH, 1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
         }
         if (j + 1 < a.nrb) conv1_compute(j + 1);
     }
@@ -272,6 +342,19 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     };
+    if (a.math == 1) {
+        if (a.C == 32) {
+            if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1>);
+            else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 1>);
+        } else if (a.C == 128) {
+            if (a.ldx == 160 && a.ld1 == 128) go(k_mrf_fused<4, 2, 3, 3, 2, 160, 128, 1>);
+            else go(k_mrf_fused<4, 2, 3, 3, 2, 0, 0, 1>);
+        } else {
+            if (a.ldx == 320 && a.ld1 == 288) go(k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 1>);
+            else go(k_mrf_fused<2, 4, 6, 3, 2, 0, 0, 1>);
+        }
+        return;
+    }
     if (a.C == 32) {
         if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608>);
         else go(k_mrf_fused<1, 8, 16, 3, 2>);

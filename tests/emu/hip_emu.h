@@ -42,6 +42,7 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
+struct uint4 { unsigned x, y, z, w; };
 struct int4 { int x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
@@ -132,6 +133,8 @@ struct Worker {
     uint64_t xchg[MAX_WAVES][2][WAVE];
     float mfma_a[MAX_WAVES][2][WAVE];
     float mfma_b[MAX_WAVES][2][WAVE];
+    unsigned mfma_a16[MAX_WAVES][2][WAVE][4];
+    unsigned mfma_b16[MAX_WAVES][2][WAVE][4];
     bool reverse = false;
 
     Worker() {
@@ -470,6 +473,44 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c)
         float d = c[r];
         for (int k = 0; k < 4; ++k) d = fmaf(A[row + 16 * k], B[col + 16 * k], d);
         c[r] = d;
+    }
+    return c;
+}
+
+// v_cvt_pk_bf16_f32: round to nearest even, `lo` in bits [15:0]
+static inline unsigned hipemu_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+static inline unsigned hipemu_cvt_pk_bf16_f32(float lo, float hi) { return hipemu_bf16_rne(lo) | (hipemu_bf16_rne(hi) << 16); }
+// v_mfma_f32_32x32x16_bf16: lane l holds row (A) / column (B) l & 31 and the eight k-slots of half l >> 5 (slot e in
+// bits [16 (e & 1) ...] of register e >> 1); C/D as the f32 32x32 form.  Products are exact; the sixteen of them are
+// summed in double and added to c with one rounding (the hardware's internal order is unspecified; tests are toleranced).
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(uint4 a, uint4 b, hipemu_f32x16 c) {
+    hipemu::Worker* w = hipemu::tl_worker;
+    hipemu::Fiber* f = w->cur;
+    const int wave = f->lin / 64, lane = f->lin % 64;
+    const int slot = (f->wave_ops++) & 1;
+    const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 4; ++j) {
+        w->mfma_a16[wave][slot][lane][j] = av[j];
+        w->mfma_b16[wave][slot][lane][j] = bv[j];
+    }
+    hipemu::wave_sync();
+    const int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        double d = 0.0;
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) {
+                const unsigned ua = w->mfma_a16[wave][slot][row + 32 * h][e >> 1], ub = w->mfma_b16[wave][slot][col + 32 * h][e >> 1];
+                const float fa = __uint_as_float((e & 1) ? (ua & 0xffff0000u) : (ua << 16));
+                const float fb = __uint_as_float((e & 1) ? (ub & 0xffff0000u) : (ub << 16));
+                d += (double)fa * (double)fb;
+            }
+        c[r] = (float)((double)c[r] + d);
     }
     return c;
 }

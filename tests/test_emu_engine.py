@@ -297,3 +297,40 @@ def test_empty_row_in_batch(emu_lib):
     L = int(solo["lengths"][0])
     assert np.array_equal(solo["audio"][0, :L], out["audio"][0, :L])
     eng.close()
+
+
+@pytest.mark.parametrize("initial_channel", [128, 256])
+def test_bf16x3_math_mode_matches_oracle_at_the_f32_tolerances(emu_lib, initial_channel):
+    """MATH_BF16X3: the f32 operands of the dense convs split exactly into three bf16 terms, six partial products on the
+    bf16 matrix cores, f32 accumulation.  Same tolerances as the f32 path (rel. RMS <= 1e-4, durations exact, every
+    decoder stage) — and in fact the same error level: the split loses nothing above 2^-24."""
+    cfg = VitsConfig.tiny_wide(initial_channel=initial_channel)  # fused MRF stages of 64 + 32 (and 128) channels
+    w = W.synthetic_weights(cfg, seed=31, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    errs = {}
+    for mode in ("f32", "bf16x3"):
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math(mode)
+        assert eng.math == mode
+        out, ora = check_parity(emu_lib, cfg, B=2, Tx=9, seed=31, weights=w, engine=eng)
+        errs[mode] = max(out["stage_errors"].values())
+        L = int(out["lengths"][0])
+        errs[mode + ".audio"] = rel_rms(out["audio"][0, :L], ora["audio"][0, 0, :L])
+        lane = eng.clone()
+        assert lane.math == mode  # a lane inherits the mode of the handle it was cloned from
+        lane.close()
+        eng.close()
+    assert errs["bf16x3"] < 3 * errs["f32"] + 1e-6 and errs["bf16x3.audio"] < 3 * errs["f32.audio"] + 1e-6, errs
+    with pytest.raises(Exception, match="math"):
+        Engine(blob, library=emu_lib).set_math(7)
+
+
+def test_bf16x3_weight_planes_are_an_exact_split():
+    """pack_conv_weights_bf16x3 (restated in numpy): w == h + m + l exactly, each plane a bf16."""
+    import torch
+
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal(4096) * np.exp(rng.uniform(-20, 20, 4096))).astype(np.float32)
+    bf = lambda x: torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    h = bf(w); m = bf(w - h); l = bf(w - h - m)
+    assert np.array_equal(h.astype(np.float64) + m + l, w.astype(np.float64))

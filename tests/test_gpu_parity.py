@@ -224,3 +224,51 @@ def test_plain_c_client_on_the_device(gpu_lib, tmp_path):
 
     out = run_c_client(gpu_lib, tmp_path, cfg=VitsConfig.vctk_low(), seed=3)
     assert "gfx950" in out and "speakers 109" in out
+
+
+@pytest.mark.parametrize("voice", ["apope_low", "vctk_low"])
+def test_bf16x3_math_bench_workload_matches_oracle(gpu_lib, voice):
+    """MATH_BF16X3 (f32 operands split exactly into 3 x bf16, six partial products on the bf16 matrix cores, f32
+    accumulate) at the benchmarked configurations, against the oracle at the UNCHANGED f32 tolerances (rel. RMS <= 1e-4,
+    durations exact, int16 criterion, every decoder stage)."""
+    cfg = VitsConfig.apope_low() if voice == "apope_low" else VitsConfig.vctk_low()
+    B, Tx = 32, 128
+    ids, lengths = _bench_batch(B, Tx)
+    forced = np.full((B, Tx), 6, np.int32)
+    sid = (np.arange(B) % cfg.n_speakers).astype(np.int64) if cfg.is_multispeaker else None
+    w = W.synthetic_weights(cfg, seed=1234)
+    eng = Engine(W.pack(cfg, w))
+    eng.set_math("bf16x3")
+    out, ora = check_parity(gpu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=5, sid=sid, weights=w,
+                            stage_rows=(0, 17), engine=eng)
+    # error level next to the f32-MFMA path's on the same inputs: the split must not cost accuracy
+    eng.set_math("f32")
+    out32, _ = check_parity(gpu_lib, cfg, ids=ids[:2], lengths=lengths[:2], forced=forced[:2], noise=True, seed=5,
+                            sid=None if sid is None else sid[:2], weights=w, engine=eng)
+    e3 = rel_rms(out["audio"][0], ora["audio"][0, 0])
+    print(f"\n{voice}: rel RMS vs oracle  bf16x3 {e3:.3e}   stages {out['stage_errors']}   f32 stages {out32['stage_errors']}")
+    assert max(out["stage_errors"].values()) < 3 * max(out32["stage_errors"].values()) + 2e-6
+    eng.close()
+
+
+def test_bf16x3_golden_shape_and_batch_invariance(gpu_lib):
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    eng = Engine(W.pack(cfg, w))
+    eng.set_math("bf16x3")
+    Tx = 180
+    ids = np.random.default_rng(99).integers(1, 50, (1, Tx)).astype(np.int64)
+    forced = np.full((1, Tx), 5, np.int32)
+    forced[0, :91] = 6
+    out, _ = check_parity(gpu_lib, cfg, ids=ids, forced=forced, noise=True, seed=99, weights=w, engine=eng)
+    assert int(out["lengths"][0]) == 253696
+    # batched == unbatched, bitwise, in this mode too
+    B = 3
+    idb = np.random.default_rng(5).integers(1, 50, (B, 40)).astype(np.int64)
+    lens = np.array([40, 23, 31])
+    fb = np.full((B, 40), 4, np.int32)
+    full = eng.run(idb, lens, [0.667, 1.0, 0.8], forced_durations=fb, seed=7)
+    one = eng.run(idb[1:2], lens[1:2], [0.667, 1.0, 0.8], forced_durations=fb[1:2], seed=7, utterance_base=1)
+    L = int(one["lengths"][0])
+    assert np.array_equal(full["audio"][1, :L], one["audio"][0, :L])
+    eng.close()
