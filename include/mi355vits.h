@@ -176,7 +176,8 @@ long mi355vits_get_tap(mi355vits_handle h, const char* name, float* out, size_t 
 long mi355vits_list_taps(mi355vits_handle h, char* buf, size_t cap);
 
 /* Kernel unit-test hook: one Conv1d through a chosen implementation on host buffers.
- * impl: 0 = generic VALU kernel, 1 = fp32-MFMA kernel.  See tests/test_kernels_*.py. */
+ * impl: 0 = generic VALU kernel, 1 = fp32-MFMA kernel, 2 = split-bf16 staged kernel (MI355VITS_MATH_BF16X3; needs
+ * Cin % 32 == 0 and T > 512).  See tests/test_gpu_parity.py, tests/test_emu_engine.py. */
 typedef struct mi355vits_conv_test {
     int32_t impl, B, Cin, Cout, T, K, dilation;
     const float* x;       /* [B,Cin,T] */

@@ -243,13 +243,24 @@ int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t) {
         }
         if (t->in_len) { HIP_CHECK(hipMemcpy(dil.p, t->in_len, t->B * 4, hipMemcpyHostToDevice)); a.in_len = dil.as<int>(); }
         if (t->out_len) { HIP_CHECK(hipMemcpy(dol.p, t->out_len, t->B * 4, hipMemcpyHostToDevice)); a.out_len = dol.as<int>(); }
-        if (t->impl == 1) {
+        if (t->impl == 1 || t->impl == 2) {
             if (!conv1d_mfma_supported(t->Cin, t->Cout, t->K, t->dilation)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the MFMA kernel");
             packed.resize(mfma_packed_floats(t->Cout, t->Cin, t->K));
             pack_conv_weights_mfma(t->w, t->Cout, t->Cin, t->K, packed.data());
             DevBuf dp(packed.size() * 4);
             HIP_CHECK(hipMemcpy(dp.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
             a.w = dp.as<float>();
+            std::vector<uint32_t> b3;
+            std::unique_ptr<DevBuf> db3;
+            if (t->impl == 2) {  // split-bf16 staged kernel (MATH_BF16X3)
+                if (!conv1d_b3_supported(t->Cin, t->Cout, t->K, t->dilation, t->T)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the split-bf16 kernel");
+                b3.resize(bf16x3_packed_words_mode(t->Cout, t->Cin, t->K, EPI_STD));
+                pack_conv_weights_bf16x3_mode(t->w, t->Cout, t->Cin, t->K, EPI_STD, 1, b3.data());
+                db3.reset(new DevBuf(b3.size() * 4));
+                HIP_CHECK(hipMemcpy(db3->p, b3.data(), b3.size() * 4, hipMemcpyHostToDevice));
+                a.wb3 = db3->as<float>();
+                a.math = MATH_BF16X3;
+            }
             launch_conv1d_mfma(a, nullptr);
             HIP_CHECK(hipDeviceSynchronize());
         } else {

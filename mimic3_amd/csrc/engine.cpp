@@ -226,6 +226,13 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             static_assert(sizeof(uint32_t) == sizeof(float), "bit patterns travel in the float arena");
             c.packed_b3 = stage(reinterpret_cast<const float*>(b3.data()), b3.size());
         }
+        if (Cin % 32 == 0 && (epi == EPI_GATE ? (Cout / 2) % 32 == 0 : true)) {
+            // ... and for the staged split-bf16 kernel (every dense conv with a multiple of 32 input channels)
+            const int pe = epi == EPI_GATE ? EPI_GATE : EPI_STD;
+            std::vector<uint32_t> b3(bf16x3_packed_words_mode(Cout, Cin, K, pe));
+            pack_conv_weights_bf16x3_mode(w.data(), Cout, Cin, K, pe, 1, b3.data());
+            c.packed_b3s = stage(reinterpret_cast<const float*>(b3.data()), b3.size());
+        }
     }
     return model_->convs[key] = c;
 }
@@ -567,6 +574,10 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     ProfScope ps(prof_, label, flops, bytes);
     if (!force_generic_ && w.packed != NO_OFF) {
         a.w = P(w.packed);
+        if (math_ == MATH_BF16X3 && w.packed_b3s != NO_OFF) {
+            a.wb3 = P(w.packed_b3s);
+            a.math = MATH_BF16X3;
+        }
         launch_conv1d_mfma(a, stream_);
     } else {
         a.w = P(w.raw);
@@ -815,7 +826,10 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             const ConvW& win = cw(S("flow.%d.in.%d", j, l));
             const ConvW& wrs = cw(S("flow.%d.rs.%d", j, l));
             const float* cond_l = d_cond_flow_.empty() ? nullptr : d_cond_flow_[j] + (long)l * 2 * H;
-            if (!force_generic_ && !no_fused_wn_ && wn_layer_fused_supported(H, win.K, dil)) {
+            // split-bf16 math: the in-layer and the res/skip convs go through the staged bf16 kernel (two launches, `u`
+            // through HBM: 38 MB per layer, nothing next to the matrix-core time saved); the fused kernel is f32-MFMA
+            const bool wn_b3 = false;  // (measured: in-layer 2.09 + res/skip 1.70 ms vs 3.65 fused f32 — no gain; kept for A/B)
+            if (!force_generic_ && !no_fused_wn_ && !wn_b3 && wn_layer_fused_supported(H, win.K, dil)) {
                 WnArgs w;
                 w.h_in = hcur; w.h_out = hnext; w.h_bs = hbs; w.h_ld = Ty;
                 w.skip = d_fskip_; w.s_bs = hbs; w.s_ld = Ty;

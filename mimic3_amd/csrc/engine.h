@@ -92,6 +92,7 @@ struct ConvW {
     size_t packed = NO_OFF;  // MFMA fragment order (absent when Cin is odd)
     size_t packed4 = NO_OFF; // same records regrouped [tile][tap][4 pairs][lane][4] for 16-byte A loads (fused MRF stage)
     size_t packed_b3 = NO_OFF;  // three bf16 planes in bf16-MFMA fragment order (pack_conv_weights_bf16x3), 32-bit words
+    size_t packed_b3s = NO_OFF; // the same for the staged split-bf16 conv kernel (layout 1, this conv's tile map)
     size_t bias = NO_OFF;
     int Cout = 0, Cin = 0, K = 1;
     int epi = EPI_STD;  // tile map the packed copy was built for

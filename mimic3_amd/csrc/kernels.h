@@ -15,6 +15,8 @@ struct ConvArgs {
     const float* x = nullptr; long x_bs = 0; int x_ld = 0;   // input  [B,Cin,T]
     float* y = nullptr;       long y_bs = 0; int y_ld = 0;   // output [B,Cout,T] (GATE: [B,H,T]; RESSKIP: h, in place)
     const float* w = nullptr;      // generic kernel: [Cout,Cin,K]; MFMA kernel: packed fragments (pack_conv_weights_mfma)
+    const float* wb3 = nullptr;    // the same weights as three bf16 planes (pack_conv_weights_bf16x3_mode, layout 1) or null
+    int math = 0;                  // MATH_BF16X3 + wb3: split-operand path on the bf16 matrix cores (k_conv1d_b3)
     const float* bias = nullptr;   // [Cout] or null
     const float* cond = nullptr; long cond_bs = 0;  // per-(b,co) additive term (speaker conditioning) or null
     const float* res = nullptr; long res_bs = 0; int res_ld = 0;  // residual [B,Cout,T] or null
@@ -58,6 +60,11 @@ void regroup_packed_x4(const float* packed, size_t n_floats, float* out);  // fu
 enum MathMode { MATH_F32 = 0, MATH_BF16X3 = 1 };
 size_t bf16x3_packed_words(int Cout, int Cin, int K);
 void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out);
+// general form: epi selects the tile -> output-channel map (EPI_GATE: tile pairs (c, H + c)), layout the k-slot ->
+// channel map (0: packed activation tiles of the fused MRF stage, 1: staged planes of k_conv1d_b3)
+size_t bf16x3_packed_words_mode(int Cout, int Cin, int K, int epi);
+void pack_conv_weights_bf16x3_mode(const float* w, int Cout, int Cin, int K, int epi, int layout, uint32_t* out);
+bool conv1d_b3_supported(int Cin, int Cout, int K, int dil, int T_hint);
 // epi = EPI_GATE packs rows as (c, H + c) tile pairs (H = Cout / 2); otherwise identical to the above.
 void pack_conv_weights_mfma_mode(const float* w, int Cout, int Cin, int K, int epi, float* out);
 

@@ -302,17 +302,28 @@ static inline float bf16_bits_to_float(uint32_t b) {
     return f;
 }
 
-void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out) {
-    const int ng = Cin / 16;
-    for (int tile = 0; tile < Cout / 32; ++tile)
+// layout 0 (packed activation tiles of the fused MRF stage): slot e of half h <-> channel 16G + (e < 4 ? 0 : 8) + h + 2 (e & 3)
+// layout 1 (staged planes of k_conv1d_b3):                     slot e of half h <-> channel 16G + 8 (e >> 2) + 4 h + (e & 3)
+static inline int b3_slot_channel(int layout, int half, int e) {
+    return layout == 0 ? (e < 4 ? 0 : 8) + half + 2 * (e & 3) : 8 * (e >> 2) + 4 * half + (e & 3);
+}
+
+size_t bf16x3_packed_words_mode(int Cout, int Cin, int K, int epi) {
+    return (size_t)n_tiles_for(epi, Cout, Cout / 2) * K * (Cin / 16) * 3 * 64 * 4;
+}
+
+void pack_conv_weights_bf16x3_mode(const float* w, int Cout, int Cin, int K, int epi, int layout, uint32_t* out) {
+    const int ng = Cin / 16, H = Cout / 2;
+    const int nt = n_tiles_for(epi, Cout, H);
+    for (int tile = 0; tile < nt; ++tile)
         for (int k = 0; k < K; ++k)
             for (int g = 0; g < ng; ++g)
                 for (int l = 0; l < 64; ++l) {
-                    const int co = tile * 32 + (l & 31), half = l >> 5;
+                    const int co = tile_row_to_co(epi, tile, l & 31, Cout, H), half = l >> 5;
                     uint32_t plane[3][8];
                     for (int e = 0; e < 8; ++e) {
-                        const int ci = 16 * g + (e < 4 ? 0 : 8) + half + 2 * (e & 3);
-                        const float v = w[((size_t)co * Cin + ci) * K + k];
+                        const int ci = 16 * g + b3_slot_channel(layout, half, e);
+                        const float v = co >= 0 ? w[((size_t)co * Cin + ci) * K + k] : 0.0f;
                         const uint32_t h = bf16_rne_bits(v);
                         const float r1 = v - bf16_bits_to_float(h);
                         const uint32_t m = bf16_rne_bits(r1);
@@ -324,6 +335,10 @@ void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t
                         for (int j = 0; j < 4; ++j) o[j] = plane[p][2 * j] | (plane[p][2 * j + 1] << 16);
                     }
                 }
+}
+
+void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out) {
+    pack_conv_weights_bf16x3_mode(w, Cout, Cin, K, EPI_STD, 0, out);
 }
 
 void pack_conv_weights_mfma(const float* w, int Cout, int Cin, int K, float* out) {
@@ -432,56 +447,12 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NT], const float* c
     }
 }
 
-template <int MT, int NT, int WM, int WN, int EPI, int RING>
-__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void k_conv1d_mfma(ConvArgs a, int CI_C) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
-    DYN_SMEM(float, xs);  // [CI_C][LD]
+// Epilogue shared by the staged kernels (f32 MFMA and split-bf16): C/D layout col = lane&31, row = (r&3) + 8*(r>>2) +
+// 4*(lane>>5).  `xs` is the workgroup's LDS (free after the last chunk; at least the size launch_cfg computed).
+template <int MT, int NT, int WM, int WN, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], float* xs, int b, int t0, int tile0, int n_tiles,
+                                              int wm, int wn, int brow, int bcol, int tid, int out_len) {
     constexpr int T_B = 32 * NT * WN;
-    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
-    const int wm = wid / WN, wn = wid % WN;
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.x * T_B;
-    // staged window starts at ts = floor4(t0 - pad) so that rows can move as aligned 16-byte vectors
-    const int tlo = t0 - a.pad;
-    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
-    const int toff = tlo - ts;  // 0..3
-    const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
-    const int n_tiles = (EPI == EPI_GATE) ? 2 * ((a.H + 31) / 32) : (a.Cout + 31) / 32;
-    const int tile0 = (blockIdx.y * WM + wm) * MT;
-    const int cpairs = a.Cin >> 1;
-    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
-    const int in_len = a.in_len ? a.in_len[b] : Tin;
-    const int out_len = a.out_len ? a.out_len[b] : a.T;
-    const float* xb = a.x + (long)b * a.x_bs;
-
-    f32x16 acc[MT][NT];
-    MI355_UNROLL
-    for (int i = 0; i < MT; ++i)
-        MI355_UNROLL
-        for (int j = 0; j < NT; ++j)
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int brow = lane >> 5, bcol = lane & 31;
-    for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
-        // ---- stage x[c0:c0+CI_C, ts : ts+LD) with mask + leaky-relu fused
-        if (!(a.ablate & 2)) stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
-        __syncthreads();
-        if (!(a.ablate & 1)) {
-            const float* wp[MT];
-            MI355_UNROLL
-            for (int i = 0; i < MT; ++i) {
-                int tile = tile0 + i;
-                if (tile >= n_tiles) tile = n_tiles - 1;  // out-of-range tile: recompute the last one, discarded below
-                wp[i] = a.w + ((long)tile * a.K * cpairs + (c0 >> 1)) * 64 + lane;
-            }
-            mfma_chunk<MT, NT, RING>(acc, wp, xs + brow * LD + bcol + wn * NT * 32 + toff, LD, a.K, CI_C >> 1, cpairs, a.dil);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if ((a.ablate & 4) && acc[0][0][0] != 1.2345f) return;
     if (EPI == EPI_STD && a.ovec) {
         // Through LDS (free after the last chunk) so that global memory sees whole rows: the C/D fragment gives a lane
@@ -573,6 +544,213 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void 
             }
         }
     }
+}
+
+template <int MT, int NT, int WM, int WN, int EPI, int RING>
+__global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void k_conv1d_mfma(ConvArgs a, int CI_C) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
+    DYN_SMEM(float, xs);  // [CI_C][LD]
+    constexpr int T_B = 32 * NT * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * T_B;
+    // staged window starts at ts = floor4(t0 - pad) so that rows can move as aligned 16-byte vectors
+    const int tlo = t0 - a.pad;
+    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
+    const int toff = tlo - ts;  // 0..3
+    const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    const int n_tiles = (EPI == EPI_GATE) ? 2 * ((a.H + 31) / 32) : (a.Cout + 31) / 32;
+    const int tile0 = (blockIdx.y * WM + wm) * MT;
+    const int cpairs = a.Cin >> 1;
+    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
+    const int in_len = a.in_len ? a.in_len[b] : Tin;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+    const float* xb = a.x + (long)b * a.x_bs;
+
+    f32x16 acc[MT][NT];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int brow = lane >> 5, bcol = lane & 31;
+    for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
+        // ---- stage x[c0:c0+CI_C, ts : ts+LD) with mask + leaky-relu fused
+        if (!(a.ablate & 2)) stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
+        __syncthreads();
+        if (!(a.ablate & 1)) {
+            const float* wp[MT];
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) {
+                int tile = tile0 + i;
+                if (tile >= n_tiles) tile = n_tiles - 1;  // out-of-range tile: recompute the last one, discarded below
+                wp[i] = a.w + ((long)tile * a.K * cpairs + (c0 >> 1)) * 64 + lane;
+            }
+            mfma_chunk<MT, NT, RING>(acc, wp, xs + brow * LD + bcol + wn * NT * 32 + toff, LD, a.K, CI_C >> 1, cpairs, a.dil);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    conv_epilogue<MT, NT, WM, WN, EPI>(a, acc, xs, b, t0, tile0, n_tiles, wm, wn, brow, bcol, tid, out_len);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same implicit GEMM with the f32 operands split into three bf16 planes each (hipx.h: split3) and the six leading
+// partial products on v_mfma_f32_32x32x16_bf16 — f32-grade results at 6/16 of the f32 MFMA's time (MATH_BF16X3).
+//   * an input chunk of CI_C channels is split ONCE while it is staged: LDS holds three planes [plane][16-channel
+//     group][half][column] x 16 B, a lane's eight k-slots of one plane side by side, so the loop's B operand is one
+//     ds_read_b128 per (plane, column tile) and carries no VALU work at all;
+//   * the weights come pre-split in the matching fragment order (pack_conv_weights_bf16x3_mode, layout 1), three
+//     global_load_dwordx4 per (row tile, group), fetched one group ahead; taps are a runtime loop, the groups of a
+//     chunk are unrolled;
+//   * MT x NT accumulator tiles per wave share every fetch (A across NT columns tiles, B across MT row tiles);
+//     the epilogues are the f32 kernel's.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int NG>  // NG 16-channel groups per chunk
+__device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NT], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS /*plane stride*/,
+                                         int LD, int K, int groups_per_tap, int dil) {
+    // wp[i]: (tap 0, first group of this chunk, plane 0) of row tile i, lane offset included; a group is 192 uint4,
+    // consecutive taps are groups_per_tap * 192 apart.  xq: (plane 0, group 0, this lane's half and column).
+    uint4 ra[2][MT][3];
+    uint4 rb[2][NT][3];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) ra[0][i][p] = wp[i][p * 64];
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j)
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) rb[0][j][p] = xq[p * PS + j * 32];
+    for (int k = 0; k < K; ++k) {
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;  // NG is even: the parity carries over from tap to tap
+            // next group's operands (the very last one re-reads itself: every load stays unconditional)
+            const bool wrap = g + 1 == NG;
+            const long woff = (wrap ? (last_tap ? (long)k * groups_per_tap + g : (long)(k + 1) * groups_per_tap) : (long)k * groups_per_tap + g + 1) * 192;
+            const int xoff = wrap ? (last_tap ? k * dil + g * 2 * LD : (k + 1) * dil) : k * dil + (g + 1) * 2 * LD;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int p = 0; p < 3; ++p) ra[nxt][i][p] = wp[i][woff + p * 64];
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j)
+                MI355_UNROLL
+                for (int p = 0; p < 3; ++p) rb[nxt][j][p] = xq[p * PS + xoff + j * 32];
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = MFMA_32x32x16_BF16(ra[cur][i][2], rb[cur][j][0], c);  // small terms first
+                    c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][2], c);
+                    c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][1], c);
+                    c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][0], c);
+                    c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][1], c);
+                    c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][0], c);
+                    acc[i][j] = c;
+                }
+            SCHED_FENCE();
+        }
+    }
+}
+
+// stage x[c0 : c0 + 16 NG, ts : ts + LD) as three bf16 planes: mask, leaky-relu and split fused.  A thread takes one
+// (group, half) and four columns: eight 16-byte loads along time (channels 16G + 4h + 0..3 and 16G + 8 + 4h + 0..3),
+// 16 pair-splits, twelve 16-byte LDS stores.
+template <int NG>
+__device__ __forceinline__ void stage_planes(const float* __restrict__ xb, long x_ld, int LD, int ts, int tend, float slope,
+                                             uint4* __restrict__ planes, int PS, int vec) {
+    const int ld4 = LD >> 2;
+    for (int idx = threadIdx.x; idx < NG * 2 * ld4; idx += 256) {
+        const int gh = idx / ld4, c4 = idx - gh * ld4;  // gh = group * 2 + half
+        const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
+        const int tt = ts + 4 * c4;
+        float v[8][4];
+        MI355_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const float* row = xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld;
+            if (vec && tt >= 0 && tt + 3 < tend) {
+                const float4 r4 = *reinterpret_cast<const float4*>(row + tt);
+                v[e][0] = r4.x; v[e][1] = r4.y; v[e][2] = r4.z; v[e][3] = r4.w;
+            } else {
+                MI355_UNROLL
+                for (int j = 0; j < 4; ++j) v[e][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
+            }
+        }
+        MI355_UNROLL
+        for (int j = 0; j < 4; ++j) {
+            uint4 h, m, l;
+            split3_pk(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), h.x, m.x, l.x);
+            split3_pk(lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope), h.y, m.y, l.y);
+            split3_pk(lrelu_f(v[4][j], slope), lrelu_f(v[5][j], slope), h.z, m.z, l.z);
+            split3_pk(lrelu_f(v[6][j], slope), lrelu_f(v[7][j], slope), h.w, m.w, l.w);
+            const int o = gh * LD + 4 * c4 + j;
+            planes[o] = h;
+            planes[PS + o] = m;
+            planes[2 * PS + o] = l;
+        }
+    }
+}
+
+template <int MT, int NT, int WM, int WN, int EPI, int NG>
+__global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
+    static_assert(NG % 2 == 0, "an even number of 16-channel groups per chunk");
+    DYN_SMEM(float, xs);
+    constexpr int T_B = 32 * NT * WN;
+    constexpr int CI_C = 16 * NG;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * T_B;
+    const int tlo = t0 - a.pad;
+    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
+    const int toff = tlo - ts;  // 0..3
+    const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    const int PS = NG * 2 * LD;  // uint4 per plane
+    const int n_tiles = (EPI == EPI_GATE) ? 2 * ((a.H + 31) / 32) : (a.Cout + 31) / 32;
+    const int tile0 = (blockIdx.y * WM + wm) * MT;
+    const int gpt = a.Cin >> 4;  // 16-channel groups per tap in the packed weights
+    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
+    const int in_len = a.in_len ? a.in_len[b] : Tin;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+    const float* xb = a.x + (long)b * a.x_bs;
+    uint4* planes = reinterpret_cast<uint4*>(xs);
+
+    f32x16 acc[MT][NT];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int brow = lane >> 5, bcol = lane & 31;
+    for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
+        if (!(a.ablate & 2)) stage_planes<NG>(xb + (long)c0 * a.x_ld, a.x_ld, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, planes, PS, a.vec);
+        __syncthreads();
+        if (!(a.ablate & 1)) {
+            const uint4* wp[MT];
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) {
+                int tile = tile0 + i;
+                if (tile >= n_tiles) tile = n_tiles - 1;  // out-of-range tile: recompute the last one, discarded below
+                wp[i] = reinterpret_cast<const uint4*>(a.wb3) + ((long)tile * a.K * gpt + (c0 >> 4)) * 192 + lane;
+            }
+            b3_chunk<MT, NT, NG>(acc, wp, planes + brow * LD + bcol + wn * NT * 32 + toff, PS, LD, a.K, gpt, a.dil);
+        }
+        __syncthreads();
+    }
+    conv_epilogue<MT, NT, WM, WN, EPI>(a, acc, xs, b, t0, tile0, n_tiles, wm, wn, brow, bcol, tid, out_len);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -795,6 +973,33 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     }
 }
 
+// split-bf16 staged kernel: 32-channel chunks (two 16-channel groups: 6 * 32 * LD bytes of LDS)
+template <int MT, int NT, int WM, int WN, int EPI>
+void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
+    constexpr int T_B = 32 * NT * WN;
+    const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    size_t shmem = (size_t)6 * 32 * LD;
+    dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
+    ConvArgs av = a;
+    av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
+    av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
+    static const bool no_ovec = getenv("MI355VITS_CONV_NO_OVEC") != nullptr;
+    av.ovec = EPI == EPI_STD && !no_ovec && av.yvec && !a.shuf_s &&
+              (!a.res || ((a.res_ld % 4 == 0) && (a.res_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.res) % 16 == 0)));
+    if (av.ovec) {
+        const size_t need = (size_t)(32 * WM) * (T_B + 4) * sizeof(float);
+        if (need > shmem) shmem = need;
+    }
+    auto kfn = k_conv1d_b3<MT, NT, WM, WN, EPI, 2>;
+#ifndef MI355_EMU
+    if (shmem > 64 * 1024) {
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)once;
+    }
+#endif
+    LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av);
+}
+
 template <int MT, int NT, int WM, int WN, int EPI>
 void launch_direct(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
@@ -807,6 +1012,16 @@ void launch_direct(const ConvArgs& a, int n_tiles, hipStream_t s) {
 
 }  // namespace
 
+bool conv1d_b3_supported(int Cin, int Cout, int K, int dil, int T_hint) {
+    (void)Cout;
+    // 32-channel chunks; the staged window of the widest tile (192 columns) must fit LDS; short sequences (the text
+    // encoder) stay on the LDS-free f32 kernels
+    // ... as do convs with little work per staged chunk (1x1 convs, the last upsampler: K * Cin < 256), where splitting
+    // the chunk costs more than the faster matrix-core loop saves (measured: flow.pre / post, res_skip, upsample 64 -> 32)
+    return Cin >= 32 && Cin % 32 == 0 && (size_t)6 * 32 * ((192 + (K - 1) * dil + 6) & ~3) <= 150 * 1024 && T_hint > 512 &&
+           K * Cin >= 256;
+}
+
 void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     if (a_in.T <= 0 || a_in.B <= 0) return;
     static const int ablate = getenv("MI355VITS_CONV_ABLATE") ? atoi(getenv("MI355VITS_CONV_ABLATE")) : 0;
@@ -814,6 +1029,19 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     a.ablate = ablate;
     if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
     const int n_tiles = n_tiles_for(a.epi, a.Cout, a.H);
+    if (a.math == MATH_BF16X3 && a.wb3 && conv1d_b3_supported(a.Cin, a.Cout, a.K, a.dil, a.T)) {
+        // split-bf16 path: one tile shape per epilogue kind (fixed by the layer, never by the batch)
+        if (a.epi == EPI_GATE) launch_b3<2, 3, 2, 2, EPI_GATE>(a, n_tiles, s);
+        else if (a.epi == EPI_RESSKIP) {
+            if (n_tiles >= 4) launch_b3<2, 3, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+            else launch_b3<1, 3, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
+        } else {
+            if (n_tiles >= 4) launch_b3<2, 3, 2, 2, EPI_STD>(a, n_tiles, s);
+            else if (n_tiles >= 2) launch_b3<1, 3, 2, 2, EPI_STD>(a, n_tiles, s);
+            else launch_b3<1, 2, 1, 4, EPI_STD>(a, n_tiles, s);
+        }
+        return;
+    }
     // Tile choice.  Every CU works through ceil(blocks / 256) workgroups' worth of MFMA time, so a grid of 576
     // workgroups runs at 576 / 768 = 75 % of one of 1152: take the largest tile whose grid fills the 256 CUs to
     // >= 85 %, else the candidate that fills them best (small problems: the finest tile = most parallelism).

@@ -334,3 +334,50 @@ def test_bf16x3_weight_planes_are_an_exact_split():
     bf = lambda x: torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
     h = bf(w); m = bf(w - h); l = bf(w - h - m)
     assert np.array_equal(h.astype(np.float64) + m + l, w.astype(np.float64))
+
+
+def _conv_ref(x, w, bias, res, dil, in_len, slope, scale):
+    import torch
+    import torch.nn.functional as F
+
+    B, Cin, T = x.shape
+    K = w.shape[2]
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).double()[:, None, :]
+    xt = F.leaky_relu(torch.from_numpy(x).double() * tm, slope)
+    ref = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil, padding=(K * dil - dil) // 2)
+    return ((ref + torch.from_numpy(res).double()) * scale * tm).numpy()
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 600, 3, 1), (2, 64, 96, 530, 7, 3), (1, 96, 29, 700, 1, 1)])
+def test_split_bf16_staged_conv_kernel(emu_lib, case):
+    """k_conv1d_b3 (impl 2) against an fp64 torch conv, next to the f32-MFMA kernel (impl 1) on the same data: the
+    split-operand path must be at least as accurate."""
+    B, Cin, Cout, T, K, dil = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, Cout, T)).astype(np.float32)
+    in_len = np.array([T] + [T - 37] * (B - 1), np.int32)
+    ref = _conv_ref(x, w, bias, res, dil, in_len, 0.1, 0.5)
+    err = {}
+    for impl in (1, 2):
+        y = emu_lib.test_conv1d(x, w, bias, res, dilation=dil, impl=impl, in_len=in_len, out_len=in_len, in_slope=0.1, out_scale=0.5)
+        err[impl] = np.abs(y - ref).max()
+    assert err[2] < 5e-6 and err[2] <= 1.5 * err[1] + 1e-7, err
+
+
+def test_bf16x3_engine_path_long_utterance_uses_the_staged_split_kernels(emu_lib):
+    """More than 512 frames: the WaveNet in-layer (gate epilogue), res/skip, flow pre/post, conv_pre, upsampler and
+    resblock convs of a tiny voice all run through k_conv1d_b3 in MATH_BF16X3; parity at the f32 tolerances."""
+    cfg = VitsConfig.tiny(n_speakers=3)
+    w = W.synthetic_weights(cfg, seed=12, frames_per_id=2.0)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    eng.set_math("bf16x3")
+    Tx = 140
+    forced = np.full((2, Tx), 4, np.int32)  # 560 frames
+    ids = np.random.default_rng(2).integers(1, cfg.num_symbols, (2, Tx))
+    out, _ = check_parity(emu_lib, cfg, ids=ids, lengths=np.array([Tx, Tx - 9]), forced=forced, noise=True, seed=12,
+                          sid=np.array([0, 2]), weights=w, engine=eng)
+    assert int(out["lengths"][0]) == 560 * cfg.hop_length
+    eng.close()

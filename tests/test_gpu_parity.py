@@ -272,3 +272,27 @@ def test_bf16x3_golden_shape_and_batch_invariance(gpu_lib):
     L = int(one["lengths"][0])
     assert np.array_equal(full["audio"][1, :L], one["audio"][0, :L])
     eng.close()
+
+
+@pytest.mark.parametrize("case", [(2, 192, 384, 1000, 5, 1), (1, 128, 128, 3000, 7, 3), (3, 96, 192, 700, 1, 1), (1, 64, 29, 2000, 3, 9),
+                                  (2, 256, 32, 520, 7, 1)])
+def test_split_bf16_staged_conv_kernel_vs_fp64(gpu_lib, case):
+    """k_conv1d_b3 (impl 2: f32 operands split 3 x bf16 while staging, six bf16-MFMA products, f32 accumulate) against
+    an fp64 conv, next to the f32-MFMA kernel (impl 1) on the same data: at least as accurate."""
+    B, Cin, Cout, T, K, dil = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, Cout, T)).astype(np.float32)
+    in_len = np.array([T] + [max(1, T - 37)] * (B - 1), np.int32)
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).double()[:, None, :]
+    xt = F.leaky_relu(torch.from_numpy(x).double() * tm, 0.1)
+    ref = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil, padding=(K * dil - dil) // 2)
+    ref = ((ref + torch.from_numpy(res).double()) * 0.5 * tm).numpy()
+    err = {}
+    for impl in (1, 2):
+        y = gpu_lib.test_conv1d(x, w, bias, res, dilation=dil, impl=impl, in_len=in_len, out_len=in_len, in_slope=0.1, out_scale=0.5)
+        err[impl] = float(np.sqrt(np.mean((y - ref) ** 2)))
+    print(f"\nconv {case}: rms error vs fp64  f32-MFMA {err[1]:.3e}  split-bf16 {err[2]:.3e}")
+    assert err[2] < 2e-6 and err[2] <= 1.25 * err[1] + 2e-8, err
