@@ -232,6 +232,11 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             std::vector<uint32_t> b3(bf16x3_packed_words_mode(Cout, Cin, K, pe));
             pack_conv_weights_bf16x3_mode(w.data(), Cout, Cin, K, pe, 1, b3.data());
             c.packed_b3s = stage(reinterpret_cast<const float*>(b3.data()), b3.size());
+            if (epi == EPI_GATE && Cout % 32 == 0) {  // plain row order for k_wn_layer_b3
+                std::vector<uint32_t> bw(bf16x3_packed_words_mode(Cout, Cin, K, EPI_STD));
+                pack_conv_weights_bf16x3_mode(w.data(), Cout, Cin, K, EPI_STD, 1, bw.data());
+                c.packed_b3w = stage(reinterpret_cast<const float*>(bw.data()), bw.size());
+            }
         }
     }
     return model_->convs[key] = c;
@@ -340,6 +345,8 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         open_device(device_);
         model_ = lane0.model_;
         math_ = lane0.math_;
+        b3_min_work_ = lane0.b3_min_work_;
+        wn_b3_ = lane0.wn_b3_;
     } catch (...) {
         release();
         throw;
@@ -362,6 +369,9 @@ void Engine::open_device(int device) {
     no_fused_wn_ = nw && nw[0] == '1';
     const char* nf = getenv("MI355VITS_NO_FUSED_MRF");
     no_fused_mrf_ = nf && nf[0] == '1';
+    const char* bw = getenv("MI355VITS_B3_MIN_WORK");
+    b3_min_work_ = bw ? atoi(bw) : 256;
+    wn_b3_ = getenv("MI355VITS_WN_B3") != nullptr;
     const char* mm = getenv("MI355VITS_MATH");
     if (mm && mm[0]) {
         if (!strcmp(mm, "bf16x3")) math_ = MATH_BF16X3;
@@ -574,7 +584,10 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     ProfScope ps(prof_, label, flops, bytes);
     if (!force_generic_ && w.packed != NO_OFF) {
         a.w = P(w.packed);
-        if (math_ == MATH_BF16X3 && w.packed_b3s != NO_OFF) {
+        // split-bf16 staged kernel where it pays: convs with little work per staged chunk (1x1 convs, the last
+        // upsampler: K * Cin < 256) spend more on splitting the chunk than the faster matrix-core loop saves
+        // (measured: flow.pre / post, res_skip, upsample 64 -> 32); MI355VITS_B3_MIN_WORK overrides the threshold (tests)
+        if (math_ == MATH_BF16X3 && w.packed_b3s != NO_OFF && (a.math == MATH_BF16X3 || (w.K * w.Cin >= b3_min_work_ && a.epi == EPI_STD))) {
             a.wb3 = P(w.packed_b3s);
             a.math = MATH_BF16X3;
         }
@@ -828,7 +841,28 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             const float* cond_l = d_cond_flow_.empty() ? nullptr : d_cond_flow_[j] + (long)l * 2 * H;
             // split-bf16 math: the in-layer and the res/skip convs go through the staged bf16 kernel (two launches, `u`
             // through HBM: 38 MB per layer, nothing next to the matrix-core time saved); the fused kernel is f32-MFMA
-            const bool wn_b3 = false;  // (measured: in-layer 2.09 + res/skip 1.70 ms vs 3.65 fused f32 — no gain; kept for A/B)
+            // in-layer + res/skip through the staged split-bf16 kernel instead of the fused f32 layer: measured 2.09 + 1.70 ms
+            // vs 3.65 ms per step — no gain (small grids, scalar res/skip epilogue); opt-in for A/B and for the tests
+            const bool wn_b3 = wn_b3_ && math_ == MATH_BF16X3 && win.packed_b3s != NO_OFF && wrs.packed_b3s != NO_OFF &&
+                               conv1d_b3_supported(win.Cin, win.Cout, win.K, dil, Ty) && !force_generic_;
+            if (!force_generic_ && !no_fused_wn_ && !wn_b3 && math_ == MATH_BF16X3 && win.packed_b3w != NO_OFF &&
+                wrs.packed_b3s != NO_OFF && wn_layer_b3_supported(H, win.K, dil)) {
+                // fused layer on the bf16 matrix cores.  Chosen by the layer shape alone (never by the grid size), so a
+                // row's bits do not depend on what it is batched with.
+                WnArgs w;
+                w.h_in = hcur; w.h_out = hnext; w.h_bs = hbs; w.h_ld = Ty;
+                w.skip = d_fskip_; w.s_bs = hbs; w.s_ld = Ty;
+                w.w_in = P(win.packed_b3w); w.b_in = P(win.bias);
+                w.w_rs = P(wrs.packed_b3s); w.b_rs = P(wrs.bias);
+                w.cond = cond_l; w.cond_bs = 2L * H * c.flow_wn_layers;
+                w.len = d_ylen_;
+                w.B = B; w.H = H; w.T = Ty; w.K = win.K; w.dil = dil; w.Crs = wrs.Cout; w.skip_init = (l == 0);
+                const double fl = 2.0 * B * (double)Ty * H * ((double)win.Cout * win.K + wrs.Cout);
+                ProfScope ps(prof_, "flow.wn_layer_b3", fl, 4.0 * B * (double)Ty * H * 4);
+                launch_wn_layer_b3(w, stream_);
+                if (wrs.Cout == 2 * H) std::swap(hcur, hnext);
+                continue;
+            }
             if (!force_generic_ && !no_fused_wn_ && !wn_b3 && wn_layer_fused_supported(H, win.K, dil)) {
                 WnArgs w;
                 w.h_in = hcur; w.h_out = hnext; w.h_bs = hbs; w.h_ld = Ty;
@@ -853,6 +887,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 in.cond_bs = 2L * H * c.flow_wn_layers;
             }
             in.B = B; in.T = Ty;
+            if (wn_b3) in.math = MATH_BF16X3;
             conv("flow.in_gate", win, in);
             ConvArgs rs;
             rs.x = d_fu_; rs.x_bs = hbs; rs.x_ld = Ty;
@@ -861,6 +896,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             rs.epi = EPI_RESSKIP; rs.H = H; rs.skip_init = (l == 0);
             rs.out_len = d_ylen_;
             rs.B = B; rs.T = Ty;
+            if (wn_b3) rs.math = MATH_BF16X3;
             conv("flow.res_skip", wrs, rs);
         }
         ConvArgs post;

@@ -93,6 +93,7 @@ struct ConvW {
     size_t packed4 = NO_OFF; // same records regrouped [tile][tap][4 pairs][lane][4] for 16-byte A loads (fused MRF stage)
     size_t packed_b3 = NO_OFF;  // three bf16 planes in bf16-MFMA fragment order (pack_conv_weights_bf16x3), 32-bit words
     size_t packed_b3s = NO_OFF; // the same for the staged split-bf16 conv kernel (layout 1, this conv's tile map)
+    size_t packed_b3w = NO_OFF; // WaveNet in-layer convs: layout 1 in plain row order (fused split-bf16 layer kernel)
     size_t bias = NO_OFF;
     int Cout = 0, Cin = 0, K = 1;
     int epi = EPI_STD;  // tile map the packed copy was built for
@@ -163,6 +164,8 @@ class Engine {
     hipEvent_t ev_start_ = nullptr, ev_end_ = nullptr;
     bool timed_ = false;
     bool force_generic_ = false;
+    int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
+    bool wn_b3_ = false;         // MATH_BF16X3: WaveNet layers as two staged split-bf16 convs instead of the fused f32 layer
     int math_ = MATH_F32;        // which matrix-core path the dense convs take (include/mi355vits.h: MI355VITS_MATH_*)
     bool no_fused_wn_ = false;   // MI355VITS_NO_FUSED_WN=1: in-layer + res/skip as two launches (A/B + fallback)
     bool no_fused_mrf_ = false;  // MI355VITS_NO_FUSED_MRF=1: conv-by-conv resblocks (A/B + fallback)

@@ -182,13 +182,16 @@ __device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long
         const int c0 = (gb >> 1) * 8 + (gb & 1);
         const int tt = ts + 4 * c4;
         float v[4][4];
-        MI355_UNROLL
-        for (int q = 0; q < 4; ++q) {
-            const float* row = xb + (long)(c0 + 2 * q) * x_ld;
-            if (vec && tt >= 0 && tt + 3 < tend) {
-                const float4 r4 = *reinterpret_cast<const float4*>(row + tt);
-                v[q][0] = r4.x; v[q][1] = r4.y; v[q][2] = r4.z; v[q][3] = r4.w;
-            } else {
+        if (vec && tt >= 0 && tt + 3 < tend) {  // one branch around all four rows: the loads are in flight together
+            float4 r4[4];
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) r4[q] = *reinterpret_cast<const float4*>(xb + (long)(c0 + 2 * q) * x_ld + tt);
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) { v[q][0] = r4[q].x; v[q][1] = r4[q].y; v[q][2] = r4[q].z; v[q][3] = r4[q].w; }
+        } else {
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                const float* row = xb + (long)(c0 + 2 * q) * x_ld;
                 MI355_UNROLL
                 for (int j = 0; j < 4; ++j) v[q][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
             }

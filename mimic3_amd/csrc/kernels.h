@@ -125,6 +125,10 @@ struct WnArgs {
 };
 bool wn_layer_fused_supported(int H, int K, int dil);
 void launch_wn_layer(WnArgs a, hipStream_t s);
+// MATH_BF16X3 form of the same layer (H = 192): w_in / w_rs are pack_conv_weights_bf16x3_mode(..., EPI_STD, layout 1)
+// fragments (plain row order: tanh rows, then sigmoid rows); 96 time columns x all rows per workgroup.
+bool wn_layer_b3_supported(int H, int K, int dil);
+void launch_wn_layer_b3(WnArgs a, hipStream_t s);
 
 // ---------------------------------------------------------------- decoder tail
 // y = tanh(conv_post(lrelu_0.01(x * mask))) (Cout = 1, no bias) + per-utterance max|y| over valid samples;

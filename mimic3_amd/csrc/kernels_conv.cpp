@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include "kernels.h"
+#include "b3.h"
 
 namespace m355 {
 
@@ -99,12 +100,164 @@ __device__ __forceinline__ void epi_resskip(const ConvArgs& a, int b, int co, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same epilogues for a lane's 16 rows of one 32 x 32 accumulator tile (column t): every optional operand (bias,
+// conditioning, residual, accumulate target, skip) is loaded for all 16 rows under ONE wave-uniform test, so the loads
+// are in flight together.  Written element by element (`if (a.res) v += a.res[...]` per row) hipcc emits a branch and
+// an s_waitcnt vmcnt(0) per optional load — up to 64 dependent memory round trips per tile.  Arithmetic and its order
+// are exactly epi_std / epi_resskip / epi_gate (same bits).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_row(int r, int brow) { return (r & 3) + 8 * (r >> 2) + 4 * brow; }
+
+__device__ __forceinline__ void epi_std_tile(const ConvArgs& a, int b, int co0, int t, int brow, const f32x16& acc, int out_len) {
+    if (a.shuf_s) {  // polyphase scatter, odd phase counts: rare, element by element
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + tile_row(r, brow);
+            if (co < a.Cout) epi_std(a, b, co, t, acc[r], out_len);
+        }
+        return;
+    }
+    const int cmax = a.Cout - 1;
+    float v[16], rv[16], yv[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    if (a.bias) {
+        float bv[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { const int co = co0 + tile_row(r, brow); bv[r] = a.bias[co < cmax ? co : cmax]; }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) v[r] += bv[r];
+    }
+    if (a.cond) {
+        float cv[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { const int co = co0 + tile_row(r, brow); cv[r] = a.cond[(long)b * a.cond_bs + (co < cmax ? co : cmax)]; }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) v[r] += cv[r];
+    }
+    if (a.res) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { const int co = co0 + tile_row(r, brow); rv[r] = a.res[(long)b * a.res_bs + (long)(co < cmax ? co : cmax) * a.res_ld + t]; }
+    }
+    if (a.accumulate) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { const int co = co0 + tile_row(r, brow); yv[r] = a.y[(long)b * a.y_bs + (long)(co < cmax ? co : cmax) * a.y_ld + t]; }
+    }
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + tile_row(r, brow);
+        float q = v[r];
+        if (a.relu) q = fmaxf(q, 0.0f);
+        if (a.mask_before_res && t >= out_len) q = 0.0f;
+        if (a.res) q = a.res_sub ? rv[r] - q : rv[r] + q;
+        q *= a.out_scale;
+        if (!a.mask_before_res && t >= out_len) q = 0.0f;
+        if (a.accumulate) q += yv[r];
+        if (co < a.Cout) a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = q;
+    }
+}
+
+__device__ __forceinline__ void epi_resskip_tile(const ConvArgs& a, int b, int co0, int t, int brow, const f32x16& acc, int out_len) {
+    if (a.Cout != a.H && (a.H & 31)) {  // the h / skip boundary cuts through a tile: element by element
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + tile_row(r, brow);
+            if (co < a.Cout) epi_resskip(a, b, co, t, acc[r], out_len);
+        }
+        return;
+    }
+    const int cmax = a.Cout - 1;
+    float v[16], old[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    if (a.bias) {
+        float bv[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { const int co = co0 + tile_row(r, brow); bv[r] = a.bias[co < cmax ? co : cmax]; }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) v[r] += bv[r];
+    }
+    const bool to_skip = a.Cout == a.H || co0 >= a.H;  // wave-uniform: H is a multiple of 32 on this path (checked by the launcher)
+    if (to_skip) {
+        const int sub = a.Cout == a.H ? 0 : a.H;
+        if (!a.skip_init) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) { const int co = co0 + tile_row(r, brow); old[r] = a.y2[(long)b * a.y2_bs + (long)((co < cmax ? co : cmax) - sub) * a.y2_ld + t]; }
+        }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + tile_row(r, brow);
+            if (co < a.Cout) a.y2[(long)b * a.y2_bs + (long)(co - sub) * a.y2_ld + t] = a.skip_init ? v[r] : old[r] + v[r];
+        }
+    } else {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { const int co = co0 + tile_row(r, brow); old[r] = a.y[(long)b * a.y_bs + (long)co * a.y_ld + t]; }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + tile_row(r, brow);
+            float h = old[r] + v[r];
+            if (t >= out_len) h = 0.0f;
+            a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = h;
+        }
+    }
+}
+
+// gate pair: acc0 = rows c (tanh half), acc1 = rows H + c (sigmoid half), c = c0 + row
+__device__ __forceinline__ void epi_gate_tile(const ConvArgs& a, int b, int c0, int t, int brow, const f32x16& acc0, const f32x16& acc1) {
+    const int cmax = a.H - 1;
+    float v0[16], v1[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) { v0[r] = acc0[r]; v1[r] = acc1[r]; }
+    if (a.bias) {
+        float b0[16], b1[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { const int c = c0 + tile_row(r, brow), cc = c < cmax ? c : cmax; b0[r] = a.bias[cc]; b1[r] = a.bias[cc + a.H]; }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { v0[r] += b0[r]; v1[r] += b1[r]; }
+    }
+    if (a.cond) {
+        float c0v[16], c1v[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + tile_row(r, brow), cc = c < cmax ? c : cmax;
+            c0v[r] = a.cond[(long)b * a.cond_bs + cc];
+            c1v[r] = a.cond[(long)b * a.cond_bs + cc + a.H];
+        }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) { v0[r] += c0v[r]; v1[r] += c1v[r]; }
+    }
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        const int c = c0 + tile_row(r, brow);
+        const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(v0[r], -15.0f), 15.0f));
+        const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
+        const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(v1[r], -30.0f), 30.0f)));
+        if (c < a.H) a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = th * sg;
+    }
+}
+
 // Polyphase ConvTranspose1d scatter straight from the accumulators.  Output channels are ordered co' = c*s + r
 // (channel-major / phase-minor), so the 4 consecutive rows a lane holds per register group are 4 consecutive phases of
 // one channel = 4 consecutive output samples: a 16-byte store per lane, 1 KiB contiguous per store instruction.
 template <int MT, int NT>
 __device__ __forceinline__ void epi_polyphase_regs(const ConvArgs& a, const f32x16 (&acc)[MT][NT], int b, int tcol0, int tile0,
                                                    int brow) {
+    // this lane's 16 biases per row tile, loaded under one test (a test per element serialises the loads)
+    float bv[MT][16];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bv[i][r] = 0.0f;
+    if (a.bias) {
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int cop = 32 * (tile0 + i) + 8 * (r >> 2) + 4 * brow + (r & 3);
+                bv[i][r] = a.bias[cop < a.Cout ? cop : a.Cout - 1];
+            }
+    }
     MI355_UNROLL
     for (int j = 0; j < NT; ++j) {
         const int t = tcol0 + j * 32;
@@ -119,7 +272,7 @@ __device__ __forceinline__ void epi_polyphase_regs(const ConvArgs& a, const f32x
                 const int n0 = t * a.shuf_s + r0 - a.shuf_p;
                 float v[4];
                 MI355_UNROLL
-                for (int m = 0; m < 4; ++m) v[m] = acc[i][j][4 * g + m] + (a.bias ? a.bias[cop + m] : 0.0f);
+                for (int m = 0; m < 4; ++m) v[m] = acc[i][j][4 * g + m] + bv[i][4 * g + m];
                 float* yp = a.y + (long)b * a.y_bs + (long)c * a.y_ld + n0;
                 if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 3) == 0 && a.yvec) {
                     *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -527,20 +680,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     for (int j = 0; j < NT; ++j) {
         const int t = t0 + (wn * NT + j) * 32 + bcol;
         if (t >= a.T) continue;
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * brow;
-            if (EPI == EPI_GATE) {
-                const int c = 32 * (tile0 >> 1) + row;
-                if (tile0 + 1 < n_tiles && c < a.H) epi_gate(a, b, c, t, acc[0][j][r], acc[MT - 1][j][r]);
-            } else {
-                MI355_UNROLL
-                for (int i = 0; i < MT; ++i) {
-                    const int co = 32 * (tile0 + i) + row;
-                    if (co >= a.Cout) continue;
-                    if (EPI == EPI_RESSKIP) epi_resskip(a, b, co, t, acc[i][j][r], out_len);
-                    else epi_std(a, b, co, t, acc[i][j][r], out_len);
-                }
+        if (EPI == EPI_GATE) {
+            if (tile0 + 1 < n_tiles) epi_gate_tile(a, b, 32 * (tile0 >> 1), t, brow, acc[0][j], acc[MT - 1][j]);
+        } else {
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) {
+                if (32 * (tile0 + i) >= a.Cout) continue;
+                if (EPI == EPI_RESSKIP) epi_resskip_tile(a, b, 32 * (tile0 + i), t, brow, acc[i][j], out_len);
+                else epi_std_tile(a, b, 32 * (tile0 + i), t, brow, acc[i][j], out_len);
             }
         }
     }
@@ -611,95 +758,6 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void 
 //   * MT x NT accumulator tiles per wave share every fetch (A across NT columns tiles, B across MT row tiles);
 //     the epilogues are the f32 kernel's.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int NG>  // NG 16-channel groups per chunk
-__device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NT], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS /*plane stride*/,
-                                         int LD, int K, int groups_per_tap, int dil) {
-    // wp[i]: (tap 0, first group of this chunk, plane 0) of row tile i, lane offset included; a group is 192 uint4,
-    // consecutive taps are groups_per_tap * 192 apart.  xq: (plane 0, group 0, this lane's half and column).
-    uint4 ra[2][MT][3];
-    uint4 rb[2][NT][3];
-    MI355_UNROLL
-    for (int i = 0; i < MT; ++i)
-        MI355_UNROLL
-        for (int p = 0; p < 3; ++p) ra[0][i][p] = wp[i][p * 64];
-    MI355_UNROLL
-    for (int j = 0; j < NT; ++j)
-        MI355_UNROLL
-        for (int p = 0; p < 3; ++p) rb[0][j][p] = xq[p * PS + j * 32];
-    for (int k = 0; k < K; ++k) {
-        const bool last_tap = k == K - 1;
-        MI355_UNROLL
-        for (int g = 0; g < NG; ++g) {
-            const int cur = g & 1, nxt = cur ^ 1;  // NG is even: the parity carries over from tap to tap
-            // next group's operands (the very last one re-reads itself: every load stays unconditional)
-            const bool wrap = g + 1 == NG;
-            const long woff = (wrap ? (last_tap ? (long)k * groups_per_tap + g : (long)(k + 1) * groups_per_tap) : (long)k * groups_per_tap + g + 1) * 192;
-            const int xoff = wrap ? (last_tap ? k * dil + g * 2 * LD : (k + 1) * dil) : k * dil + (g + 1) * 2 * LD;
-            MI355_UNROLL
-            for (int i = 0; i < MT; ++i)
-                MI355_UNROLL
-                for (int p = 0; p < 3; ++p) ra[nxt][i][p] = wp[i][woff + p * 64];
-            MI355_UNROLL
-            for (int j = 0; j < NT; ++j)
-                MI355_UNROLL
-                for (int p = 0; p < 3; ++p) rb[nxt][j][p] = xq[p * PS + xoff + j * 32];
-            SCHED_FENCE();
-            MI355_UNROLL
-            for (int i = 0; i < MT; ++i)
-                MI355_UNROLL
-                for (int j = 0; j < NT; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = MFMA_32x32x16_BF16(ra[cur][i][2], rb[cur][j][0], c);  // small terms first
-                    c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][2], c);
-                    c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][1], c);
-                    c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][0], c);
-                    c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][1], c);
-                    c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][0], c);
-                    acc[i][j] = c;
-                }
-            SCHED_FENCE();
-        }
-    }
-}
-
-// stage x[c0 : c0 + 16 NG, ts : ts + LD) as three bf16 planes: mask, leaky-relu and split fused.  A thread takes one
-// (group, half) and four columns: eight 16-byte loads along time (channels 16G + 4h + 0..3 and 16G + 8 + 4h + 0..3),
-// 16 pair-splits, twelve 16-byte LDS stores.
-template <int NG>
-__device__ __forceinline__ void stage_planes(const float* __restrict__ xb, long x_ld, int LD, int ts, int tend, float slope,
-                                             uint4* __restrict__ planes, int PS, int vec) {
-    const int ld4 = LD >> 2;
-    for (int idx = threadIdx.x; idx < NG * 2 * ld4; idx += 256) {
-        const int gh = idx / ld4, c4 = idx - gh * ld4;  // gh = group * 2 + half
-        const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
-        const int tt = ts + 4 * c4;
-        float v[8][4];
-        MI355_UNROLL
-        for (int e = 0; e < 8; ++e) {
-            const float* row = xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld;
-            if (vec && tt >= 0 && tt + 3 < tend) {
-                const float4 r4 = *reinterpret_cast<const float4*>(row + tt);
-                v[e][0] = r4.x; v[e][1] = r4.y; v[e][2] = r4.z; v[e][3] = r4.w;
-            } else {
-                MI355_UNROLL
-                for (int j = 0; j < 4; ++j) v[e][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
-            }
-        }
-        MI355_UNROLL
-        for (int j = 0; j < 4; ++j) {
-            uint4 h, m, l;
-            split3_pk(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), h.x, m.x, l.x);
-            split3_pk(lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope), h.y, m.y, l.y);
-            split3_pk(lrelu_f(v[4][j], slope), lrelu_f(v[5][j], slope), h.z, m.z, l.z);
-            split3_pk(lrelu_f(v[6][j], slope), lrelu_f(v[7][j], slope), h.w, m.w, l.w);
-            const int o = gh * LD + 4 * c4 + j;
-            planes[o] = h;
-            planes[PS + o] = m;
-            planes[2 * PS + o] = l;
-        }
-    }
-}
-
 template <int MT, int NT, int WM, int WN, int EPI, int NG>
 __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -840,15 +898,10 @@ __global__ __launch_bounds__(256) void k_conv_direct_mfma(ConvArgs a) {
         const int t = t0 + (wn * NT + j) * 32 + bcol;
         if (t >= a.T) continue;
         MI355_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * brow;
-            MI355_UNROLL
-            for (int i = 0; i < MT; ++i) {
-                const int co = 32 * (tile0 + i) + row;
-                if (co >= a.Cout) continue;
-                if (EPI == EPI_RESSKIP) epi_resskip(a, b, co, t, acc[i][j][r], out_len);
-                else epi_std(a, b, co, t, acc[i][j][r], out_len);
-            }
+        for (int i = 0; i < MT; ++i) {
+            if (32 * (tile0 + i) >= a.Cout) continue;
+            if (EPI == EPI_RESSKIP) epi_resskip_tile(a, b, 32 * (tile0 + i), t, brow, acc[i][j], out_len);
+            else epi_std_tile(a, b, 32 * (tile0 + i), t, brow, acc[i][j], out_len);
         }
     }
 }
@@ -1016,10 +1069,7 @@ bool conv1d_b3_supported(int Cin, int Cout, int K, int dil, int T_hint) {
     (void)Cout;
     // 32-channel chunks; the staged window of the widest tile (192 columns) must fit LDS; short sequences (the text
     // encoder) stay on the LDS-free f32 kernels
-    // ... as do convs with little work per staged chunk (1x1 convs, the last upsampler: K * Cin < 256), where splitting
-    // the chunk costs more than the faster matrix-core loop saves (measured: flow.pre / post, res_skip, upsample 64 -> 32)
-    return Cin >= 32 && Cin % 32 == 0 && (size_t)6 * 32 * ((192 + (K - 1) * dil + 6) & ~3) <= 150 * 1024 && T_hint > 512 &&
-           K * Cin >= 256;
+    return Cin >= 32 && Cin % 32 == 0 && (size_t)6 * 32 * ((192 + (K - 1) * dil + 6) & ~3) <= 150 * 1024 && T_hint > 512;
 }
 
 void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {

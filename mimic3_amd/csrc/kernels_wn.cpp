@@ -13,6 +13,7 @@
 // L2; B: LDS, one step ahead; taps unrolled).  h is read from one buffer and written to another (neighbouring
 // workgroups read each other's halo columns).
 #include "kernels.h"
+#include "b3.h"
 
 namespace m355 {
 
@@ -309,6 +310,8 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     const int t = t0 + bcol;
     const bool two = a.Crs == 2 * H;
     f32x16 hres[MT];
+    const float* condp = a.cond ? a.cond + (long)b * a.cond_bs : a.b_in;
+    const float cond_on = a.cond ? 1.0f : 0.0f;
     {   // ---- in-layer conv: packed tiles 3w .. 3w+2 (tile 2p = rows 32p.. of the tanh half, 2p+1 = same rows, sigmoid half)
         f32x16 acc[MT];
         const float* wp[MT];
@@ -319,9 +322,9 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int c = row0 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                float v = a.b_in[c];
-                if (a.cond) v += a.cond[(long)b * a.cond_bs + c];
-                acc[m][r] = v;
+                // unconditional loads (a test per element serialises them); without conditioning the second term is
+                // +0.0f * bias: the sum is unchanged bit for bit
+                acc[m][r] = a.b_in[c] + cond_on * condp[c];
             }
             wp[m] = a.w_in + (long)q * a.K * CP * 64 + lane;
         }
@@ -360,16 +363,21 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     const bool live = t < len;
     auto finish = [&](const f32x16& acc, int q, const f32x16& hr) {
         if (t >= a.T || ((a.ablate & 4) && acc[0] != 1.2345f)) return;
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            if (two && row < H) {
-                a.h_out[(long)b * a.h_bs + (long)row * a.h_ld + t] = live ? hr[r] + acc[r] : 0.0f;
-            } else {
-                float* sp = a.skip + (long)b * a.s_bs + (long)(two ? row - H : row) * a.s_ld + t;
-                *sp = a.skip_init ? acc[r] : *sp + acc[r];
-            }
+        if (two && 32 * q < H) {  // wave-uniform: a tile lies entirely in the h' half or in the skip half
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r)
+                a.h_out[(long)b * a.h_bs + (long)(32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.h_ld + t] = live ? hr[r] + acc[r] : 0.0f;
+            return;
         }
+        // skip: the 16 old values under one test, in flight together (a test per element serialises the loads)
+        float* sp = a.skip + (long)b * a.s_bs + (long)(32 * q - (two ? H : 0) + 4 * brow) * a.s_ld + t;
+        float old[16];
+        if (!a.skip_init) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) old[r] = sp[(long)((r & 3) + 8 * (r >> 2)) * a.s_ld];
+        }
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) sp[(long)((r & 3) + 8 * (r >> 2)) * a.s_ld] = a.skip_init ? acc[r] : old[r] + acc[r];
     };
     if (two) {
         f32x16 acc[MT];
@@ -418,6 +426,202 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
         finish(acc[0], w, hres[0]);
         if (nq == 2) finish(acc[1], w + 4, hres[0]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same WaveNet layer in MATH_BF16X3 (f32 operands split 3 x bf16, six products on v_mfma_f32_32x32x16_bf16).
+// At 16x the f32 MFMA rate the 32-column geometry above would be bound by streaming the layer's weights (every
+// workgroup reads all of them; 32 columns of reuse), so the tile is turned around:
+//   * a workgroup owns 96 time columns of ALL 2H = 384 in-layer rows: B x T / 96 workgroups (256 for the batch-32
+//     bench shape: one per CU), four waves = one per SIMD with the whole 512-register file each;
+//   * a wave computes 3 row tiles x 3 column tiles (9 accumulators): every weight fragment feeds 3 MFMA groups, every
+//     activation fragment 3 — 18 operand fetches per 54 MFMAs;
+//   * h (+halo) is split into three bf16 planes once while it is staged (b3.h), the raw in-layer result goes through
+//     LDS (the dead h planes' space), is gated by all threads, split, and becomes the B operand of the res/skip conv;
+//     u never leaves the CU.
+// LDS: max(3 planes x 192 ch x 104 col x 2 B = 117 KiB, raw 384 x 96 x 4 B = 144 KiB).
+// ------------------------------------------------------------------------------------------------
+constexpr int WNB_H = 192, WNB_TB = 96, WNB_NG = WNB_H / 16;
+
+__global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
+    constexpr int H = WNB_H, T_B = WNB_TB, NG = WNB_NG;
+    DYN_SMEM(float, smem);
+    uint4* planes = reinterpret_cast<uint4*>(smem);
+    float* R = smem;  // [2H][T_B] raw in-layer result, later scratch of the epilogue
+    const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * T_B;
+    int len = a.len ? a.len[b] : a.T;
+    if (len > a.T) len = a.T;
+    const int pad = (a.K - 1) / 2 * a.dil;
+    const int tlo = t0 - pad;
+    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
+    const int toff = tlo - ts;
+    const int LD = a.ldx;          // staged columns of the h tile
+    const int PS = NG * 2 * LD;    // uint4 per plane
+    const bool two = a.Crs == 2 * H;
+
+    if (!(a.ablate & 2)) stage_planes<NG>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, a.vec);
+    __syncthreads();
+
+    // ---- in-layer conv: wave w owns row tiles w, w + 4, w + 8 (rows 32 q .. 32 q + 31 of the 2H), all 3 column tiles
+    // (speaker conditioning without a branch per element — a test per load makes hipcc wait for each one in turn)
+    const float* condp = a.cond ? a.cond + (long)b * a.cond_bs : a.b_in;
+    const float cond_on = a.cond ? 1.0f : 0.0f;
+    {
+        f32x16 acc[3][3];
+        const uint4* wp[3];
+        MI355_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            const int q = w + 4 * i;
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                const float v = a.b_in[c] + cond_on * condp[c];  // unconditional loads: all 48 in flight together
+                MI355_UNROLL
+                for (int j = 0; j < 3; ++j) acc[i][j][r] = v;
+            }
+            wp[i] = reinterpret_cast<const uint4*>(a.w_in) + (long)q * a.K * NG * 192 + lane;
+        }
+        if (!(a.ablate & 1)) b3_chunk<3, 3, NG>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+        __syncthreads();  // every wave is done with the h planes: the raw result takes their place
+        MI355_UNROLL
+        for (int i = 0; i < 3; ++i)
+            MI355_UNROLL
+            for (int j = 0; j < 3; ++j)
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    R[(32 * (w + 4 * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r];
+    }
+    __syncthreads();
+    // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
+    constexpr int ITEMS = NG * 2 * T_B / 256;  // 9
+    float u[ITEMS][8];
+    MI355_UNROLL
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = tid + 256 * it;
+        const int gh = idx / T_B, col = idx - gh * T_B;
+        const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
+        MI355_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const int c = cbase + 8 * (e >> 2) + (e & 3);
+            const float at = R[c * T_B + col], as = R[(H + c) * T_B + col];
+            const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(at, -15.0f), 15.0f));
+            const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
+            const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(as, -30.0f), 30.0f)));
+            u[it][e] = th * sg;
+        }
+    }
+    __syncthreads();  // the raw result has been consumed: u's planes take its place (column pitch T_B)
+    constexpr int PSU = NG * 2 * T_B;
+    MI355_UNROLL
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = tid + 256 * it;  // = gh * T_B + col
+        uint4 h4, m4, l4;
+        split3_pk(u[it][0], u[it][1], h4.x, m4.x, l4.x);
+        split3_pk(u[it][2], u[it][3], h4.y, m4.y, l4.y);
+        split3_pk(u[it][4], u[it][5], h4.z, m4.z, l4.z);
+        split3_pk(u[it][6], u[it][7], h4.w, m4.w, l4.w);
+        planes[idx] = h4;
+        planes[PSU + idx] = m4;
+        planes[2 * PSU + idx] = l4;
+    }
+    __syncthreads();
+    // ---- res/skip 1x1 conv: Crs / 32 row tiles (12, last layer 6), tile q on wave q % 4
+    const int ntr = a.Crs / 32;
+    f32x16 acc[3][3];
+    {
+        const uint4* wp[3];
+        MI355_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            int q = w + 4 * i;
+            if (q >= ntr) q = ntr - 1;  // beyond the last tile: recompute it, discarded below
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const float v = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow];
+                MI355_UNROLL
+                for (int j = 0; j < 3; ++j) acc[i][j][r] = v;
+            }
+            wp[i] = reinterpret_cast<const uint4*>(a.w_rs) + (long)q * NG * 192 + lane;
+        }
+        if (!(a.ablate & 1)) {
+            if (two) {
+                b3_chunk<3, 3, NG>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+            } else {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
+                f32x16 a2[2][3];
+                const uint4* w2[2] = {wp[0], wp[1]};
+                MI355_UNROLL
+                for (int i = 0; i < 2; ++i)
+                    MI355_UNROLL
+                    for (int j = 0; j < 3; ++j) a2[i][j] = acc[i][j];
+                b3_chunk<2, 3, NG>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                MI355_UNROLL
+                for (int i = 0; i < 2; ++i)
+                    MI355_UNROLL
+                    for (int j = 0; j < 3; ++j) acc[i][j] = a2[i][j];
+            }
+        }
+    }
+    if ((a.ablate & 4) && acc[0][0][0] != 1.2345f) return;
+    // ---- epilogue: rows < H (two-output layers): h' = (h + rs) * mask; the others: skip (+)= rs.  Per 32 x 32 tile the 16
+    // old values of a lane are loaded under one wave-uniform test (all in flight together), then combined and stored.
+    MI355_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        const int q = w + 4 * i;
+        if (q >= ntr) continue;
+        const bool to_h = two && 32 * q < H;  // wave-uniform
+        MI355_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const int t = t0 + j * 32 + bcol;
+            const int tc = t < a.T ? t : a.T - 1;  // clamped: loads stay unconditional, stores are guarded
+            const bool live = t < len;
+            float old[16];
+            if (to_h) {
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) old[r] = a.h_in[(long)b * a.h_bs + (long)(32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.h_ld + tc];
+                if (t < a.T) {
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        a.h_out[(long)b * a.h_bs + (long)(32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.h_ld + t] = live ? old[r] + acc[i][j][r] : 0.0f;
+                }
+            } else {
+                const int sub = two ? H : 0;
+                if (!a.skip_init) {
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) old[r] = a.skip[(long)b * a.s_bs + (long)(32 * q - sub + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.s_ld + tc];
+                }
+                if (t < a.T) {
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        a.skip[(long)b * a.s_bs + (long)(32 * q - sub + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.s_ld + t] =
+                            a.skip_init ? acc[i][j][r] : old[r] + acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+bool wn_layer_b3_supported(int H, int K, int dil) {
+    return H == WNB_H && (K % 2) == 1 && K >= 1 && dil >= 1 && (K - 1) * dil <= 24;
+}
+
+void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    if (!wn_layer_b3_supported(a.H, a.K, a.dil)) throw std::runtime_error("wn_layer_b3: unsupported shape");
+    a.ldx = (WNB_TB + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    static const int ablate = getenv("MI355VITS_WN_ABLATE") ? atoi(getenv("MI355VITS_WN_ABLATE")) : 0;
+    a.ablate = ablate;
+    a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
+    size_t shmem = (size_t)3 * WNB_NG * 2 * a.ldx * 16;
+    const size_t raw = (size_t)2 * WNB_H * WNB_TB * sizeof(float);
+    if (raw > shmem) shmem = raw;
+    dim3 grid((a.T + WNB_TB - 1) / WNB_TB, a.B);
+#ifndef MI355_EMU
+    static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wn_layer_b3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)once;
+#endif
+    LAUNCH_KERNEL(k_wn_layer_b3, grid, dim3(256), shmem, s, a);
 }
 
 bool wn_layer_fused_supported(int H, int K, int dil) {

@@ -370,9 +370,16 @@ def test_split_bf16_staged_conv_kernel(emu_lib, case):
 def test_bf16x3_engine_path_long_utterance_uses_the_staged_split_kernels(emu_lib):
     """More than 512 frames: the WaveNet in-layer (gate epilogue), res/skip, flow pre/post, conv_pre, upsampler and
     resblock convs of a tiny voice all run through k_conv1d_b3 in MATH_BF16X3; parity at the f32 tolerances."""
+    import os
+
     cfg = VitsConfig.tiny(n_speakers=3)
     w = W.synthetic_weights(cfg, seed=12, frames_per_id=2.0)
-    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    os.environ["MI355VITS_WN_B3"] = "1"        # the tiny voice's convs are below the engine's "worth it" thresholds:
+    os.environ["MI355VITS_B3_MIN_WORK"] = "0"  # route them through the split kernels anyway (read when a handle is created)
+    try:
+        eng = Engine(W.pack(cfg, w), library=emu_lib)
+    finally:
+        del os.environ["MI355VITS_WN_B3"], os.environ["MI355VITS_B3_MIN_WORK"]
     eng.set_math("bf16x3")
     Tx = 140
     forced = np.full((2, Tx), 4, np.int32)  # 560 frames
@@ -381,3 +388,25 @@ def test_bf16x3_engine_path_long_utterance_uses_the_staged_split_kernels(emu_lib
                           sid=np.array([0, 2]), weights=w, engine=eng)
     assert int(out["lengths"][0]) == 560 * cfg.hop_length
     eng.close()
+
+
+@pytest.mark.parametrize("n_speakers", [1, 3])
+def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
+    """k_wn_layer_b3 (H = 192: 96 columns x all 384 rows per workgroup, operands split 3 x bf16, raw result gated through
+    LDS, res/skip from the u planes): flow output `z` and the waveform vs the oracle, ragged batch with rows shorter and
+    longer than one 96-column tile, speaker conditioning; and against the f32 fused kernel."""
+    cfg = VitsConfig.tiny_h192(n_speakers=n_speakers)
+    w = W.synthetic_weights(cfg, seed=71, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    ids = np.random.default_rng(4).integers(1, cfg.num_symbols, (2, 30))
+    forced = np.full((2, 30), 4, np.int32)  # 120 and 68 frames
+    sid = np.array([2, 0]) if n_speakers > 1 else None
+    outs = {}
+    for mode in ("f32", "bf16x3"):
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math(mode)
+        outs[mode], _ = check_parity(emu_lib, cfg, ids=ids, lengths=np.array([30, 17]), forced=forced, noise=True, seed=71,
+                                     sid=sid, weights=w, engine=eng)
+        eng.close()
+    L = int(outs["f32"]["lengths"][1])
+    assert rel_rms(outs["bf16x3"]["audio"][1, :L], outs["f32"]["audio"][1, :L]) < 2e-5
