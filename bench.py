@@ -41,6 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); MATH_BF16X3 spends 6 bf16 products per f32 multiply-add
+PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 SAMPLE_RATE = 22050
 
@@ -53,13 +55,20 @@ def make_batch(B, Tx, base):
 class Workload:
     """One voice on one or more devices: ``streams`` engine handles per device, steps dealt to them in turn."""
 
-    def __init__(self, cfg, weights, devices, streams, B, Tx, fpi, rank, world, multispeaker_sid=False):
+    def __init__(self, cfg, weights, devices, streams, B, Tx, fpi, rank, world, multispeaker_sid=False, math=None):
         from mimic3_amd import weights as W
         from mimic3_amd._native import Engine
 
         self.cfg, self.B, self.Tx, self.fpi, self.rank, self.world = cfg, B, Tx, fpi, rank, world
         blob = W.pack(cfg, weights)
-        self.engines = [Engine(blob, device=d) for d in devices for _ in range(max(1, streams))]
+        self.engines = []
+        for d in devices:  # one weight replica per device, the further handles of a device share it
+            first = Engine(blob, device=d)
+            if math:
+                first.set_math(math)
+            self.engines.append(first)
+            self.engines.extend(first.clone() for _ in range(max(1, streams) - 1))
+        self.math = self.engines[0].math
         self.n_devices = len(devices)
         self.ids, self.lengths = make_batch(B, Tx, rank * B)
         self.forced = np.full((B, Tx), fpi, np.int32)
@@ -135,18 +144,25 @@ def kernel_table(eng, step, nsteps):
     return rep, table, tot_ms
 
 
-def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice):
+def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32"):
     dom = table[0]
     drec = rep[dom["kernel"]]
     dsec = drec["ms"] * 1e-3
     traffic = _pmc_traffic(dom["kernel"], workload_key, voice)
+    # the roof of the dominant kernel: kernels named *_b3 / running in MATH_BF16X3 execute six bf16 MFMA products per
+    # algorithmic f32 multiply-add, so their matrix-core roof is 2500 / 6 TFLOP/s of ALGORITHMIC f32 work
+    on_bf16 = math == "bf16x3" and any(t in dom["kernel"] for t in ("mrf", "wn_layer_b3", "dec.rb", "upsample.s0", "upsample.s1", "conv_pre"))
+    peak = PEAK_BF16X3_TFLOPS if on_bf16 else PEAK_FP32_TFLOPS
     return {
         "kernel": dom["kernel"],
         "bound": "mfma",
         "achieved": drec["flops"] / dsec / 1e12,
-        "peak": PEAK_FP32_TFLOPS,
+        "peak": peak,
         "unit": "TFLOP/s",
-        "frac": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
+        "frac": drec["flops"] / dsec / 1e12 / peak,
+        "matrix_core_path": ("v_mfma_f32_32x32x16_bf16 x 6 partial products per f32 multiply-add (operands split 3 x bf16, f32 "
+                             "accumulate): peak = 2500 TFLOP/s dense bf16 / 6") if on_bf16 else "v_mfma_f32_32x32x2_f32: peak = 157.3 TFLOP/s",
+        "frac_of_f32_mfma_peak": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
         "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
         "traffic_detail": traffic,
         "algorithmic_flops_per_launch": drec["flops"] / drec["calls"],
@@ -155,9 +171,11 @@ def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice):
         "launches": drec["calls"],
         "hbm_algorithmic_gbs": drec["bytes"] / dsec / 1e9,
         "hbm_frac": drec["bytes"] / dsec / 1e9 / PEAK_HBM_GBS,
-        "note": "fp32 Conv1d is compute-bound on MI355X (AI >= 24 FLOP/B vs ridge 19.7): peak = 157.3 TFLOP/s fp32 "
-                "matrix-core rate; hbm_* give the same launches against the 8 TB/s HBM roof as BASELINE asks; traffic = "
-                "rocprofv3 PMC passes of this workload committed under profiles/ (counters cannot be read in-process)",
+        "note": "achieved = ALGORITHMIC f32 FLOPs (2 x Cout x Cin x K per output sample, halo recompute not counted) / launch "
+                "time by HIP events on the engine stream; the dense Conv1d stacks are matrix-core-bound on MI355X (AI >= 24 "
+                "FLOP/B vs ridge 19.7 at f32); hbm_* give the same launches against the 8 TB/s HBM roof as BASELINE asks; "
+                "traffic = rocprofv3 PMC passes of this workload committed under profiles/ (counters cannot be read "
+                "in-process)",
         "whole_step": {
             "tflops": sum(v["flops"] for v in rep.values()) / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
             "hbm_algorithmic_gbs": sum(v["bytes"] for v in rep.values()) / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
@@ -183,6 +201,9 @@ def main():
     ap.add_argument("--frames-per-id", type=int, default=6)
     ap.add_argument("--voice", choices=["apope_low", "vctk_low"], default="apope_low",
                     help="headline voice (BASELINE metric: apope_low; vctk_low is measured as an extra leg either way)")
+    ap.add_argument("--math", choices=["bf16x3", "f32"], default=None,
+                    help="matrix-core path of the dense convs (default: the engine's, MI355VITS_MATH or bf16x3 = f32 operands "
+                         "split exactly into 3 bf16 terms, six MFMA products, f32 accumulate; f32 = v_mfma_f32 only)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "3")),
                     help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
     ap.add_argument("--single-process", action="store_true",
@@ -226,8 +247,10 @@ def main():
     n_gpus = args.gpus if single else world
     B, Tx, fpi = args.batch, args.tx, args.frames_per_id
     # single-process: every step of every device is one batch of B utterances; the job's step = n_gpus batches
-    wl = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker)
+    wl = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
+                  math=args.math)
     eng = wl.engines[0]
+    math = wl.math
 
     def barrier():
         if dist is not None:
@@ -272,7 +295,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if math == "f32" else "f32 (dense convs: operands split exactly into 3 x bf16, 6 bf16-MFMA products per "
+                                             "multiply-add, f32 accumulate; f32 in / f32 out, parity at the f32 tolerances)",
+        "math": math,
         "data": f"synthetic (seeded random-init weights of the {args.voice} shapes, seeded phoneme ids)",
         "config": {
             "workload": f"{'en_UK/apope_low' if args.voice == 'apope_low' else 'en_US/vctk_low'}, {B} utterances/GPU x {Tx} "
@@ -343,7 +368,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         nsteps = 3
         rep, table, tot_ms = kernel_table(eng, lambda i: wl.step(i, device_only=True), nsteps)
-        result["roofline"] = roofline_of(rep, table, tot_ms, nsteps, [B, Tx, fpi], args.voice)
+        result["roofline"] = roofline_of(rep, table, tot_ms, nsteps, [B, Tx, fpi], args.voice, math)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w") as f:
             json.dump(table, f, indent=1)
@@ -353,7 +378,7 @@ def main():
         # ---- BASELINE.json configs[2]: en_US/vctk_low multi-speaker, batch 32 x 128 phonemes, one MI355X
         vcfg = VitsConfig.vctk_low()
         vw = Workload(vcfg, W.synthetic_weights(vcfg, seed=1234), devices, args.streams, 32, 128, fpi, 0, 1,
-                      multispeaker_sid=True)
+                      multispeaker_sid=True, math=args.math)
         vw.size_workspaces()
         vsteps = max(20, args.steps // 3)
         el_v, out_v = timed(vw, vsteps, 5)
@@ -362,16 +387,52 @@ def main():
             "workload": f"en_US/vctk_low (109 speakers, gin 512), 32 utterances x 128 phoneme ids, sid = b mod 109, forced "
                         f"{fpi} frames/id; host-to-host",
             "value": sps * vsteps / el_v, "unit": "samples/s", "steps": vsteps, "ms_per_step": el_v / vsteps * 1e3,
-            "x_realtime": (sps / SAMPLE_RATE) / (el_v / vsteps), "dtype": "f32",
+            "x_realtime": (sps / SAMPLE_RATE) / (el_v / vsteps), "dtype": "f32", "math": math,
         }
         if not args.no_roofline:
             repv, tablev, totv = kernel_table(vw.engines[0], lambda i: vw.step(i, device_only=True), 3)
-            extra["roofline"] = roofline_of(repv, tablev, totv, 3, [32, 128, fpi], "vctk_low")
+            extra["roofline"] = roofline_of(repv, tablev, totv, 3, [32, 128, fpi], "vctk_low", math)
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_vctk.json"), "w") as f:
                 json.dump(tablev, f, indent=1)
             print_table("vctk_low b32, per-kernel (HIP events):", tablev[:12])
         result["extra"] = {"vctk_low_b32": extra}
         vw.close()
+        if math != "f32":
+            # ---- the same headline workload on the pure f32-MFMA path (v_mfma_f32_32x32x2_f32 everywhere), for reference
+            fw = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
+                          math="f32")
+            fw.size_workspaces()
+            fsteps = max(20, args.steps // 4)
+            el_f, out_f = timed(fw, fsteps, 5)
+            f32_leg = {"math": "f32", "value": int(out_f["lengths"].sum()) * fsteps / el_f, "unit": "samples/s", "steps": fsteps,
+                       "ms_per_step": el_f / fsteps * 1e3,
+                       "note": "same workload, every dense conv on v_mfma_f32_32x32x2_f32 (MI355VITS_MATH=f32)"}
+            if not args.no_roofline:
+                repf, tablef, totf = kernel_table(fw.engines[0], lambda i: fw.step(i, device_only=True), 3)
+                f32_leg["roofline"] = roofline_of(repf, tablef, totf, 3, [B, Tx, fpi], args.voice, "f32")
+                with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_f32.json"), "w") as f:
+                    json.dump(tablef, f, indent=1)
+            result["extra"]["f32_mfma"] = f32_leg
+            fw.close()
+            # ---- BASELINE.json configs[4], first slice: bf16 weights (reduced precision: its own tolerance, rel RMS <= 2e-2,
+            # tests/test_gpu_parity.py::test_bf16_weights_mode_at_its_own_tolerance) — never the headline
+            bw = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
+                          math="bf16w")
+            bw.size_workspaces()
+            el_b, out_b = timed(bw, fsteps, 5)
+            bw_leg = {"math": "bf16w", "dtype": "bf16-weights (bf16 x exact-f32 activations, f32 accumulate)",
+                      "value": int(out_b["lengths"].sum()) * fsteps / el_b, "unit": "samples/s", "steps": fsteps,
+                      "ms_per_step": el_b / fsteps * 1e3,
+                      "note": "same workload, weights rounded to bf16 (3 bf16-MFMA products per multiply-add); reduced precision"}
+            if not args.no_roofline:
+                repb, tableb, totb = kernel_table(bw.engines[0], lambda i: bw.step(i, device_only=True), 3)
+                rl = roofline_of(repb, tableb, totb, 3, [B, Tx, fpi], args.voice, "bf16x3")
+                rl["peak"] = PEAK_BF16_TFLOPS / 3.0
+                rl["frac"] = rl["achieved"] / rl["peak"]
+                rl["matrix_core_path"] = "v_mfma_f32_32x32x16_bf16 x 3 partial products per multiply-add: peak = 2500 / 3 TFLOP/s"
+                bw_leg["roofline"] = rl
+            result["extra"]["bf16_weights"] = bw_leg
+            bw.close()
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, wl, args.cpu_seconds)

@@ -6,17 +6,19 @@
 
 namespace m355 {
 
-template <int MT, int NT, int NG>  // NG 16-channel groups per chunk
-__device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NT], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS /*plane stride*/,
+// W1: the weights contribute their leading bf16 term only ("bf16 weights", MATH_BF16W): three products per multiply-add
+template <int MT, int NT, int NG, int NA = NT, bool W1 = false>  // NG 16-channel groups per chunk; NA >= NT: accumulator array extent
+__device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NA], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS /*plane stride*/,
                                          int LD, int K, int groups_per_tap, int dil) {
     // wp[i]: (tap 0, first group of this chunk, plane 0) of row tile i, lane offset included; a group is 192 uint4,
     // consecutive taps are groups_per_tap * 192 apart.  xq: (plane 0, group 0, this lane's half and column).
     uint4 ra[2][MT][3];
     uint4 rb[2][NT][3];
+    constexpr int NPA = W1 ? 1 : 3;  // weight planes fetched
     MI355_UNROLL
     for (int i = 0; i < MT; ++i)
         MI355_UNROLL
-        for (int p = 0; p < 3; ++p) ra[0][i][p] = wp[i][p * 64];
+        for (int p = 0; p < NPA; ++p) ra[0][i][p] = wp[i][p * 64];
     MI355_UNROLL
     for (int j = 0; j < NT; ++j)
         MI355_UNROLL
@@ -33,7 +35,7 @@ __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NT], const uint4* con
             MI355_UNROLL
             for (int i = 0; i < MT; ++i)
                 MI355_UNROLL
-                for (int p = 0; p < 3; ++p) ra[nxt][i][p] = wp[i][woff + p * 64];
+                for (int p = 0; p < NPA; ++p) ra[nxt][i][p] = wp[i][woff + p * 64];
             MI355_UNROLL
             for (int j = 0; j < NT; ++j)
                 MI355_UNROLL
@@ -44,10 +46,10 @@ __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NT], const uint4* con
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) {
                     f32x16 c = acc[i][j];
-                    c = MFMA_32x32x16_BF16(ra[cur][i][2], rb[cur][j][0], c);  // small terms first
+                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[cur][i][2], rb[cur][j][0], c);  // small terms first
                     c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][2], c);
-                    c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][1], c);
-                    c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][0], c);
+                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][1], c);
+                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][0], c);
                     c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][1], c);
                     c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][0], c);
                     acc[i][j] = c;
@@ -64,41 +66,53 @@ template <int NG>
 __device__ __forceinline__ void stage_planes(const float* __restrict__ xb, long x_ld, int LD, int ts, int tend, float slope,
                                              uint4* __restrict__ planes, int PS, int vec, int nthreads = 256) {
     const int ld4 = LD >> 2;
-    for (int idx = threadIdx.x; idx < NG * 2 * ld4; idx += nthreads) {
-        const int gh = idx / ld4, c4 = idx - gh * ld4;  // gh = group * 2 + half
-        const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
-        const int tt = ts + 4 * c4;
-        float v[8][4];
-        // the in-range test depends on the columns only: one branch around all eight rows, so that the eight loads are
-        // in flight together (a test per row makes hipcc wait for every load before it issues the next)
-        if (vec && tt >= 0 && tt + 3 < tend) {
-            float4 r4[8];
-            MI355_UNROLL
-            for (int e = 0; e < 8; ++e) r4[e] = *reinterpret_cast<const float4*>(xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld + tt);
-            MI355_UNROLL
-            for (int e = 0; e < 8; ++e) { v[e][0] = r4[e].x; v[e][1] = r4[e].y; v[e][2] = r4[e].z; v[e][3] = r4[e].w; }
-        } else {
-            MI355_UNROLL
-            for (int e = 0; e < 8; ++e) {
-                const float* row = xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld;
+    const int n_items = NG * 2 * ld4;
+    // two items per thread and pass: their sixteen 16-byte loads are in flight together (one memory round trip per pass)
+    for (int idx0 = threadIdx.x; idx0 < n_items; idx0 += 2 * nthreads) {
+        float v[2][8][4];
+        MI355_UNROLL
+        for (int u = 0; u < 2; ++u) {
+            const int idx = idx0 + u * nthreads;
+            const int idc = idx < n_items ? idx : idx0;  // a missing second item re-reads the first (discarded)
+            const int gh = idc / ld4, c4 = idc - gh * ld4;  // gh = group * 2 + half
+            const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
+            const int tt = ts + 4 * c4;
+            // the in-range test depends on the columns only: one branch around all eight rows, so that the eight loads
+            // are in flight together (a test per row makes hipcc wait for every load before it issues the next)
+            if (vec && tt >= 0 && tt + 3 < tend) {
+                float4 r4[8];
                 MI355_UNROLL
-                for (int j = 0; j < 4; ++j) v[e][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
+                for (int e = 0; e < 8; ++e) r4[e] = *reinterpret_cast<const float4*>(xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld + tt);
+                MI355_UNROLL
+                for (int e = 0; e < 8; ++e) { v[u][e][0] = r4[e].x; v[u][e][1] = r4[e].y; v[u][e][2] = r4[e].z; v[u][e][3] = r4[e].w; }
+            } else {
+                MI355_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const float* row = xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld;
+                    MI355_UNROLL
+                    for (int j = 0; j < 4; ++j) v[u][e][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
+                }
             }
         }
         MI355_UNROLL
-        for (int j = 0; j < 4; ++j) {
-            uint4 h, m, l;
-            split3_pk(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), h.x, m.x, l.x);
-            split3_pk(lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope), h.y, m.y, l.y);
-            split3_pk(lrelu_f(v[4][j], slope), lrelu_f(v[5][j], slope), h.z, m.z, l.z);
-            split3_pk(lrelu_f(v[6][j], slope), lrelu_f(v[7][j], slope), h.w, m.w, l.w);
-            const int o = gh * LD + 4 * c4 + j;
-            planes[o] = h;
-            planes[PS + o] = m;
-            planes[2 * PS + o] = l;
+        for (int u = 0; u < 2; ++u) {
+            const int idx = idx0 + u * nthreads;
+            if (idx >= n_items) continue;
+            const int gh = idx / ld4, c4 = idx - gh * ld4;
+            MI355_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                uint4 h, m, l;
+                split3_pk(lrelu_f(v[u][0][j], slope), lrelu_f(v[u][1][j], slope), h.x, m.x, l.x);
+                split3_pk(lrelu_f(v[u][2][j], slope), lrelu_f(v[u][3][j], slope), h.y, m.y, l.y);
+                split3_pk(lrelu_f(v[u][4][j], slope), lrelu_f(v[u][5][j], slope), h.z, m.z, l.z);
+                split3_pk(lrelu_f(v[u][6][j], slope), lrelu_f(v[u][7][j], slope), h.w, m.w, l.w);
+                const int o = gh * LD + 4 * c4 + j;
+                planes[o] = h;
+                planes[PS + o] = m;
+                planes[2 * PS + o] = l;
+            }
         }
     }
 }
-
 
 }  // namespace m355

@@ -347,6 +347,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         math_ = lane0.math_;
         b3_min_work_ = lane0.b3_min_work_;
         wn_b3_ = lane0.wn_b3_;
+        no_mrf_b3_ = lane0.no_mrf_b3_;
     } catch (...) {
         release();
         throw;
@@ -372,16 +373,21 @@ void Engine::open_device(int device) {
     const char* bw = getenv("MI355VITS_B3_MIN_WORK");
     b3_min_work_ = bw ? atoi(bw) : 256;
     wn_b3_ = getenv("MI355VITS_WN_B3") != nullptr;
+    // pre-split LDS planes for the 32 / 64-channel MRF stages: measured slower than splitting on the fly (3.17 / 2.79 ms vs
+    // 2.82 / 2.71 ms per step: four waves cannot hide the plane <-> row conversions of the epilogues), so it is opt-in
+    no_mrf_b3_ = getenv("MI355VITS_MRF_PRESPLIT") == nullptr;
+    math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
     const char* mm = getenv("MI355VITS_MATH");
     if (mm && mm[0]) {
         if (!strcmp(mm, "bf16x3")) math_ = MATH_BF16X3;
         else if (!strcmp(mm, "f32")) math_ = MATH_F32;
-        else throw EngineError(MI355VITS_ERR_INVALID, std::string("MI355VITS_MATH: unknown mode '") + mm + "' (f32 | bf16x3)");
+        else if (!strcmp(mm, "bf16w")) math_ = MATH_BF16W;
+        else throw EngineError(MI355VITS_ERR_INVALID, std::string("MI355VITS_MATH: unknown mode '") + mm + "' (f32 | bf16x3 | bf16w)");
     }
 }
 
 void Engine::set_math(int mode) {
-    if (mode != MATH_F32 && mode != MATH_BF16X3) throw EngineError(MI355VITS_ERR_INVALID, "unknown math mode");
+    if (mode != MATH_F32 && mode != MATH_BF16X3 && mode != MATH_BF16W) throw EngineError(MI355VITS_ERR_INVALID, "unknown math mode");
     math_ = mode;
 }
 
@@ -587,9 +593,11 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
         // split-bf16 staged kernel where it pays: convs with little work per staged chunk (1x1 convs, the last
         // upsampler: K * Cin < 256) spend more on splitting the chunk than the faster matrix-core loop saves
         // (measured: flow.pre / post, res_skip, upsample 64 -> 32); MI355VITS_B3_MIN_WORK overrides the threshold (tests)
-        if (math_ == MATH_BF16X3 && w.packed_b3s != NO_OFF && (a.math == MATH_BF16X3 || (w.K * w.Cin >= b3_min_work_ && a.epi == EPI_STD))) {
+        if (math_on_bf16(math_) && w.packed_b3s != NO_OFF && (math_on_bf16(a.math) || (w.K * w.Cin >= b3_min_work_ && a.epi == EPI_STD))) {
             a.wb3 = P(w.packed_b3s);
-            a.math = MATH_BF16X3;
+            a.math = math_;
+        } else {
+            a.math = MATH_F32;
         }
         launch_conv1d_mfma(a, stream_);
     } else {
@@ -843,9 +851,9 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             // through HBM: 38 MB per layer, nothing next to the matrix-core time saved); the fused kernel is f32-MFMA
             // in-layer + res/skip through the staged split-bf16 kernel instead of the fused f32 layer: measured 2.09 + 1.70 ms
             // vs 3.65 ms per step — no gain (small grids, scalar res/skip epilogue); opt-in for A/B and for the tests
-            const bool wn_b3 = wn_b3_ && math_ == MATH_BF16X3 && win.packed_b3s != NO_OFF && wrs.packed_b3s != NO_OFF &&
+            const bool wn_b3 = wn_b3_ && math_on_bf16(math_) && win.packed_b3s != NO_OFF && wrs.packed_b3s != NO_OFF &&
                                conv1d_b3_supported(win.Cin, win.Cout, win.K, dil, Ty) && !force_generic_;
-            if (!force_generic_ && !no_fused_wn_ && !wn_b3 && math_ == MATH_BF16X3 && win.packed_b3w != NO_OFF &&
+            if (!force_generic_ && !no_fused_wn_ && !wn_b3 && math_on_bf16(math_) && win.packed_b3w != NO_OFF &&
                 wrs.packed_b3s != NO_OFF && wn_layer_b3_supported(H, win.K, dil)) {
                 // fused layer on the bf16 matrix cores.  Chosen by the layer shape alone (never by the grid size), so a
                 // row's bits do not depend on what it is batched with.
@@ -857,6 +865,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 w.cond = cond_l; w.cond_bs = 2L * H * c.flow_wn_layers;
                 w.len = d_ylen_;
                 w.B = B; w.H = H; w.T = Ty; w.K = win.K; w.dil = dil; w.Crs = wrs.Cout; w.skip_init = (l == 0);
+                w.math = math_;
                 const double fl = 2.0 * B * (double)Ty * H * ((double)win.Cout * win.K + wrs.Cout);
                 ProfScope ps(prof_, "flow.wn_layer_b3", fl, 4.0 * B * (double)Ty * H * 4);
                 launch_wn_layer_b3(w, stream_);
@@ -887,7 +896,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 in.cond_bs = 2L * H * c.flow_wn_layers;
             }
             in.B = B; in.T = Ty;
-            if (wn_b3) in.math = MATH_BF16X3;
+            if (wn_b3) in.math = math_;
             conv("flow.in_gate", win, in);
             ConvArgs rs;
             rs.x = d_fu_; rs.x_bs = hbs; rs.x_ld = Ty;
@@ -896,7 +905,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             rs.epi = EPI_RESSKIP; rs.H = H; rs.skip_init = (l == 0);
             rs.out_len = d_ylen_;
             rs.B = B; rs.T = Ty;
-            if (wn_b3) rs.math = MATH_BF16X3;
+            if (wn_b3) rs.math = math_;
             conv("flow.res_skip", wrs, rs);
         }
         ConvArgs post;
@@ -964,15 +973,38 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.d1[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 0];
                     m.d2[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 1];
                 }
+                // MATH_BF16X3, 32 / 64 channels: the whole stage on pre-split planes
+                bool all_b3s = math_ == MATH_BF16X3;  // (pre-split variant: BF16X3 only)
+                for (int j = 0; j < nk && all_b3s; ++j)
+                    for (int q = 0; q < 2; ++q) all_b3s = all_b3s && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3s != NO_OFF;
+                if (all_b3s && !no_mrf_b3_ && mrf_b3_supported(ch, nk, m.k, m.d1, m.d2)) {
+                    double flops = 0;
+                    for (int j = 0; j < nk; ++j) {
+                        for (int q = 0; q < 2; ++q) {
+                            const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
+                            m.w[j][q] = P(w.packed_b3s);
+                            m.bias[j][q] = P(w.bias);
+                        }
+                        flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];
+                    }
+                    m.nrb = nk;
+                    m.math = MATH_BF16X3;
+                    m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
+                    m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
+                    m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
+                    ProfScope ps(prof_, i == 1 ? "dec.mrf_b3.s1" : (i == 2 ? "dec.mrf_b3.s2" : "dec.mrf_b3"), flops, 8.0 * B * (double)T * ch);
+                    launch_mrf_b3(m, stream_);
+                    n_fused = nk;
+                }
                 // the longest prefix of resblocks whose tiles fit LDS together (128 channels: only the narrow ones)
-                int p = nk;
+                int p = n_fused ? 0 : nk;
                 while (p > 0 && !(mrf_fused_supported(ch, p, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF)) --p;
                 if (p > 0) {
                     double flops = 0;
-                    bool b3 = math_ == MATH_BF16X3;
+                    bool b3 = math_on_bf16(math_);
                     for (int j = 0; j < p; ++j)
                         for (int q = 0; q < 2; ++q) b3 = b3 && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3 != NO_OFF;
-                    m.math = b3 ? MATH_BF16X3 : MATH_F32;
+                    m.math = b3 ? math_ : MATH_F32;
                     for (int j = 0; j < p; ++j) {
                         for (int q = 0; q < 2; ++q) {
                             const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));

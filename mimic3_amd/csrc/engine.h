@@ -165,8 +165,9 @@ class Engine {
     bool timed_ = false;
     bool force_generic_ = false;
     int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
+    bool no_mrf_b3_ = false;     // MATH_BF16X3: keep the on-the-fly split MRF kernel (A/B against the pre-split one)
     bool wn_b3_ = false;         // MATH_BF16X3: WaveNet layers as two staged split-bf16 convs instead of the fused f32 layer
-    int math_ = MATH_F32;        // which matrix-core path the dense convs take (include/mi355vits.h: MI355VITS_MATH_*)
+    int math_ = MATH_BF16X3;     // which matrix-core path the dense convs take (include/mi355vits.h: MI355VITS_MATH_*)
     bool no_fused_wn_ = false;   // MI355VITS_NO_FUSED_WN=1: in-layer + res/skip as two launches (A/B + fallback)
     bool no_fused_mrf_ = false;  // MI355VITS_NO_FUSED_MRF=1: conv-by-conv resblocks (A/B + fallback)
     Profiler prof_;

@@ -57,7 +57,8 @@ void regroup_packed_x4(const float* packed, size_t n_floats, float* out);  // fu
 // v_mfma_f32_32x32x16_bf16: [Cout/32][K][Cin/16][plane h,m,l][64 lanes][8 bf16]; lane l = (half l >> 5, row l & 31)
 // holds the k-slots e < 4: channel 16G + half + 2e, e >= 4: 16G + 8 + half + 2(e - 4) — the channels a lane's two
 // ds_read_b128 of a packed activation tile deliver.  Needs Cin % 16 == 0 and Cout % 32 == 0; sizes in 32-bit words.
-enum MathMode { MATH_F32 = 0, MATH_BF16X3 = 1 };
+enum MathMode { MATH_F32 = 0, MATH_BF16X3 = 1, MATH_BF16W = 2 };  // BF16W: BF16X3 with the weights' leading bf16 term only
+inline bool math_on_bf16(int m) { return m == MATH_BF16X3 || m == MATH_BF16W; }
 size_t bf16x3_packed_words(int Cout, int Cin, int K);
 void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out);
 // general form: epi selects the tile -> output-channel map (EPI_GATE: tile pairs (c, H + c)), layout the k-slot ->
@@ -107,6 +108,9 @@ struct MrfArgs {
 };
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);
+// MATH_BF16X3 with pre-split LDS planes (C = 32 or 64); w[][] = pack_conv_weights_bf16x3_mode(..., EPI_STD, layout 1)
+bool mrf_b3_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
+void launch_mrf_b3(MrfArgs a, hipStream_t s);
 
 // ---------------------------------------------------------------- fused WaveNet layer of the coupling flow (K8)
 // u = tanh(in(h)[:H] + cond) * sigmoid(in(h)[H:] + cond); rs = res_skip(u); h' = (h + rs[:H]) * mask; skip += rs[H:]
@@ -122,6 +126,7 @@ struct WnArgs {
     int B = 1, H = 0, T = 0, K = 1, dil = 1, Crs = 0, skip_init = 0;
     int ldx = 0, vec = 0;  // filled by the launcher
     int ablate = 0;        // timing experiments only (MI355VITS_WN_ABLATE): 1 no MFMA loops, 2 no staging, 4 no stores
+    int math = 0;          // launch_wn_layer_b3: MATH_BF16X3 or MATH_BF16W
 };
 bool wn_layer_fused_supported(int H, int K, int dil);
 void launch_wn_layer(WnArgs a, hipStream_t s);

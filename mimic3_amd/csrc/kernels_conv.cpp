@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void 
 //   * MT x NT accumulator tiles per wave share every fetch (A across NT columns tiles, B across MT row tiles);
 //     the epilogues are the f32 kernel's.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int EPI, int NG>
+template <int MT, int NT, int WM, int WN, int EPI, int NG, bool W1 = false>
 __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
                 if (tile >= n_tiles) tile = n_tiles - 1;  // out-of-range tile: recompute the last one, discarded below
                 wp[i] = reinterpret_cast<const uint4*>(a.wb3) + ((long)tile * a.K * gpt + (c0 >> 4)) * 192 + lane;
             }
-            b3_chunk<MT, NT, NG>(acc, wp, planes + brow * LD + bcol + wn * NT * 32 + toff, PS, LD, a.K, gpt, a.dil);
+            b3_chunk<MT, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + wn * NT * 32 + toff, PS, LD, a.K, gpt, a.dil);
         }
         __syncthreads();
     }
@@ -1043,14 +1043,17 @@ void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
         const size_t need = (size_t)(32 * WM) * (T_B + 4) * sizeof(float);
         if (need > shmem) shmem = need;
     }
-    auto kfn = k_conv1d_b3<MT, NT, WM, WN, EPI, 2>;
+    auto go = [&](auto kfn) {
 #ifndef MI355_EMU
-    if (shmem > 64 * 1024) {
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)once;
-    }
+        if (shmem > 64 * 1024) {
+            static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)once;
+        }
 #endif
-    LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av);
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av);
+    };
+    if (a.math == MATH_BF16W) go(k_conv1d_b3<MT, NT, WM, WN, EPI, 2, true>);
+    else go(k_conv1d_b3<MT, NT, WM, WN, EPI, 2, false>);
 }
 
 template <int MT, int NT, int WM, int WN, int EPI>
@@ -1079,7 +1082,7 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     a.ablate = ablate;
     if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
     const int n_tiles = n_tiles_for(a.epi, a.Cout, a.H);
-    if (a.math == MATH_BF16X3 && a.wb3 && conv1d_b3_supported(a.Cin, a.Cout, a.K, a.dil, a.T)) {
+    if (math_on_bf16(a.math) && a.wb3 && conv1d_b3_supported(a.Cin, a.Cout, a.K, a.dil, a.T)) {
         // split-bf16 path: one tile shape per epilogue kind (fixed by the layer, never by the batch)
         if (a.epi == EPI_GATE) launch_b3<2, 3, 2, 2, EPI_GATE>(a, n_tiles, s);
         else if (a.epi == EPI_RESSKIP) {

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "b3.h"
 
 namespace m355 {
 
@@ -78,16 +79,17 @@ __device__ __forceinline__ void mfma_conv_tiles(f32x16 (&acc)[NA], const float4*
 // same packed f32 tiles: a lane's eight k-slots of a 16-channel group are two ds_read_b128 (channels 16G + brow + 2e and
 // 16G + 8 + brow + 2e), split in registers; the weights come pre-split ([tile][tap][16-ch group][plane][lane] x 16 B,
 // pack_conv_weights_bf16x3).  A planes and the raw B floats are fetched one group ahead.
-template <int NTL, int NA, int CP>
+template <int NTL, int NA, int CP, bool W1 = false>
 __device__ __forceinline__ void mfma_conv_tiles_b3(f32x16 (&acc)[NA], const uint4* __restrict__ wp, const float4* __restrict__ x4,
                                                    int tstride, int LD, int K, int dil, int ablate) {
     static_assert(NTL <= NA, "tile count");
     static_assert(CP % 16 == 0, "channel pairs per tap must be a multiple of 16");
     if (ablate & 1) return;
     constexpr int NG = CP / 8;  // 16-channel groups per tap (even)
+    constexpr int NPA = W1 ? 1 : 3;  // weight planes fetched ("bf16 weights": the leading term only)
     uint4 ra[2][3];
     MI355_UNROLL
-    for (int p = 0; p < 3; ++p) ra[0][p] = wp[p * 64];
+    for (int p = 0; p < NPA; ++p) ra[0][p] = wp[p * 64];
     float4 xb[2][NTL][2];
     MI355_UNROLL
     for (int i = 0; i < NTL; ++i) {
@@ -103,7 +105,7 @@ __device__ __forceinline__ void mfma_conv_tiles_b3(f32x16 (&acc)[NA], const uint
             // next group's operands (the very last iteration re-reads its own: every load stays unconditional)
             const uint4* wa = (last_tap && g + 1 >= NG) ? wk + g * 192 : wk + (g + 1) * 192;
             MI355_UNROLL
-            for (int p = 0; p < 3; ++p) ra[(g + 1) & 1][p] = wa[p * 64];
+            for (int p = 0; p < NPA; ++p) ra[(g + 1) & 1][p] = wa[p * 64];
             const float4* xn = (g + 1 < NG) ? xk + (g + 1) * 4 * LD : (last_tap ? xk + g * 4 * LD : xk + dil);
             MI355_UNROLL
             for (int i = 0; i < NTL; ++i) {
@@ -111,16 +113,16 @@ __device__ __forceinline__ void mfma_conv_tiles_b3(f32x16 (&acc)[NA], const uint
                 xb[(g + 1) & 1][i][1] = xn[i * tstride + 2 * LD];
             }
             SCHED_FENCE();  // the prefetches stay ahead of this group's arithmetic (hipcc would sink them to their use)
-            const uint4 ah = ra[g & 1][0], am = ra[g & 1][1], al = ra[g & 1][2];
+            const uint4 ah = ra[g & 1][0], am = ra[g & 1][W1 ? 0 : 1], al = ra[g & 1][W1 ? 0 : 2];
             MI355_UNROLL
             for (int i = 0; i < NTL; ++i) {
                 uint4 bh, bm, bl;
                 split3_x8(xb[g & 1][i][0], xb[g & 1][i][1], bh, bm, bl);
                 // small terms first
-                acc[i] = MFMA_32x32x16_BF16(al, bh, acc[i]);
+                if constexpr (!W1) acc[i] = MFMA_32x32x16_BF16(al, bh, acc[i]);
                 acc[i] = MFMA_32x32x16_BF16(ah, bl, acc[i]);
-                acc[i] = MFMA_32x32x16_BF16(am, bm, acc[i]);
-                acc[i] = MFMA_32x32x16_BF16(am, bh, acc[i]);
+                if constexpr (!W1) acc[i] = MFMA_32x32x16_BF16(am, bm, acc[i]);
+                if constexpr (!W1) acc[i] = MFMA_32x32x16_BF16(am, bh, acc[i]);
                 acc[i] = MFMA_32x32x16_BF16(ah, bm, acc[i]);
                 acc[i] = MFMA_32x32x16_BF16(ah, bh, acc[i]);
             }
@@ -133,9 +135,9 @@ __device__ __forceinline__ void mfma_conv_tiles_b3(f32x16 (&acc)[NA], const uint
 template <int MATH, int NTL, int NA, int CP>
 __device__ __forceinline__ void conv_tiles(f32x16 (&acc)[NA], const float* __restrict__ w, int wm, int lane, const float4* __restrict__ x4,
                                            int tstride, int LD, int K, int dil, int ablate) {
-    if constexpr (MATH == 1) {
+    if constexpr (MATH == 1 || MATH == 2) {
         const uint4* wp = reinterpret_cast<const uint4*>(w) + (long)wm * K * (CP / 8) * 192 + lane;
-        mfma_conv_tiles_b3<NTL, NA, CP>(acc, wp, x4, tstride, LD, K, dil, ablate);
+        mfma_conv_tiles_b3<NTL, NA, CP, MATH == 2>(acc, wp, x4, tstride, LD, K, dil, ablate);
     } else {
         const float4* wp = reinterpret_cast<const float4*>(w + (long)wm * K * CP * 64) + lane;
         mfma_conv_tiles<NTL, NA, CP>(acc, wp, x4, tstride, LD, K, dil, ablate);
@@ -188,7 +190,8 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
 // finishes its conv2 share early flows straight into the next MFMA stream instead of idling at a barrier.
 // LDXC / LD1C: row pitches of the two LDS tiles when known at compile time (the "_low" voices' stage shapes): every
 // ds_read of an unrolled k-step group then carries its offset as an immediate; 0 = take them from the arguments.
-// MATH: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f32 operands split 3 x bf16, six products on the bf16 MFMA.
+// MATH: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f32 operands split 3 x bf16, six products on the bf16 MFMA,
+// 2 = the same with the weights' leading bf16 term only (three products; "bf16 weights").
 template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0, int MATH = 0>
 __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 8, "8 waves per workgroup");
@@ -342,7 +345,7 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     };
-    if (a.math == 1) {
+    if (a.math == MATH_BF16X3) {
         if (a.C == 32) {
             if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1>);
             else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 1>);
@@ -355,6 +358,12 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
         }
         return;
     }
+    if (a.math == MATH_BF16W) {  // generic row pitches only: this mode is a measured variant, not the product default
+        if (a.C == 32) go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 2>);
+        else if (a.C == 128) go(k_mrf_fused<4, 2, 3, 3, 2, 0, 0, 2>);
+        else go(k_mrf_fused<2, 4, 6, 3, 2, 0, 0, 2>);
+        return;
+    }
     if (a.C == 32) {
         if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608>);
         else go(k_mrf_fused<1, 8, 16, 3, 2>);
@@ -365,6 +374,224 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
         if (a.ldx == 320 && a.ld1 == 288) go(k_mrf_fused<2, 4, 6, 3, 2, 320, 288>);
         else go(k_mrf_fused<2, 4, 6, 3, 2>);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused stage in MATH_BF16X3 with the split done once per element: both LDS tiles hold three bf16 PLANES
+// ([plane][16-channel group][half][column] x 16 B, b3.h) instead of f32 values, so the matrix-core loops carry no VALU
+// work at all (on the fly the split costs as much issue time as the MFMAs it feeds: tools/bf16x3_probe, V3 vs V5).
+//   * x (+halo) is split while it is staged (stage_planes), x1 in conv1's epilogue — a lane's 16 rows of a 32 x 32 tile
+//     are exactly two 16-byte plane records (eight channels each), so the epilogue writes 6 ds_write_b128 per tile and
+//     the residual / accumulator preload reads 6 ds_read_b128 (x = h + m + l exactly);
+//   * four waves, one per SIMD with the whole register file: a wave owns a contiguous run of up to NT1MAX column tiles
+//     of one 32-row tile, every weight fragment feeds all of them (b3_chunk);
+//   * 6 B per element instead of 4: T_B = 256 columns for 32 channels, 128 for 64 (halo 45 + 36 per side).
+// ------------------------------------------------------------------------------------------------
+// a lane's rows r = 0..7 (a = 0, 1) of row tile wm are the eight k-slots of record [group 2 wm][half brow], rows 8..15 of
+// [group 2 wm + 1][half brow]: value of row r = plane sums of slot (r & 3) + 4 ((r >> 2) & 1)
+__device__ __forceinline__ void planes_to_rows(const uint4* __restrict__ P, int PS, int LD, int wm, int brow, int col, float (&v)[16]) {
+    MI355_UNROLL
+    for (int hg = 0; hg < 2; ++hg) {
+        const int o = ((2 * wm + hg) * 2 + brow) * LD + col;
+        const uint4 h = P[o], m = P[PS + o], l = P[2 * PS + o];
+        const unsigned hh[4] = {h.x, h.y, h.z, h.w}, mm[4] = {m.x, m.y, m.z, m.w}, ll[4] = {l.x, l.y, l.z, l.w};
+        MI355_UNROLL
+        for (int q = 0; q < 4; ++q) {  // slots 2q, 2q + 1
+            v[8 * hg + 2 * q] = (__uint_as_float(hh[q] << 16) + __uint_as_float(mm[q] << 16)) + __uint_as_float(ll[q] << 16);
+            v[8 * hg + 2 * q + 1] = (__uint_as_float(hh[q] & 0xffff0000u) + __uint_as_float(mm[q] & 0xffff0000u)) + __uint_as_float(ll[q] & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ void rows_to_planes(uint4* __restrict__ P, int PS, int LD, int wm, int brow, int col, const float (&v)[16]) {
+    MI355_UNROLL
+    for (int hg = 0; hg < 2; ++hg) {
+        uint4 h, m, l;
+        split3_pk(v[8 * hg + 0], v[8 * hg + 1], h.x, m.x, l.x);
+        split3_pk(v[8 * hg + 2], v[8 * hg + 3], h.y, m.y, l.y);
+        split3_pk(v[8 * hg + 4], v[8 * hg + 5], h.z, m.z, l.z);
+        split3_pk(v[8 * hg + 6], v[8 * hg + 7], h.w, m.w, l.w);
+        const int o = ((2 * wm + hg) * 2 + brow) * LD + col;
+        P[o] = h;
+        P[PS + o] = m;
+        P[2 * PS + o] = l;
+    }
+}
+// accumulator register r of a lane <-> slot order of the two records: r = 4 a + m  ->  record a >> 1, slot 4 (a & 1) + m
+__device__ __forceinline__ int rec_index(int r) { return 8 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3); }
+
+template <int C, int WM, int WT, int N2, int NT1MAX>
+__global__ __launch_bounds__(256) void k_mrf_b3(MrfArgs a) {
+    static_assert(WM * WT == 4 && C == 32 * WM, "4 waves: WM row tiles x WT column runs");
+    static_assert(N2 % WT == 0, "output column tiles divide evenly");
+    constexpr int NG = C / 16, T_B = 32 * N2, NT2 = N2 / WT;
+    DYN_SMEM(float, smem);
+    const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
+    const int PSX = NG * 2 * LDX, PS1 = NG * 2 * LD1;
+    uint4* Xp = reinterpret_cast<uint4*>(smem);
+    uint4* X1p = Xp + 3 * PSX;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int wm = wid / WT, wt = wid % WT;
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * T_B;
+    int len = a.len ? a.len[b] : a.T;
+    if (len > a.T) len = a.T;
+
+    if (!(a.ablate & 2)) stage_planes<NG>(a.x + (long)b * a.x_bs, a.x_ld, LDX, t0 - R, len, 0.1f, Xp, PSX, a.vec);
+    __syncthreads();
+
+    f32x16 out[1][NT2];
+    MI355_UNROLL
+    for (int i = 0; i < NT2; ++i)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) out[0][i][r] = 0.0f;
+    // biases travel one conv ahead of their use (16 loads in flight under the previous conv's matrix-core loop): a wave
+    // alone on its SIMD has nothing else to hide an L2 round trip per conv behind
+    float bias_n[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) bias_n[r] = a.bias[0][0][32 * wm + (r & 3) + 8 * (r >> 2) + 4 * brow];
+
+    for (int j = 0; j < a.nrb; ++j) {
+        const int K = a.k[j], d1 = a.d1[j], d2 = a.d2[j];
+        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
+        // ---- conv1 over the extended range e in [0, T_B + 2 r2): column tile q <-> t = t0 - r2 + 32 q + bcol; this wave: a
+        // contiguous run of cnt tiles from `start`
+        const int n1 = (T_B + 2 * r2 + 31) / 32;
+        const int base = n1 / WT, rem = n1 % WT;
+        const int cnt = base + (wt < rem ? 1 : 0), start = wt * base + (wt < rem ? wt : rem);
+        f32x16 acc1[1][NT1MAX];
+        float bias[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bias_n[r] = a.bias[j][1][32 * wm + (r & 3) + 8 * (r >> 2) + 4 * brow];  // conv2's, for later
+        MI355_UNROLL
+        for (int i = 0; i < NT1MAX; ++i) {
+            if (i < cnt) {
+                float v[16];
+                planes_to_rows(Xp, PSX, LDX, wm, brow, (R - r2) + (start + i) * 32 + bcol, v);
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) acc1[0][i][r] = unlrelu(v[rec_index(r)]) + bias[r];
+            }
+        }
+        {
+            const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.w[j][0]) + (long)wm * K * NG * 192 + lane};
+            const uint4* xq = Xp + brow * LDX + bcol + (R - r2 - r1) + start * 32;
+            if (!(a.ablate & 1)) {
+                if (cnt >= 4 && NT1MAX >= 4) b3_chunk<1, (NT1MAX >= 4 ? 4 : NT1MAX), NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
+                else if (cnt == 3 && NT1MAX >= 3) b3_chunk<1, (NT1MAX >= 3 ? 3 : NT1MAX), NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
+                else if (cnt == 2) b3_chunk<1, 2, NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
+                else if (cnt == 1) b3_chunk<1, 1, NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
+            }
+        }
+        if (j > 0) __syncthreads();  // every wave is done reading the previous resblock's x1
+        // ---- conv1 epilogue: x1 (zero outside the row), leaky-relu, split -> planes
+        MI355_UNROLL
+        for (int i = 0; i < NT1MAX; ++i) {
+            if (i < cnt) {
+                const int e = (start + i) * 32 + bcol;
+                const int t = t0 - r2 + e;
+                const bool live = t >= 0 && t < len;
+                float v[16];
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const float x1 = acc1[0][i][r];
+                    v[rec_index(r)] = live ? fmaxf(x1, 0.1f * x1) : 0.0f;
+                }
+                if (e < LD1) rows_to_planes(X1p, PS1, LD1, wm, brow, e, v);
+            }
+        }
+        __syncthreads();
+        // ---- conv2 into the output registers: out += x1 + bias + conv(lrelu(x1)); this wave: tiles wt * NT2 ..
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
+        {
+            const int jn = j + 1 < a.nrb ? j + 1 : j;  // next resblock's conv1 bias (the last one re-reads its own)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) bias_n[r] = a.bias[jn][0][32 * wm + (r & 3) + 8 * (r >> 2) + 4 * brow];
+        }
+        MI355_UNROLL
+        for (int i = 0; i < NT2; ++i) {
+            float v[16];
+            planes_to_rows(X1p, PS1, LD1, wm, brow, r2 + (wt * NT2 + i) * 32 + bcol, v);
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) out[0][i][r] += unlrelu(v[rec_index(r)]) + bias[r];
+        }
+        {
+            const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.w[j][1]) + (long)wm * K * NG * 192 + lane};
+            if (!(a.ablate & 1)) b3_chunk<1, NT2, NG>(out, wp, X1p + brow * LD1 + bcol + wt * NT2 * 32, PS1, LD1, K, NG, d2);
+        }
+    }
+
+    const float n = (float)a.nrb;
+    MI355_UNROLL
+    for (int i = 0; i < NT2; ++i) {
+        const int t = t0 + (wt * NT2 + i) * 32 + bcol;
+        if (t < a.T && !(a.ablate & 4)) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = a.out_scale > 0.0f ? out[0][i][r] * a.out_scale : out[0][i][r] / n;
+            }
+        }
+    }
+}
+
+namespace {
+struct GeoB3 { int C, T_B, WT, NT1MAX; };
+inline bool geometry_b3(int C, GeoB3* g) {
+    if (C == 32) { *g = {32, 256, 4, 3}; return true; }
+    if (C == 64) { *g = {64, 128, 2, 4}; return true; }
+    return false;
+}
+inline void shape_b3(const GeoB3& g, int nrb, const int* k, const int* d1, const int* d2, int* R, int* ldx, int* ld1, bool* ok) {
+    int Rm = 0, r2max = 0;
+    *ok = true;
+    for (int j = 0; j < nrb; ++j) {
+        if (k[j] < 1 || (k[j] % 2) == 0 || d1[j] < 1 || d2[j] < 1) { *ok = false; return; }
+        const int r1 = (k[j] - 1) / 2 * d1[j], r2 = (k[j] - 1) / 2 * d2[j];
+        Rm = Rm > r1 + r2 ? Rm : r1 + r2;
+        r2max = r2max > r2 ? r2max : r2;
+        const int n1 = (g.T_B + 2 * r2 + 31) / 32;
+        if ((n1 + g.WT - 1) / g.WT > g.NT1MAX) *ok = false;
+    }
+    *R = (Rm + 3) & ~3;  // the staged window starts on a 16-byte boundary
+    *ldx = (g.T_B + *R + Rm + 3) & ~3;
+    *ld1 = (g.T_B + 2 * r2max + 3) & ~3;
+}
+}  // namespace
+
+bool mrf_b3_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
+    GeoB3 g;
+    if (!geometry_b3(C, &g) || nrb < 1 || nrb > MRF_MAX_RB) return false;
+    int R, ldx, ld1;
+    bool ok;
+    shape_b3(g, nrb, k, d1, d2, &R, &ldx, &ld1, &ok);
+    return ok && (size_t)96 * (C / 16) * (ldx + ld1) <= LDS_LIMIT;
+}
+
+void launch_mrf_b3(MrfArgs a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    GeoB3 g;
+    if (!geometry_b3(a.C, &g) || !mrf_b3_supported(a.C, a.nrb, a.k, a.d1, a.d2)) throw std::runtime_error("mrf_b3: unsupported stage shape");
+    bool ok;
+    shape_b3(g, a.nrb, a.k, a.d1, a.d2, &a.R, &a.ldx, &a.ld1, &ok);
+    a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
+    {
+        const char* ab = getenv("MI355VITS_MRF_ABLATE");
+        a.ablate = ab ? atoi(ab) : 0;
+    }
+    const size_t shmem = (size_t)96 * (a.C / 16) * (a.ldx + a.ld1);
+    dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
+    auto go = [&](auto kfn) {
+#ifndef MI355_EMU
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+        (void)once;
+#endif
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+    };
+    if (a.C == 32) go(k_mrf_b3<32, 1, 4, 8, 3>);
+    else go(k_mrf_b3<64, 2, 2, 4, 4>);
 }
 
 }  // namespace m355

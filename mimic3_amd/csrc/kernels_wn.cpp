@@ -443,6 +443,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 // ------------------------------------------------------------------------------------------------
 constexpr int WNB_H = 192, WNB_TB = 96, WNB_NG = WNB_H / 16;
 
+template <bool W1>
 __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     constexpr int H = WNB_H, T_B = WNB_TB, NG = WNB_NG;
     DYN_SMEM(float, smem);
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             }
             wp[i] = reinterpret_cast<const uint4*>(a.w_in) + (long)q * a.K * NG * 192 + lane;
         }
-        if (!(a.ablate & 1)) b3_chunk<3, 3, NG>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+        if (!(a.ablate & 1)) b3_chunk<3, 3, NG, 3, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         __syncthreads();  // every wave is done with the h planes: the raw result takes their place
         MI355_UNROLL
         for (int i = 0; i < 3; ++i)
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
         }
         if (!(a.ablate & 1)) {
             if (two) {
-                b3_chunk<3, 3, NG>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                b3_chunk<3, 3, NG, 3, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
             } else {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
                 f32x16 a2[2][3];
                 const uint4* w2[2] = {wp[0], wp[1]};
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
                 for (int i = 0; i < 2; ++i)
                     MI355_UNROLL
                     for (int j = 0; j < 3; ++j) a2[i][j] = acc[i][j];
-                b3_chunk<2, 3, NG>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                b3_chunk<2, 3, NG, 3, W1>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 MI355_UNROLL
                 for (int i = 0; i < 2; ++i)
                     MI355_UNROLL
@@ -617,11 +618,15 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     const size_t raw = (size_t)2 * WNB_H * WNB_TB * sizeof(float);
     if (raw > shmem) shmem = raw;
     dim3 grid((a.T + WNB_TB - 1) / WNB_TB, a.B);
+    auto go = [&](auto kfn) {
 #ifndef MI355_EMU
-    static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wn_layer_b3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)once;
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)once;
 #endif
-    LAUNCH_KERNEL(k_wn_layer_b3, grid, dim3(256), shmem, s, a);
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+    };
+    if (a.math == MATH_BF16W) go(k_wn_layer_b3<true>);
+    else go(k_wn_layer_b3<false>);
 }
 
 bool wn_layer_fused_supported(int H, int K, int dil) {

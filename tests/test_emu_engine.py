@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from mimic3_amd import weights as W
 from mimic3_amd._native import Engine, NativeError
 from mimic3_amd.config import VitsConfig
+from oracle.vits_oracle import VitsOracle
 from tests.util import check_parity, rel_rms
 
 
@@ -100,7 +101,9 @@ def test_engine_forced_durations_and_length_scale(emu_lib):
     check_parity(emu_lib, cfg, B=1, Tx=6, seed=6, scales=(0.0, 1.7, 0.0))
 
 
-def test_fused_mrf_stage_kernel(emu_lib):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_fused_mrf_stage_kernel(emu_lib, math, monkeypatch):
+    monkeypatch.setenv("MI355VITS_MATH", math)  # read when a handle is created: both matrix-core paths, same checks
     """Decoder stages of 64 and 32 channels go through k_mrf_fused (all resblocks of a stage in one kernel);
     compare the stage taps and the waveform with the oracle, ragged batch, and with the conv-by-conv path."""
     import os
@@ -131,7 +134,9 @@ def test_fused_mrf_stage_kernel(emu_lib):
         assert rel_rms(fused_audio[b, :L], plain_audio[b, :L]) < 1e-5
 
 
-def test_partly_fused_mrf_stage_with_128_channels(emu_lib):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_partly_fused_mrf_stage_with_128_channels(emu_lib, math, monkeypatch):
+    monkeypatch.setenv("MI355VITS_MATH", math)  # read when a handle is created: both matrix-core paths, same checks
     """First decoder stage of the real voices (128 channels): the two narrow resblocks (k = 3, 5) run in the fused
     kernel (4 x 2 waves, 96-column tiles), the wide one (k = 7, halo 45) conv by conv, accumulated onto the same output."""
     import os
@@ -184,7 +189,9 @@ def test_generic_kernels_agree_with_mfma_path(emu_lib):
         assert rel_rms(a["audio"][r, :L], b["audio"][r, :L]) < 1e-5
 
 
-def test_fused_wavenet_layer_hidden_192(emu_lib):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_fused_wavenet_layer_hidden_192(emu_lib, math, monkeypatch):
+    monkeypatch.setenv("MI355VITS_MATH", math)  # read when a handle is created: both matrix-core paths, same checks
     """Flow with the real hidden width: k_wn_layer<6> (in-layer conv + gate + res/skip in one kernel, h ping-pong),
     multi-speaker conditioning included; also against the two-launch path."""
     import os
@@ -410,3 +417,25 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
         eng.close()
     L = int(outs["f32"]["lengths"][1])
     assert rel_rms(outs["bf16x3"]["audio"][1, :L], outs["f32"]["audio"][1, :L]) < 2e-5
+
+
+def test_bf16_weights_mode_separate_tolerance(emu_lib):
+    """MATH_BF16W (BASELINE configs[4] "bf16 weights"): weights rounded to bf16 (their leading split term only), activations
+    exact, f32 accumulate — a reduced-precision variant with its own tolerance (rel. RMS <= 2e-2 vs the f32 oracle), and
+    clearly worse than the f32-grade modes (it must not be mistaken for them)."""
+    cfg = VitsConfig.tiny_wide()
+    w = W.synthetic_weights(cfg, seed=31, frames_per_id=2.0)
+    from tests.util import make_inputs
+
+    ids, lengths, _ = make_inputs(cfg, 2, 9, 31)
+    ora = VitsOracle(cfg, w).infer(ids, lengths, (0.0, 1.0, 0.0))
+    errs = {}
+    for mode in ("bf16x3", "bf16w"):
+        eng = Engine(W.pack(cfg, w), library=emu_lib)
+        eng.set_math(mode)
+        out = eng.run(ids, lengths, (0.0, 1.0, 0.0))
+        assert np.array_equal(out["lengths"], ora["audio_lengths"])
+        L = int(out["lengths"][0])
+        errs[mode] = rel_rms(out["audio"][0, :L], ora["audio"][0, 0, :L])
+        eng.close()
+    assert errs["bf16x3"] < 1e-5 and 1e-5 < errs["bf16w"] < 2e-2, errs

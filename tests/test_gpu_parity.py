@@ -69,18 +69,37 @@ def test_tiny_graphs_match_oracle(gpu_lib, cfgname):
     check_parity(gpu_lib, cfg, B=2, Tx=10, seed=4, noise=True)
 
 
-def test_apope_low_b1_matches_oracle(gpu_lib):
+def _engine_in(math, cfg, w):
+    eng = Engine(W.pack(cfg, w))
+    eng.set_math(math)
+    return eng
+
+
+MATH_MODES = ["bf16x3", "f32"]  # the default path and the pure f32-MFMA path: both at the same tolerances
+
+
+@pytest.mark.parametrize("math", MATH_MODES)
+def test_apope_low_b1_matches_oracle(gpu_lib, math):
     """configs[1] shape class: en_UK/apope_low graph, B = 1, natural durations, deterministic scales."""
-    check_parity(gpu_lib, VitsConfig.apope_low(), B=1, Tx=40, seed=21, frames_per_id=3.0)
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=121, frames_per_id=3.0)
+    eng = _engine_in(math, cfg, w)
+    check_parity(gpu_lib, cfg, B=1, Tx=40, seed=21, weights=w, engine=eng)
+    eng.close()
 
 
 def test_apope_low_b1_injected_noise_matches_oracle(gpu_lib):
     check_parity(gpu_lib, VitsConfig.apope_low(), B=1, Tx=24, seed=22, frames_per_id=3.0, noise=True)
 
 
-def test_vctk_low_ragged_batch_matches_oracle(gpu_lib):
+@pytest.mark.parametrize("math", MATH_MODES)
+def test_vctk_low_ragged_batch_matches_oracle(gpu_lib, math):
     """configs[2] shape class: multi-speaker graph (109 speakers, gin 512), ragged batch."""
-    check_parity(gpu_lib, VitsConfig.vctk_low(), B=3, Tx=20, seed=23, frames_per_id=2.5)
+    cfg = VitsConfig.vctk_low()
+    w = W.synthetic_weights(cfg, seed=123, frames_per_id=2.5)
+    eng = _engine_in(math, cfg, w)
+    check_parity(gpu_lib, cfg, B=3, Tx=20, seed=23, weights=w, engine=eng)
+    eng.close()
 
 
 def test_committed_golden_vector(gpu_lib):
@@ -99,13 +118,14 @@ def test_committed_golden_vector(gpu_lib):
     eng.close()
 
 
-def test_full_size_properties_b8_forced(gpu_lib):
+@pytest.mark.parametrize("math", MATH_MODES)
+def test_full_size_properties_b8_forced(gpu_lib, math):
     """BASELINE.json sizes (Tx = 128, forced 6 frames/id -> 768 frames, 196,608 samples per row) through
     properties that do not need the oracle: batch invariance (bitwise), determinism, per-row pcm16 ==
     audio_float_to_int16(float row), Philox noise independent of the batch split."""
     cfg = VitsConfig.apope_low()
     w = W.synthetic_weights(cfg, seed=1234)
-    eng = Engine(W.pack(cfg, w))
+    eng = _engine_in(math, cfg, w)
     B, Tx = 8, 128
     ids = np.stack([np.random.default_rng(1234 + b).integers(1, 50, Tx) for b in range(B)]).astype(np.int64)
     lengths = np.full(B, Tx, np.int64)
@@ -145,7 +165,8 @@ def _bench_batch(B, Tx, base=0):
     return make_batch(B, Tx, base)
 
 
-def test_bench_workload_apope_low_b32_matches_oracle(gpu_lib):
+@pytest.mark.parametrize("math", MATH_MODES)
+def test_bench_workload_apope_low_b32_matches_oracle(gpu_lib, math):
     """THE benchmarked configuration (bench.py default: en_UK/apope_low, 32 utterances x 128 ids, forced 6 frames/id,
     scales [0.667, 1, 0.8]) against the oracle with both Gaussian draws injected: every row's waveform, int16, the
     taps, and the decoder stages of three rows."""
@@ -153,8 +174,11 @@ def test_bench_workload_apope_low_b32_matches_oracle(gpu_lib):
     B, Tx = 32, 128
     ids, lengths = _bench_batch(B, Tx)
     forced = np.full((B, Tx), 6, np.int32)
-    out, _ = check_parity(gpu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=5,
-                          weights=W.synthetic_weights(cfg, seed=1234), stage_rows=(0, 13, 31))
+    w = W.synthetic_weights(cfg, seed=1234)
+    eng = _engine_in(math, cfg, w)
+    out, _ = check_parity(gpu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=5, weights=w,
+                          stage_rows=(0, 13, 31), engine=eng)
+    eng.close()
     assert list(out["lengths"]) == [768 * 256] * B
 
 
@@ -189,13 +213,17 @@ def test_length_scale_and_rate(gpu_lib):
     check_parity(gpu_lib, VitsConfig.tiny_wide(), B=2, Tx=12, seed=61, scales=(0.0, 1.37, 0.0))
 
 
-def test_long_form_full_size_utterance(gpu_lib):
+@pytest.mark.parametrize("math", MATH_MODES)
+def test_long_form_full_size_utterance(gpu_lib, math):
     """600 phoneme ids at the real voice shapes (more than the 512-key register budget of the MFMA attention, so the
     fallback attention runs at head dimension 96) -> 1800 frames = 20.9 s of audio through every fused kernel."""
     cfg = VitsConfig.apope_low()
     Tx = 600
     forced = np.full((1, Tx), 3, np.int32)
-    out, ora = check_parity(gpu_lib, cfg, B=1, Tx=Tx, seed=77, forced=forced, taps=False, ragged=False)
+    w = W.synthetic_weights(cfg, seed=177)
+    eng = _engine_in(math, cfg, w)
+    out, ora = check_parity(gpu_lib, cfg, B=1, Tx=Tx, seed=77, forced=forced, taps=False, ragged=False, weights=w, engine=eng)
+    eng.close()
     assert int(out["lengths"][0]) == Tx * 3 * 256
 
 
@@ -205,6 +233,7 @@ def test_wavenet_layer_geometries_give_identical_bits(gpu_lib):
     cfg = VitsConfig.apope_low()
     w = W.synthetic_weights(cfg, seed=1234)
     eng = Engine(W.pack(cfg, w))
+    eng.set_math("f32")  # the geometries belong to the f32 fused layer kernel
     ids = np.random.default_rng(3).integers(1, 50, (2, 48)).astype(np.int64)
     forced = np.full((2, 48), 4, np.int32)
     outs = {}
@@ -296,3 +325,30 @@ def test_split_bf16_staged_conv_kernel_vs_fp64(gpu_lib, case):
         err[impl] = float(np.sqrt(np.mean((y - ref) ** 2)))
     print(f"\nconv {case}: rms error vs fp64  f32-MFMA {err[1]:.3e}  split-bf16 {err[2]:.3e}")
     assert err[2] < 2e-6 and err[2] <= 1.25 * err[1] + 2e-8, err
+
+
+def test_bf16_weights_mode_at_its_own_tolerance(gpu_lib):
+    """BASELINE.json configs[4] first slice: MATH_BF16W — bf16-rounded weights (leading split term), exact f32 activations,
+    f32 accumulate on v_mfma_f32_32x32x16_bf16 — on the full-size apope_low graph, bench-shaped rows.  Reduced precision:
+    its OWN tolerance (rel. RMS <= 2e-2 vs the f32 oracle, durations still exactly equal: the duration predictor stays
+    f32), and demonstrably not f32-grade (so it can never be mistaken for the default)."""
+    cfg = VitsConfig.apope_low()
+    B, Tx = 4, 128
+    ids, lengths = _bench_batch(B, Tx)
+    forced = np.full((B, Tx), 6, np.int32)
+    w = W.synthetic_weights(cfg, seed=1234)
+    rng = np.random.default_rng(11)
+    nw = rng.standard_normal((B, 2, Tx)).astype(np.float32)
+    nz = rng.standard_normal((B, cfg.inter_channels, Tx * 6)).astype(np.float32)
+    sc = (0.667, 1.0, 0.8)
+    ora = VitsOracle(cfg, w).infer(ids, lengths, sc, noise_w=nw, noise_z=nz, forced_durations=forced, stage_rows=())
+    eng = _engine_in("bf16w", cfg, w)
+    out = eng.run(ids, lengths, sc, noise_w=nw, noise_z=nz, forced_durations=forced, want_pcm16=True, debug_taps=True)
+    assert np.array_equal(out["lengths"], ora["audio_lengths"]) and np.array_equal(eng.tap("w_ceil"), ora["w_ceil"])
+    errs = [rel_rms(out["audio"][b, : int(out["lengths"][b])], ora["audio"][b, 0, : int(out["lengths"][b])]) for b in range(B)]
+    print(f"\nbf16-weights mode: rel RMS vs f32 oracle {max(errs):.3e}")
+    assert 2e-5 < max(errs) < 2e-2, errs
+    for b in range(B):
+        L = int(out["lengths"][b])
+        assert np.array_equal(out["pcm"][b, :L], audio_float_to_int16(out["audio"][b, :L]))
+    eng.close()
