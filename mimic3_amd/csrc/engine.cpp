@@ -593,7 +593,8 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
         // split-bf16 staged kernel where it pays: convs with little work per staged chunk (1x1 convs, the last
         // upsampler: K * Cin < 256) spend more on splitting the chunk than the faster matrix-core loop saves
         // (measured: flow.pre / post, res_skip, upsample 64 -> 32); MI355VITS_B3_MIN_WORK overrides the threshold (tests)
-        if (math_on_bf16(math_) && w.packed_b3s != NO_OFF && (math_on_bf16(a.math) || (w.K * w.Cin >= b3_min_work_ && a.epi == EPI_STD))) {
+        if (math_on_bf16(math_) && w.packed_b3s != NO_OFF &&
+            (math_on_bf16(a.math) || ((w.K * w.Cin >= b3_min_work_ || (a.shuf_s && w.Cin % 64 == 0)) && a.epi == EPI_STD))) {
             a.wb3 = P(w.packed_b3s);
             a.math = math_;
         } else {

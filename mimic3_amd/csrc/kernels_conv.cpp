@@ -1026,12 +1026,16 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     }
 }
 
-// split-bf16 staged kernel: 32-channel chunks (two 16-channel groups: 6 * 32 * LD bytes of LDS)
+// split-bf16 staged kernel: 32-channel chunks (two 16-channel groups: 6 * 32 * LD bytes of LDS); convs with one or two taps
+// (the polyphase upsamplers) take 64-channel chunks when C_in allows — with so few taps a 32-channel chunk is only 72 - 144
+// MFMAs per wave between two stage / barrier cycles.  The chunk size is a function of the layer alone (never of the batch),
+// so the summation order of an output does not depend on what it is batched with.
 template <int MT, int NT, int WM, int WN, int EPI>
 void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
     const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
-    size_t shmem = (size_t)6 * 32 * LD;
+    const bool wide = a.K <= 2 && a.Cin % 64 == 0 && EPI == EPI_STD;
+    size_t shmem = (size_t)6 * (wide ? 64 : 32) * LD;
     dim3 grid((a.T + T_B - 1) / T_B, (n_tiles + MT * WM - 1) / (MT * WM), a.B);
     ConvArgs av = a;
     av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
@@ -1052,6 +1056,13 @@ void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av);
     };
+    if constexpr (EPI == EPI_STD) {
+        if (wide) {
+            if (a.math == MATH_BF16W) go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, true>);
+            else go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, false>);
+            return;
+        }
+    }
     if (a.math == MATH_BF16W) go(k_conv1d_b3<MT, NT, WM, WN, EPI, 2, true>);
     else go(k_conv1d_b3<MT, NT, WM, WN, EPI, 2, false>);
 }

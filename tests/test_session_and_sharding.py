@@ -475,3 +475,62 @@ def test_fused_volume_equals_audioop_mul_and_wav_helpers(emu_lib):
         wf.setframerate(22050); wf.setsampwidth(2); wf.setnchannels(1)
         wf.writeframes(frames.tobytes())
     assert blob == ref.getvalue()
+
+
+def test_chunked_streaming_of_long_form_audio(emu_lib):
+    """N4: sentences of a long request are synthesised with a look-ahead window on one shared session (lanes + micro-batching
+    underneath) and delivered in order as they finish; the streamed WAV body equals the joined one."""
+    import io
+    import wave
+
+    from mimic3_amd import postprocess as PP
+    from mimic3_amd import streaming as ST
+
+    cfg = VitsConfig.tiny()
+    blob = W.pack(cfg, W.synthetic_weights(cfg, seed=3, frames_per_id=2.0))
+    so = SessionOptions()
+    so.lanes = 2
+    so.micro_batch_window_ms = 2.0
+    so.seed = 5
+    sess = InferenceSession(blob, sess_options=so, _library=emu_lib)
+    plain = InferenceSession(blob, _library=emu_lib)
+    rng = np.random.default_rng(1)
+    sentences = [rng.integers(1, cfg.num_symbols, int(rng.integers(3, 14))).tolist() for _ in range(23)]
+    det = (0.0, 1.0, 0.0)  # deterministic scales: the streamed audio must equal one-by-one synthesis exactly
+    expect = [plain.run_pcm16(ST._feed(s, det, None))[0][0] for s in sentences]
+
+    consumed = []
+
+    def lazily():
+        for i, s in enumerate(sentences):
+            consumed.append(i)
+            yield s
+
+    got = []
+    for k, audio in enumerate(ST.stream_sentences(sess, lazily(), scales=det, look_ahead=4)):
+        assert len(consumed) <= k + 1 + 4, "more than look_ahead sentences were pulled ahead of the consumer"
+        got.append(audio)
+    assert len(got) == len(expect) and all(np.array_equal(a, b) for a, b in zip(got, expect))
+
+    body = b"".join(ST.stream_wav(sess, sentences, scales=det, break_ms=50, look_ahead=6))
+    assert body[:4] == b"RIFF" and body[8:16] == b"WAVEfmt " and body[40:44] == struct_pack_u32(ST.STREAM_SIZE)
+    joined = PP.utterances_to_wav(expect, 22050, break_ms=50)
+    assert body[44:] == joined[44:]  # same PCM as the reference-style joined WAV; only the two size fields differ
+    with wave.open(io.BytesIO(joined), "rb") as wf:
+        assert wf.getnframes() * 2 == len(body) - 44
+
+    # a failing sentence surfaces at its turn, later ones are not delivered
+    bad = sentences[:3] + [[cfg.num_symbols + 5]] + sentences[3:6]
+    out = []
+    with pytest.raises(ValueError, match="phoneme id"):
+        for a in ST.stream_sentences(sess, bad, scales=det, look_ahead=3):
+            out.append(a)
+    assert len(out) == 3
+    sess.close()
+    plain.close()
+
+
+def struct_pack_u32(v):
+    import struct
+
+    return struct.pack("<I", v)

@@ -8,7 +8,11 @@ other workers (mimic3_tts/voice.py:277-292, mimic3_http/synthesis.py:88-136) —
   batch        micro-batching window 2 ms, max 32
   batch+lanes  both
 
+and, with STREAM=1, a long-form request (BASELINE.json configs[4]: ~10k characters = 120 sentences) delivered as a chunked
+stream (mimic3_amd.streaming): time to first audio and total time vs synthesising everything before answering.
+
 Prints one JSON line per mode: sentences/s, audio seconds per second, latency percentiles.  Run on the GPU box.
+MI355VITS_DEVICES=all spreads every session over all visible GPUs (in-process device round-robin).
 """
 import json
 import os
@@ -76,7 +80,28 @@ def main():
         if sess._batcher is not None:
             out["mean_batch"] = sess._batcher.requests / max(1, sess._batcher.batches)
         print(json.dumps(out), flush=True)
-        del sess
+        sess.close()
+    if os.environ.get("STREAM"):
+        from mimic3_amd import streaming as ST
+
+        so = SessionOptions()
+        so.lanes = 3
+        so.micro_batch_window_ms = 1.0
+        sess = InferenceSession(blob, sess_options=so)
+        sentences = [f["input"][0].tolist() for f in feeds[:120]]  # ~100 phoneme ids each: about 10k characters of text
+        list(ST.stream_sentences(sess, sentences[:8], look_ahead=8))  # warm-up
+        for look in (1, 8, 32):
+            t0 = time.perf_counter()
+            first, n = None, 0
+            for audio in ST.stream_sentences(sess, sentences, look_ahead=look):
+                if first is None:
+                    first = time.perf_counter() - t0
+                n += audio.shape[0]
+            total = time.perf_counter() - t0
+            print(json.dumps({"mode": "stream", "sentences": len(sentences), "look_ahead": look, "first_audio_ms": first * 1e3,
+                              "total_ms": total * 1e3, "audio_s": n / 22050, "x_realtime": n / 22050 / total,
+                              "devices": sess.devices}), flush=True)
+        sess.close()
 
 
 if __name__ == "__main__":
