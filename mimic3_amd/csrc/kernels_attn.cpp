@@ -183,16 +183,22 @@ __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __rest
     constexpr int U = 4;
     for (int cp0 = 0; cp0 < d / 2; cp0 += U) {
         float qv[U], ekv[U], kv[U][NKW];
+        // loads through clamped indices, the out-of-range test applied to the VALUE: a test around each load makes hipcc
+        // wait for every load in turn (a chain of ~100 dependent L2 round trips per workgroup: 50 us per launch)
         MI355_UNROLL
         for (int u = 0; u < U; ++u) {
             const int c = 2 * (cp0 + u) + brow;
             const bool cin = c < d;
-            qv[u] = (iq && cin) ? qb[(long)c * T + i] * scale : 0.0f;
-            ekv[u] = (w == 0 && bcol < nrel && cin) ? ek[bcol * d + c] : 0.0f;
+            const int cc = cin ? c : d - 1;
+            const float qraw = qb[(long)cc * T + (iq ? i : T - 1)];
+            const float eraw = ek[(bcol < nrel ? bcol : nrel - 1) * d + cc];
+            qv[u] = (iq && cin) ? qraw * scale : 0.0f;
+            ekv[u] = (w == 0 && bcol < nrel && cin) ? eraw : 0.0f;
             MI355_UNROLL
             for (int m = 0; m < NKW; ++m) {
                 const int j = (w + 4 * m) * 32 + bcol;
-                kv[u][m] = (j < T && cin) ? kb[(long)c * T + j] : 0.0f;
+                const float kraw = kb[(long)cc * T + (j < T ? j : T - 1)];
+                kv[u][m] = (j < T && cin) ? kraw : 0.0f;
             }
         }
         MI355_UNROLL
@@ -258,10 +264,16 @@ __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __rest
         for (int m = 0; m < NKW; ++m) {
             MI355_UNROLL
             for (int g = 0; g < 4; ++g) {
+                float vraw[4];
                 MI355_UNROLL
                 for (int q = 0; q < 4; ++q) {
                     const int j = (w + 4 * m) * 32 + 8 * g + 4 * brow + q;
-                    const float vv = (cv && j < T) ? vr[j] : 0.0f;
+                    vraw[q] = vr[j < T ? j : T - 1];
+                }
+                MI355_UNROLL
+                for (int q = 0; q < 4; ++q) {
+                    const int j = (w + 4 * m) * 32 + 8 * g + 4 * brow + q;
+                    const float vv = (cv && j < T) ? vraw[q] : 0.0f;
                     o = MFMA_32x32x2_F32(vv, st[m][4 * g + q], o);
                 }
             }
@@ -269,7 +281,8 @@ __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __rest
         if (w == 0) {
             for (int s2 = 0; s2 < (nrel + 1) / 2; ++s2) {
                 const int r = 2 * s2 + brow;
-                const float evv = (cv && r < nrel) ? ev[r * d + cr] : 0.0f;
+                const float eraw = ev[(r < nrel ? r : nrel - 1) * d + (cv ? cr : 0)];
+                const float evv = (cv && r < nrel) ? eraw : 0.0f;
                 const float pv = r < nrel ? tab[r * 32 + bcol] : 0.0f;
                 o = MFMA_32x32x2_F32(evv, pv, o);
             }

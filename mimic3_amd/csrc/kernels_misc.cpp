@@ -71,6 +71,12 @@ __device__ __forceinline__ float block_cg_sum(float v, float* red, int tl, int c
     return s;
 }
 
+// Channels per thread held in registers (C <= LN_CG * LN_NPT): the input is read ONCE, with all loads of a thread in flight
+// together, and mean / variance / output come from the registers.  (Three sweeps with a test per element — `if (a.res)` —
+// make hipcc wait for every load in turn: 36 dependent L2 round trips per thread for C = 192, 13 us per launch at batch 1.)
+constexpr int LN_NPT = 16;
+
+template <bool CACHED>
 __global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
     DYN_SMEM(float, red);
     const int b = blockIdx.y;
@@ -78,6 +84,62 @@ __global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
     const int t = blockIdx.x * LN_TT + tl;
     const bool live = t < a.T;
     const long base = (long)b * a.C * a.T + (live ? t : 0);
+    if (CACHED) {
+        float v[LN_NPT];
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i) {
+            const int c = cg + i * LN_CG;
+            v[i] = a.x[base + (long)(c < a.C ? c : a.C - 1) * a.T];  // clamped: unconditional loads, batched
+        }
+        if (a.res) {
+            float r[LN_NPT];
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) {
+                const int c = cg + i * LN_CG;
+                r[i] = a.res[base + (long)(c < a.C ? c : a.C - 1) * a.T];
+            }
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) v[i] += r[i];
+        }
+        float sum = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i)
+            if (live && cg + i * LN_CG < a.C) sum += v[i];  // same order of additions as the sweep version: c ascending
+        const float mean = block_cg_sum(sum, red, tl, cg) / (float)a.C;
+        float sq = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i)
+            if (live && cg + i * LN_CG < a.C) { const float d = v[i] - mean; sq += d * d; }
+        const float var = block_cg_sum(sq, red, tl, cg) / (float)a.C;
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        __syncthreads();  // in-place use: all reads of x above are done before anyone writes y
+        if (!live) return;
+        const bool masked = a.out_len && t >= a.out_len[b];
+        float g[LN_NPT], be[LN_NPT], ad[LN_NPT];
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i) {
+            const int c = cg + i * LN_CG, cc = c < a.C ? c : a.C - 1;
+            g[i] = a.gamma[cc];
+            be[i] = a.beta[cc];
+        }
+        if (a.add_to) {
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) {
+                const int c = cg + i * LN_CG;
+                ad[i] = a.add_to[base + (long)(c < a.C ? c : a.C - 1) * a.T];
+            }
+        }
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i) {
+            const int c = cg + i * LN_CG;
+            float y = (v[i] - mean) * rstd * g[i] + be[i];
+            if (a.gelu) y = gelu_erf(y);
+            if (a.add_to) y += ad[i];
+            if (masked) y = 0.0f;
+            if (c < a.C) a.y[base + (long)c * a.T] = y;
+        }
+        return;
+    }
     float sum = 0.0f;
     if (live)
         for (int c = cg; c < a.C; c += LN_CG) {
@@ -111,7 +173,8 @@ __global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
 }
 void launch_layernorm(const LNArgs& a, hipStream_t s) {
     if (a.T <= 0) return;
-    LAUNCH_KERNEL(k_layernorm, dim3((a.T + LN_TT - 1) / LN_TT, a.B), dim3(256), 256 * sizeof(float), s, a);
+    if (a.C <= LN_CG * LN_NPT) LAUNCH_KERNEL(k_layernorm<true>, dim3((a.T + LN_TT - 1) / LN_TT, a.B), dim3(256), 256 * sizeof(float), s, a);
+    else LAUNCH_KERNEL(k_layernorm<false>, dim3((a.T + LN_TT - 1) / LN_TT, a.B), dim3(256), 256 * sizeof(float), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -127,6 +190,10 @@ __device__ __forceinline__ float dwconv_at(const float* xrow, const float* w, fl
     }
     return acc;
 }
+// CACHED (C <= LN_CG * LN_NPT, K <= 3... any K via the inner loop): the depthwise result of a thread's channels is computed
+// once into registers — taps read through clamped indices and a 0/1 factor instead of a test per tap, so all loads of a
+// thread are in flight together — and mean / variance / output come from the registers (same arithmetic, same order).
+template <bool CACHED>
 __global__ __launch_bounds__(256) void k_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias,
                                                             const float* gamma, const float* beta, const int* len,
                                                             int C, int T, int K, int dil, float* y) {
@@ -137,6 +204,57 @@ __global__ __launch_bounds__(256) void k_dds_dwconv_ln_gelu(const float* x, cons
     const bool live = t < T;
     const int L = len[b];
     const float* xb = x + (long)b * C * T;
+    if (CACHED) {
+        const int pad = (K * dil - dil) / 2;
+        const int tend = L < T ? L : T;
+        float v[LN_NPT];
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i) {
+            const int c = cg + i * LN_CG, cc = c < C ? c : C - 1;
+            v[i] = bias[cc];
+        }
+        for (int k = 0; k < K; ++k) {
+            const int tt = (live ? t : 0) - pad + k * dil;
+            const bool in = tt >= 0 && tt < tend;
+            const int tc = in ? tt : 0;
+            float xv[LN_NPT], wv[LN_NPT];
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) {
+                const int c = cg + i * LN_CG, cc = c < C ? c : C - 1;
+                xv[i] = xb[(long)cc * T + tc];
+                wv[i] = w[cc * K + k];
+            }
+            if (in) {  // (a skipped tap leaves acc untouched, exactly like the test in dwconv_at)
+                MI355_UNROLL
+                for (int i = 0; i < LN_NPT; ++i) v[i] = fmaf(wv[i], xv[i], v[i]);
+            }
+        }
+        float sum = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i)
+            if (live && cg + i * LN_CG < C) sum += v[i];
+        const float mean = block_cg_sum(sum, red, tl, cg) / (float)C;
+        float sq = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i)
+            if (live && cg + i * LN_CG < C) { const float d = v[i] - mean; sq += d * d; }
+        const float var = block_cg_sum(sq, red, tl, cg) / (float)C;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        if (!live) return;
+        float g[LN_NPT], be[LN_NPT];
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i) {
+            const int c = cg + i * LN_CG, cc = c < C ? c : C - 1;
+            g[i] = gamma[cc];
+            be[i] = beta[cc];
+        }
+        MI355_UNROLL
+        for (int i = 0; i < LN_NPT; ++i) {
+            const int c = cg + i * LN_CG;
+            if (c < C) y[((long)b * C + c) * T + t] = gelu_erf((v[i] - mean) * rstd * g[i] + be[i]);
+        }
+        return;
+    }
     float sum = 0.0f;
     if (live)
         for (int c = cg; c < C; c += LN_CG) sum += dwconv_at(xb + (long)c * T, w + c * K, bias[c], t, T, L, K, dil);
@@ -159,8 +277,12 @@ __global__ __launch_bounds__(256) void k_dds_dwconv_ln_gelu(const float* x, cons
 void launch_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias, const float* gamma,
                                const float* beta, const int* len, int B, int C, int T, int K, int dil, float* y,
                                hipStream_t s) {
-    LAUNCH_KERNEL(k_dds_dwconv_ln_gelu, dim3((T + LN_TT - 1) / LN_TT, B), dim3(256), 256 * sizeof(float), s, x, w, bias, gamma,
-                  beta, len, C, T, K, dil, y);
+    if (C <= LN_CG * LN_NPT)
+        LAUNCH_KERNEL(k_dds_dwconv_ln_gelu<true>, dim3((T + LN_TT - 1) / LN_TT, B), dim3(256), 256 * sizeof(float), s, x, w, bias,
+                      gamma, beta, len, C, T, K, dil, y);
+    else
+        LAUNCH_KERNEL(k_dds_dwconv_ln_gelu<false>, dim3((T + LN_TT - 1) / LN_TT, B), dim3(256), 256 * sizeof(float), s, x, w, bias,
+                      gamma, beta, len, C, T, K, dil, y);
 }
 
 // ------------------------------------------------------------------------------------------------
