@@ -204,17 +204,32 @@ __device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long
 }
 
 // ---- f32 operands on the bf16 matrix cores ---------------------------------------------------------------------------
-// x = h + m + l exactly, each a bf16 (8-bit significand): h = rne(x), m = rne(x - h), l = rne(x - h - m); both
+// x = h + m + l exactly, each a bf16 (8-bit significand): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); both
 // subtractions are exact in f32.  With both operands of a product split this way, the six leading partial products
 // (hh, hm, mh, mm, hl, lh) carry everything down to 2^-24 relative — the f32 rounding level — and the bf16 MFMA forms
 // each product exactly and sums in f32: f32-grade results at 6/16 of the f32 MFMA's time (MI355X: bf16 MFMA = 16x f32).
-// One pair of elements -> one packed register per plane: 3 cvt_pk + 4 bit ops + 4 subtractions.
+// In the kernels the ACTIVATIONS are split by truncation instead (h = the top 16 bits of x, and so on): the three terms
+// still sum to x exactly, and it needs no conversion instruction — v_and + v_sub per level and one v_perm_b32 to pack a
+// pair, 25 % less issue time than v_cvt_pk_bf16_f32 based rounding (tools/bf16x3_probe: V7 vs V2).  Truncated residuals
+// are up to 4x larger than rounded ones (m < 2^-7 x, l < 2^-14 x), but the WEIGHTS are split with round-to-nearest on the
+// host (m_w <= 2^-9 w, l_w <= 2^-18 w, random signs), so the dropped products m l_w + l m_w + l l_w stay below 2^-22 of
+// the product in the worst case, ~2^-26 typically, and unbiased.
+// One pair of elements -> one packed register per plane: 4 and + 4 sub + 3 perm.
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
+#ifdef MI355_EMU
+    return (lo >> 16) | (hi & 0xffff0000u);
+#else
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);  // v_perm_b32: bytes 3:2 of each
+#endif
+}
 __device__ __forceinline__ void split3_pk(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
-    h = CVT_PK_BF16_F32(a0, a1);
-    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
-    m = CVT_PK_BF16_F32(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = CVT_PK_BF16_F32(s0, s1);
+    const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
+    h = pack_hi16(u0, u1);
+    const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = pack_hi16(v0, v1);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = pack_hi16(__float_as_uint(s0), __float_as_uint(s1));
 }
 // eight k-slots of one lane (two packed-tile float4: channels 16G + brow + 2e | 16G + 8 + brow + 2e) -> three planes
 __device__ __forceinline__ void split3_x8(const float4& lo4, const float4& hi4, uint4& h, uint4& m, uint4& l) {

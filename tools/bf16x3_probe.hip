@@ -29,6 +29,26 @@ __device__ __forceinline__ void split3_pk(float a0, float a1, unsigned& h, unsig
     const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
     l = cvt(s0, s1);
 }
+// truncation split: hi = top 16 bits (no cvt instruction): and + sub per level, v_perm_b32 to pack
+__device__ __forceinline__ void split3_pk_t(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+template <bool TR>
+__device__ __forceinline__ void split8x(const float4& a, const float4& b, uint4& h, uint4& m, uint4& l) {
+    if (TR) {
+        split3_pk_t(a.x, a.y, h.x, m.x, l.x); split3_pk_t(a.z, a.w, h.y, m.y, l.y);
+        split3_pk_t(b.x, b.y, h.z, m.z, l.z); split3_pk_t(b.z, b.w, h.w, m.w, l.w);
+    } else {
+        split3_pk(a.x, a.y, h.x, m.x, l.x); split3_pk(a.z, a.w, h.y, m.y, l.y);
+        split3_pk(b.x, b.y, h.z, m.z, l.z); split3_pk(b.z, b.w, h.w, m.w, l.w);
+    }
+}
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& h, uint4& m, uint4& l) {
     split3_pk(a.x, a.y, h.x, m.x, l.x); split3_pk(a.z, a.w, h.y, m.y, l.y);
     split3_pk(b.x, b.y, h.z, m.z, l.z); split3_pk(b.z, b.w, h.w, m.w, l.w);
@@ -79,7 +99,7 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ w, float* __r
 #pragma unroll
                 for (int p = 0; p < 3; ++p) ra[(g + 1) & 1][p] = xu[4096 + off + p * 64];
             }
-            if (V == 2 || V == 3 || V == 4) {
+            if (V == 2 || V == 3 || V == 4 || V == 7 || V == 8) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) { xb[(g + 1) & 1][n][0] = xw[off + n * 64]; xb[(g + 1) & 1][n][1] = xw[off + n * 64 + 2048]; }
             }
@@ -108,6 +128,21 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ w, float* __r
                     uint4 bh, bm, bl;
                     split8(xb[g & 1][n][0], xb[g & 1][n][1], bh, bm, bl);
                     sink ^= bh.x ^ bm.y ^ bl.z ^ bh.w ^ bm.x ^ bl.y ^ bh.z ^ bm.w ^ bl.x ^ bh.y ^ bm.z ^ bl.w;
+                }
+            } else if (V == 7) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    uint4 bh, bm, bl;
+                    split8x<true>(xb[g & 1][n][0], xb[g & 1][n][1], bh, bm, bl);
+                    sink ^= bh.x ^ bm.y ^ bl.z ^ bh.w ^ bm.x ^ bl.y ^ bh.z ^ bm.w ^ bl.x ^ bh.y ^ bm.z ^ bl.w;
+                }
+            } else if (V == 8) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    uint4 bh, bm, bl;
+                    split8x<true>(xb[g & 1][n][0], xb[g & 1][n][1], bh, bm, bl);
+                    acc[n] = mf(al, bh, acc[n]); acc[n] = mf(ah, bl, acc[n]); acc[n] = mf(am, bm, acc[n]);
+                    acc[n] = mf(am, bh, acc[n]); acc[n] = mf(ah, bm, acc[n]); acc[n] = mf(ah, bh, acc[n]);
                 }
             } else if (V == 3 || V == 4) {
 #pragma unroll
@@ -155,7 +190,7 @@ void run(const char* name, const uint4* w, float* out, int waves_per_block, int 
     CHECK(hipEventElapsedTime(&ms, a, b));
     const double waves_per_simd = waves_per_block * blocks_per_cu / 4.0;
     const double ns_per_group_per_simd = ms * 1e6 / groups / waves_per_simd;   // time one SIMD spends per wave-group
-    const double mfma = (V == 2) ? 0 : 6.0 * NT;
+    const double mfma = (V == 2 || V == 7) ? 0 : 6.0 * NT;
     const double tf = mfma * 2.0 * 32 * 32 * 16 * groups * grid * waves_per_block / (ms * 1e-3) / 1e12;
     printf("%-34s NT=%d waves/CU=%2d  %8.3f ms  %7.1f ns/group/SIMD = %6.0f cyc@2.4GHz (%4.1f cyc/MFMA)  %7.1f TF bf16 = %6.1f TF f32-equivalent\n",
            name, NT, waves_per_block * blocks_per_cu, ms, ns_per_group_per_simd, ns_per_group_per_simd * 2.4,
@@ -171,6 +206,8 @@ int main() {
         run<1, 3>("V1 mfma product-major", w, out, wpb);
         run<2, 3>("V2 split only", w, out, wpb);
         run<3, 3>("V3 on-the-fly (A regs)", w, out, wpb);
+        run<7, 3>("V7 split only, truncation", w, out, wpb);
+        run<8, 3>("V8 on-the-fly, truncation split", w, out, wpb);
         run<4, 3>("V4 on-the-fly + A global", w, out, wpb);
         run<5, 3>("V5 pre-split + A global", w, out, wpb);
         run<6, 3>("V6 pre-split + A from LDS", w, out, wpb);
