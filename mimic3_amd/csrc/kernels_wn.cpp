@@ -441,11 +441,16 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 //     u never leaves the CU.
 // LDS: max(3 planes x 192 ch x 104 col x 2 B = 117 KiB, raw 384 x 96 x 4 B = 144 KiB).
 // ------------------------------------------------------------------------------------------------
-constexpr int WNB_H = 192, WNB_TB = 96, WNB_NG = WNB_H / 16;
+constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
 
-template <bool W1>
+// NT column tiles per workgroup: 3 (96 columns) when the grid fills the chip, 1 (32 columns) for small grids (one
+// utterance: a third of the dependent MFMA chain per wave, three times the workgroups).  The arithmetic of an output
+// element — chunk, tap, group and product order — is the same in both, so the results are bit-identical and the choice
+// may depend on the grid size.
+
+template <bool W1, int NT>
 __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
-    constexpr int H = WNB_H, T_B = WNB_TB, NG = WNB_NG;
+    constexpr int H = WNB_H, T_B = 32 * NT, NG = WNB_NG;
     DYN_SMEM(float, smem);
     uint4* planes = reinterpret_cast<uint4*>(smem);
     float* R = smem;  // [2H][T_B] raw in-layer result, later scratch of the epilogue
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     const float* condp = a.cond ? a.cond + (long)b * a.cond_bs : a.b_in;
     const float cond_on = a.cond ? 1.0f : 0.0f;
     {
-        f32x16 acc[3][3];
+        f32x16 acc[3][NT];
         const uint4* wp[3];
         MI355_UNROLL
         for (int i = 0; i < 3; ++i) {
@@ -481,23 +486,23 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
                 const int c = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
                 const float v = a.b_in[c] + cond_on * condp[c];  // unconditional loads: all 48 in flight together
                 MI355_UNROLL
-                for (int j = 0; j < 3; ++j) acc[i][j][r] = v;
+                for (int j = 0; j < NT; ++j) acc[i][j][r] = v;
             }
             wp[i] = reinterpret_cast<const uint4*>(a.w_in) + (long)q * a.K * NG * 192 + lane;
         }
-        if (!(a.ablate & 1)) b3_chunk<3, 3, NG, 3, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+        if (!(a.ablate & 1)) b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         __syncthreads();  // every wave is done with the h planes: the raw result takes their place
         MI355_UNROLL
         for (int i = 0; i < 3; ++i)
             MI355_UNROLL
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < NT; ++j)
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r)
                     R[(32 * (w + 4 * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r];
     }
     __syncthreads();
     // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
-    constexpr int ITEMS = NG * 2 * T_B / 256;  // 9
+    constexpr int ITEMS = NG * 2 * T_B / 256;  // 9 (96 columns) or 3 (32)
     float u[ITEMS][8];
     MI355_UNROLL
     for (int it = 0; it < ITEMS; ++it) {
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     __syncthreads();
     // ---- res/skip 1x1 conv: Crs / 32 row tiles (12, last layer 6), tile q on wave q % 4
     const int ntr = a.Crs / 32;
-    f32x16 acc[3][3];
+    f32x16 acc[3][NT];
     {
         const uint4* wp[3];
         MI355_UNROLL
@@ -542,25 +547,25 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const float v = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow];
                 MI355_UNROLL
-                for (int j = 0; j < 3; ++j) acc[i][j][r] = v;
+                for (int j = 0; j < NT; ++j) acc[i][j][r] = v;
             }
             wp[i] = reinterpret_cast<const uint4*>(a.w_rs) + (long)q * NG * 192 + lane;
         }
         if (!(a.ablate & 1)) {
             if (two) {
-                b3_chunk<3, 3, NG, 3, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
             } else {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
-                f32x16 a2[2][3];
+                f32x16 a2[2][NT];
                 const uint4* w2[2] = {wp[0], wp[1]};
                 MI355_UNROLL
                 for (int i = 0; i < 2; ++i)
                     MI355_UNROLL
-                    for (int j = 0; j < 3; ++j) a2[i][j] = acc[i][j];
-                b3_chunk<2, 3, NG, 3, W1>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                    for (int j = 0; j < NT; ++j) a2[i][j] = acc[i][j];
+                b3_chunk<2, NT, NG, NT, W1>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 MI355_UNROLL
                 for (int i = 0; i < 2; ++i)
                     MI355_UNROLL
-                    for (int j = 0; j < 3; ++j) acc[i][j] = a2[i][j];
+                    for (int j = 0; j < NT; ++j) acc[i][j] = a2[i][j];
             }
         }
     }
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
         if (q >= ntr) continue;
         const bool to_h = two && 32 * q < H;  // wave-uniform
         MI355_UNROLL
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int t = t0 + j * 32 + bcol;
             const int tc = t < a.T ? t : a.T - 1;  // clamped: loads stay unconditional, stores are guarded
             const bool live = t < len;
@@ -610,14 +615,19 @@ bool wn_layer_b3_supported(int H, int K, int dil) {
 void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!wn_layer_b3_supported(a.H, a.K, a.dil)) throw std::runtime_error("wn_layer_b3: unsupported shape");
-    a.ldx = (WNB_TB + (a.K - 1) * a.dil + 3 + 3) & ~3;
     static const int ablate = getenv("MI355VITS_WN_ABLATE") ? atoi(getenv("MI355VITS_WN_ABLATE")) : 0;
     a.ablate = ablate;
     a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
+    // 96-column tiles when they fill the chip, 32-column tiles for small grids (same bits, see k_wn_layer_b3)
+    const char* nt_s = getenv("MI355VITS_WN_B3_NT");  // read per launch: tests flip it inside one process
+    const long nwg3 = (long)((a.T + 95) / 96) * a.B;
+    const int nt = nt_s ? atoi(nt_s) : (nwg3 < 128 ? 1 : 3);
+    const int tb = nt == 1 ? 32 : 96;
+    a.ldx = (tb + (a.K - 1) * a.dil + 3 + 3) & ~3;
     size_t shmem = (size_t)3 * WNB_NG * 2 * a.ldx * 16;
-    const size_t raw = (size_t)2 * WNB_H * WNB_TB * sizeof(float);
+    const size_t raw = (size_t)2 * WNB_H * tb * sizeof(float);
     if (raw > shmem) shmem = raw;
-    dim3 grid((a.T + WNB_TB - 1) / WNB_TB, a.B);
+    dim3 grid((a.T + tb - 1) / tb, a.B);
     auto go = [&](auto kfn) {
 #ifndef MI355_EMU
         static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -625,8 +635,13 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
     };
-    if (a.math == MATH_BF16W) go(k_wn_layer_b3<true>);
-    else go(k_wn_layer_b3<false>);
+    if (nt == 1) {
+        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>);
+        else go(k_wn_layer_b3<false, 1>);
+    } else {
+        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3>);
+        else go(k_wn_layer_b3<false, 3>);
+    }
 }
 
 bool wn_layer_fused_supported(int H, int K, int dil) {

@@ -417,6 +417,21 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
         eng.close()
     L = int(outs["f32"]["lengths"][1])
     assert rel_rms(outs["bf16x3"]["audio"][1, :L], outs["f32"]["audio"][1, :L]) < 2e-5
+    # the two tile widths of the split-bf16 layer kernel (96 columns for full grids, 32 for small ones) do the same
+    # arithmetic in the same order: identical bits, so the choice may depend on the grid size
+    import os
+
+    by_nt = {}
+    for nt in ("1", "3"):
+        os.environ["MI355VITS_WN_B3_NT"] = nt
+        try:
+            eng = Engine(blob, library=emu_lib)
+            eng.set_math("bf16x3")
+            by_nt[nt] = eng.run(ids, np.array([30, 17]), (0.667, 1.0, 0.8), sid, forced_durations=forced, seed=3)["audio"]
+            eng.close()
+        finally:
+            del os.environ["MI355VITS_WN_B3_NT"]
+    assert np.array_equal(by_nt["1"], by_nt["3"])
 
 
 def test_bf16_weights_mode_separate_tolerance(emu_lib):
