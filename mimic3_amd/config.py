@@ -162,6 +162,16 @@ class VitsConfig:
         audio = d.get("audio", {})
         infer = d.get("inference", {})
         cfg = VitsConfig()
+        # A key that config.json leaves out takes the REFERENCE's default (ModelConfig, mimic3_tts/config.py:112-139: the
+        # "high quality" graph — ResBlock1, kernels 3/7/11, upsampling 8-8-2-2 from 512 channels), not this engine's
+        # "low" defaults: the reference would build exactly that graph from the same file.
+        cfg.resblock = "1"
+        cfg.resblock_kernel_sizes = (3, 7, 11)
+        cfg.resblock_dilation_sizes = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+        cfg.upsample_rates = (8, 8, 2, 2)
+        cfg.upsample_initial_channel = 512
+        cfg.upsample_kernel_sizes = (16, 16, 4, 4)
+        cfg.declared_model_keys = frozenset(k for k in model if isinstance(k, str))  # what the file actually says
         for k in (
             "num_symbols", "n_speakers", "inter_channels", "hidden_channels", "filter_channels",
             "n_heads", "n_layers", "kernel_size", "resblock", "upsample_initial_channel",

@@ -575,6 +575,7 @@ Engine::~Engine() { release(); }
 // launch helpers
 // =================================================================================================
 void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
+    a.fixed_rule = phase_b_ ? 1 : 0;  // frames-sized tensors: the kernel is a function of the layer, not of the batch's padding
     a.Cin = w.Cin;
     a.Cout = w.Cout;
     a.K = w.K;
@@ -818,6 +819,7 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
 // K6/K7 expand + K8 flow^-1 + K9-K12 decoder
 // =================================================================================================
 void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
+    struct PhaseB { bool& f; explicit PhaseB(bool& r) : f(r) { f = true; } ~PhaseB() { f = false; } } phase_guard(phase_b_);
     const mi355vits_config& c = cfg_;
     const int H = c.hidden_channels, I = c.inter_channels, half = I / 2;
     const int Tx = Tx_;
@@ -1167,6 +1169,13 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     if (multi && !args.sid) throw EngineError(MI355VITS_ERR_INVALID, "multi-speaker voice: feed 'sid' is required");
     const int B = args.batch, Tx = args.tx_max;
     if ((long)B * Tx > (1L << 26)) throw EngineError(MI355VITS_ERR_INVALID, "batch * tx_max too large");
+    {
+        // beyond 512 ids the attention falls back to a kernel that keeps one score row per wave in LDS (64 KiB)
+        const int d = c.hidden_channels / c.n_heads, tx_cap = (64 * 1024) / 16 - d - (2 * c.window_size + 1);
+        if (Tx > 512 && Tx > tx_cap)
+            throw EngineError(MI355VITS_ERR_INVALID, "phoneme sequence too long: at most " + std::to_string(tx_cap) +
+                                                     " ids per utterance (split the text into sentences, as Mimic 3 does)");
+    }
     for (int i = 0; i < 3; ++i)
         if (!std::isfinite(args.scales[i])) throw EngineError(MI355VITS_ERR_INVALID, "scales must be finite");
     if (args.scales[0] < 0 || args.scales[2] < 0) throw EngineError(MI355VITS_ERR_INVALID, "noise scales must be >= 0");

@@ -163,6 +163,7 @@ class Engine {
     hipStream_t stream_ = nullptr;
     hipEvent_t ev_start_ = nullptr, ev_end_ = nullptr;
     bool timed_ = false;
+    bool phase_b_ = false;       // inside flow_and_decoder (see Engine::conv)
     bool force_generic_ = false;
     int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
     bool no_mrf_b3_ = false;     // MATH_BF16X3: keep the on-the-fly split MRF kernel (A/B against the pre-split one)

@@ -42,6 +42,8 @@ struct ConvArgs {
     int yvec = 0;  // set by the launcher: output rows are 16-byte aligned -> vector stores (polyphase epilogue)
     int ovec = 0;  // set by the launcher: row-major epilogue through LDS (16-byte loads / stores of y, res)
     int ablate = 0;  // timing experiments only (MI355VITS_CONV_ABLATE): 1 no MFMA loop, 2 no staging, 4 no epilogue
+    int fixed_rule = 0;  // kernel choice from the layer shape alone, never from T (flow / decoder convs: T = frames depends on
+                         // what a row is batched with, and a row's bits must not)
 };
 
 // Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).

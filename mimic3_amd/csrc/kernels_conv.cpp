@@ -1093,7 +1093,7 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     a.ablate = ablate;
     if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
     const int n_tiles = n_tiles_for(a.epi, a.Cout, a.H);
-    if (math_on_bf16(a.math) && a.wb3 && conv1d_b3_supported(a.Cin, a.Cout, a.K, a.dil, a.T)) {
+    if (math_on_bf16(a.math) && a.wb3 && conv1d_b3_supported(a.Cin, a.Cout, a.K, a.dil, a.fixed_rule ? 1 << 30 : a.T)) {
         // split-bf16 path: one tile shape per epilogue kind (fixed by the layer, never by the batch)
         if (a.epi == EPI_GATE) launch_b3<2, 3, 2, 2, EPI_GATE>(a, n_tiles, s);
         else if (a.epi == EPI_RESSKIP) {
@@ -1139,7 +1139,7 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     static const int poly_direct_cin = getenv("MI355VITS_POLY_DIRECT_CIN") ? atoi(getenv("MI355VITS_POLY_DIRECT_CIN")) : 64;
     const bool direct = a.epi != EPI_GATE && ((a.K * (a.Cin >> 1)) % 8) == 0 &&
                         (a.shuf_s ? (a.K <= 2 && a.Cin <= poly_direct_cin && (a.shuf_s & 3) == 0)
-                                  : (a.K == 1 || (a.K <= 3 && a.T <= 512)));
+                                  : (a.K == 1 || (a.K <= 3 && a.T <= 512 && !a.fixed_rule)));
     // deep + short (encoder FFN conv_2): split the k-steps over the four waves of a workgroup.  The rule looks at the
     // layer shape only, never at the batch size, so a row's bits do not depend on what it is batched with.
     if (direct && a.epi == EPI_STD && a.T <= 512 && a.K * (a.Cin >> 1) >= 512 && ((a.K * (a.Cin >> 1)) % 32) == 0) {

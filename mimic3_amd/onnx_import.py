@@ -635,7 +635,10 @@ def import_onnx_bytes(blob: bytes, declared: Optional[VitsConfig] = None, where:
     model = parse_model(blob)
     cfg = infer_config(model, declared)
     if declared is not None:
+        present = getattr(declared, "declared_model_keys", None)
         for k in _CHECKED:
+            if present is not None and k not in present:
+                continue  # not stated in config.json: nothing to contradict, the graph decides
             a, b = getattr(declared, k), getattr(cfg, k)
             if k == "n_speakers":
                 a, b = max(1, a), max(1, b)

@@ -308,10 +308,14 @@ class _MicroBatcher:
                     self._q.put(None)
                     break
                 items.append(nxt)
-            # only requests with identical scales / output kind can share a call (the ABI takes one `scales`)
+            # only requests with identical scales / output kind can share a call (the ABI takes one `scales`); and only
+            # requests of the same phoneme-length class: the text encoder picks its attention / FFN kernels by the padded
+            # length (<= 128, 256, 512, beyond), so within a class a row gets the kernels — and the bits — it would get alone
             groups: Dict[Any, list] = {}
             for it in items:
-                key = (tuple(np.asarray(it[2], np.float32).tolist()), it[3] is None, tuple(sorted(it[4].items())))
+                n = int(it[1][0])
+                bucket = 0 if n <= 128 else (1 if n <= 256 else (2 if n <= 512 else 3))
+                key = (tuple(np.asarray(it[2], np.float32).tolist()), it[3] is None, tuple(sorted(it[4].items())), bucket)
                 groups.setdefault(key, []).append(it)
             for group in groups.values():
                 if self._pool is not None:

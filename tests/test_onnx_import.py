@@ -185,6 +185,30 @@ def test_convert_cli_and_config_json(tmp_path, tiny_onnx):
     assert not (d / "x.m355").exists()
 
 
+def test_config_json_that_relies_on_reference_defaults(tmp_path, tiny_onnx):
+    """keys a config.json leaves out are not filled with this engine's "low" defaults and then held against the
+    graph — the graph decides them; keys it DOES state must still agree; and a file with no model keys at all gets the
+    reference's ModelConfig defaults (mimic3_tts/config.py:112-139), not ours."""
+    cfg, w, blob = tiny_onnx
+    d = tmp_path / "voice"
+    d.mkdir()
+    (d / "generator.onnx").write_bytes(blob)
+    full = json.loads(cfg.to_json())
+    partial = {"model": {k: full["model"][k] for k in ("num_symbols", "hidden_channels", "n_speakers")}, "audio": full["audio"],
+               "inference": full["inference"]}
+    (d / "config.json").write_text(json.dumps(partial))
+    cfg2, t2 = OI.import_onnx(str(d / "generator.onnx"))
+    assert cfg2.resblock == cfg.resblock and cfg2.upsample_rates == cfg.upsample_rates and set(t2) == set(w)
+    partial["model"]["n_layers"] = cfg.n_layers + 1  # stated, and wrong
+    (d / "config.json").write_text(json.dumps(partial))
+    with pytest.raises(OI.OnnxImportError, match="n_layers"):
+        OI.import_onnx(str(d / "generator.onnx"))
+    ref_defaults = VitsConfig.from_json({"model": {"num_symbols": 60}})
+    assert (ref_defaults.resblock, ref_defaults.upsample_rates, ref_defaults.upsample_initial_channel,
+            ref_defaults.resblock_kernel_sizes) == ("1", (8, 8, 2, 2), 512, (3, 7, 11))
+    assert ref_defaults.declared_model_keys == frozenset({"num_symbols"})
+
+
 def test_session_loads_the_onnx_file_directly(emu_lib, tmp_path, tiny_onnx):
     """What Mimic 3 does: InferenceSession(str(voice_dir / "generator.onnx")) — no .m355 beside it."""
     cfg, w, blob = tiny_onnx
