@@ -348,6 +348,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         b3_min_work_ = lane0.b3_min_work_;
         wn_b3_ = lane0.wn_b3_;
         no_mrf_b3_ = lane0.no_mrf_b3_;
+        no_fused_dds_ = lane0.no_fused_dds_;
     } catch (...) {
         release();
         throw;
@@ -376,6 +377,7 @@ void Engine::open_device(int device) {
     // pre-split LDS planes for the 32 / 64-channel MRF stages: measured slower than splitting on the fly (3.17 / 2.79 ms vs
     // 2.82 / 2.71 ms per step: four waves cannot hide the plane <-> row conversions of the epilogues), so it is opt-in
     no_mrf_b3_ = getenv("MI355VITS_MRF_PRESPLIT") == nullptr;
+    no_fused_dds_ = getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
     const char* mm = getenv("MI355VITS_MATH");
     if (mm && mm[0]) {
@@ -734,6 +736,23 @@ void Engine::dds(const std::string& key, float* X, float* Y1, float* Y2, int B, 
     const int C = c.hidden_channels;
     const long bs = (long)C * T;
     int dil = 1;
+    if (!force_generic_ && !no_fused_dds_ && c.dp_dds_layers >= 2 && dds_layer_fused_supported(C) &&
+        cw(key + S(".convs_1x1.%d", 0)).packed != NO_OFF) {
+        // one launch per layer; x ping-pongs through the scratch buffers and the last layer lands in X again
+        const float* src = X;
+        for (int i = 0; i < c.dp_dds_layers; ++i) {
+            float* dst = (i == c.dp_dds_layers - 1) ? X : ((i & 1) ? Y2 : Y1);
+            const ConvW& w = cw(key + S(".convs_1x1.%d", i));
+            ProfScope ps(prof_, "dds.layer", 2.0 * B * (double)T * C * C, 8.0 * B * C * T);
+            launch_dds_layer(src, dst, vec(key + S(".convs_sep.%d.weight", i)), vec(key + S(".convs_sep.%d.bias", i)),
+                             vec(key + S(".norms_1.%d.gamma", i)), vec(key + S(".norms_1.%d.beta", i)), P(w.packed), P(w.bias),
+                             vec(key + S(".norms_2.%d.gamma", i)), vec(key + S(".norms_2.%d.beta", i)), d_len_, B, C, T,
+                             c.dp_kernel_size, dil, stream_);
+            src = dst;
+            dil *= c.dp_kernel_size;
+        }
+        return;
+    }
     for (int i = 0; i < c.dp_dds_layers; ++i) {
         {
             ProfScope ps(prof_, "dds.dwconv_ln_gelu", 0, 8.0 * B * C * T);

@@ -175,6 +175,12 @@ void launch_rel_attention_mfma(const float* qkv, const float* emb_rel_k, const f
 void launch_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias, const float* gamma,
                                const float* beta, const int* len, int B, int C, int T, int K, int dil, float* y,
                                hipStream_t s);
+// one whole DDS layer: y = x + gelu(LN2(conv1x1(gelu(LN1(dwconv(x * mask))))))  (x, y different buffers; w1x1 = packed f32
+// A fragments of the 1x1 conv).  C in {32, 64, 128, 192, 256}.
+bool dds_layer_fused_supported(int C);
+void launch_dds_layer(const float* x, float* y, const float* dw_w, const float* dw_b, const float* g1, const float* b1,
+                      const float* w1x1_packed, const float* bias1x1, const float* g2, const float* b2, const int* len, int B,
+                      int C, int T, int K, int dil, hipStream_t s);
 // h[b,c,t] = w[c] * z[b,ch,t] + bias[c] + g[b,c,t]      (ConvFlow.pre on one channel + conditioning)
 void launch_convflow_pre(const float* z, int ch, const float* w, const float* bias, const float* g, int B, int C,
                          int T, float* h, hipStream_t s);

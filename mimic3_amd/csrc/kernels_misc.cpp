@@ -286,6 +286,163 @@ void launch_dds_dwconv_ln_gelu(const float* x, const float* w, const float* bias
 }
 
 // ------------------------------------------------------------------------------------------------
+// One whole DDS layer (A.6) in ONE launch:  x += gelu(LN2(conv1x1(gelu(LN1(dwconv_{K,dil}(x * mask))))))
+// A workgroup owns 32 time columns of all C channels (C / 32 waves): the depthwise conv + LN1 + GELU result goes to LDS
+// ([C][32], the B operand of the 1x1 conv), wave w computes output rows 32 w .. on the f32 matrix cores (weights: the
+// packed A fragments of the conv, streamed from L2), the raw result replaces the tile in LDS, LN2 + GELU + residual are
+// applied from there.  Three launches (9 + 18 + 7 us at batch 1) become one; the text side of the graph is bound by
+// launch latency, not by bytes (a [32, 192, 128] tensor is 3 MB).  x is updated in place (a column's inputs are the
+// neighbouring columns of the OLD x: they are read before any workgroup writes only within its own columns — the
+// depthwise halo of neighbouring workgroups therefore needs the OLD values: the kernel reads x and writes y = x_new to a
+// second buffer; the engine ping-pongs).
+// ------------------------------------------------------------------------------------------------
+struct DdsLayerArgs {
+    const float* x; float* y;          // [B, C, T] in / out (different buffers)
+    const float* dw_w; const float* dw_b;   // depthwise [C, K], [C]
+    const float* g1; const float* b1;       // LN1
+    const float* w1x1;                      // packed f32 A fragments [C/32][1][C/2][64]
+    const float* bias1x1;                   // [C]
+    const float* g2; const float* b2;       // LN2
+    const int* len;
+    int B, C, T, K, dil;
+};
+
+template <int NW>  // C = 32 NW
+__global__ __launch_bounds__(64 * NW) void k_dds_layer(DdsLayerArgs a) {
+    constexpr int C = 32 * NW, NCG = 2 * NW, NTH = 64 * NW, NPT = 16;  // 16 channels per thread: c = cg + NCG i
+    DYN_SMEM(float, smem);
+    float* Y = smem;            // [C][32]
+    float* red = smem + C * 32; // [NCG][32]
+    const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
+    const int col = tid & 31, cg = tid >> 5;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 32;
+    const int t = t0 + col;
+    const bool live = t < a.T;
+    const int L = a.len[b];
+    const int tend = L < a.T ? L : a.T;
+    const float* xb = a.x + (long)b * C * a.T;
+    auto col_sum = [&](float v) {  // sum over the NCG channel groups of this column (fixed order)
+        __syncthreads();
+        red[cg * 32 + col] = v;
+        __syncthreads();
+        float s = 0.0f;
+        MI355_UNROLL
+        for (int g = 0; g < NCG; ++g) s += red[g * 32 + col];
+        return s;
+    };
+    // ---- depthwise conv (taps through clamped indices: all loads in flight together) + LN1 + GELU -> Y
+    float v[NPT];
+    {
+        const int pad = (a.K * a.dil - a.dil) / 2;
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) v[i] = a.dw_b[cg + NCG * i];
+        for (int k = 0; k < a.K; ++k) {
+            const int tt = (live ? t : 0) - pad + k * a.dil;
+            const bool in = tt >= 0 && tt < tend;
+            const int tc = in ? tt : 0;
+            float xv[NPT], wv[NPT];
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                const int c = cg + NCG * i;
+                xv[i] = xb[(long)c * a.T + tc];
+                wv[i] = a.dw_w[c * a.K + k];
+            }
+            if (in) {
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) v[i] = fmaf(wv[i], xv[i], v[i]);
+            }
+        }
+        float sum = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) sum += v[i];
+        const float mean = col_sum(sum) / (float)C;
+        float sq = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) { const float d = v[i] - mean; sq += d * d; }
+        const float rstd = 1.0f / sqrtf(col_sum(sq) / (float)C + 1e-5f);
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) {
+            const int c = cg + NCG * i;
+            Y[c * 32 + col] = live ? gelu_erf((v[i] - mean) * rstd * a.g1[c] + a.b1[c]) : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- 1x1 conv on the f32 matrix cores: wave w -> rows 32 w .. 32 w + 31, the 32 columns; k-steps = channel pairs
+    const int brow = lane >> 5, bcol = lane & 31;
+    f32x16 acc;
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    {
+        const float* wp = a.w1x1 + (long)w * (C / 2) * 64 + lane;
+        const float* yb = Y + brow * 32 + bcol;
+        float ra[8];
+        MI355_UNROLL
+        for (int u = 0; u < 4; ++u) ra[u] = wp[u * 64];
+        for (int cp0 = 0; cp0 < C / 2; cp0 += 8) {
+            MI355_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const int nxt = cp0 + u + 4 < C / 2 ? cp0 + u + 4 : C / 2 - 1;  // the tail re-reads the last record
+                ra[(u + 4) & 7] = wp[nxt * 64];
+                acc = MFMA_32x32x2_F32(ra[u], yb[(cp0 + u) * 64], acc);
+            }
+        }
+    }
+    float bias[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) bias[r] = a.bias1x1[32 * w + (r & 3) + 8 * (r >> 2) + 4 * brow];
+    __syncthreads();  // every wave is done reading Y: the raw conv result takes its place
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) Y[(32 * w + (r & 3) + 8 * (r >> 2) + 4 * brow) * 32 + bcol] = acc[r] + bias[r];
+    __syncthreads();
+    // ---- LN2 + GELU + residual
+    {
+        float z[NPT], xr[NPT];
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) {
+            const int c = cg + NCG * i;
+            z[i] = Y[c * 32 + col];
+            xr[i] = xb[(long)c * a.T + (live ? t : 0)];
+        }
+        float sum = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) sum += z[i];
+        const float mean = col_sum(sum) / (float)C;
+        float sq = 0.0f;
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) { const float d = z[i] - mean; sq += d * d; }
+        const float rstd = 1.0f / sqrtf(col_sum(sq) / (float)C + 1e-5f);
+        if (live) {
+            float* yo = a.y + (long)b * C * a.T + t;
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                const int c = cg + NCG * i;
+                yo[(long)c * a.T] = xr[i] + gelu_erf((z[i] - mean) * rstd * a.g2[c] + a.b2[c]);
+            }
+        }
+    }
+}
+
+bool dds_layer_fused_supported(int C) { return C == 32 || C == 64 || C == 128 || C == 192 || C == 256; }
+
+void launch_dds_layer(const float* x, float* y, const float* dw_w, const float* dw_b, const float* g1, const float* b1,
+                      const float* w1x1_packed, const float* bias1x1, const float* g2, const float* b2, const int* len, int B,
+                      int C, int T, int K, int dil, hipStream_t s) {
+    if (T <= 0 || B <= 0) return;
+    DdsLayerArgs a{x, y, dw_w, dw_b, g1, b1, w1x1_packed, bias1x1, g2, b2, len, B, C, T, K, dil};
+    dim3 grid((T + 31) / 32, B);
+    const size_t sh = ((size_t)C * 32 + (size_t)(C / 16) * 32) * sizeof(float);
+    switch (C / 32) {
+        case 1: LAUNCH_KERNEL(k_dds_layer<1>, grid, dim3(64), sh, s, a); break;
+        case 2: LAUNCH_KERNEL(k_dds_layer<2>, grid, dim3(128), sh, s, a); break;
+        case 4: LAUNCH_KERNEL(k_dds_layer<4>, grid, dim3(256), sh, s, a); break;
+        case 6: LAUNCH_KERNEL(k_dds_layer<6>, grid, dim3(384), sh, s, a); break;
+        case 8: LAUNCH_KERNEL(k_dds_layer<8>, grid, dim3(512), sh, s, a); break;
+        default: throw std::runtime_error("dds_layer: unsupported channel count");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // relative-position multi-head attention (A.4).  One wave per query row; scores and probabilities of the
 // row live in LDS; window terms E_k / E_v enter as 2W+1 extra logits / values.
 //   s[i,j] = (q_i/sqrt(d)) . k_j + [|j-i|<=W] (q_i/sqrt(d)) . E_k[j-i+W];  masked -> -1e4;  softmax_j

@@ -454,3 +454,24 @@ def test_bf16_weights_mode_separate_tolerance(emu_lib):
         errs[mode] = rel_rms(out["audio"][0, :L], ora["audio"][0, 0, :L])
         eng.close()
     assert errs["bf16x3"] < 1e-5 and 1e-5 < errs["bf16w"] < 2e-2, errs
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "h192"])
+def test_fused_dds_layer_kernel(emu_lib, cfgname, monkeypatch):
+    """k_dds_layer (depthwise conv + LN + GELU + 1x1 conv on the matrix cores + LN + GELU + residual in one launch) against
+    the three-launch path: same durations, logw within f32 rounding; and against the oracle (check_parity)."""
+    cfg = VitsConfig.tiny(n_speakers=2) if cfgname == "tiny" else VitsConfig.tiny_h192()
+    w = W.synthetic_weights(cfg, seed=91, frames_per_id=2.5)
+    out, _ = check_parity(emu_lib, cfg, B=2, Tx=37, seed=91, weights=w, noise=True)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    ids = np.random.default_rng(9).integers(1, cfg.num_symbols, (2, 37))
+    sid = np.array([1, 0]) if cfg.is_multispeaker else None
+    eng.run(ids, [37, 20], [0, 1, 0], sid, debug_taps=True)
+    fused = eng.tap("logw"), eng.tap("w_ceil")
+    eng.close()
+    monkeypatch.setenv("MI355VITS_NO_FUSED_DDS", "1")
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    eng.run(ids, [37, 20], [0, 1, 0], sid, debug_taps=True)
+    plain = eng.tap("logw"), eng.tap("w_ceil")
+    eng.close()
+    assert np.array_equal(fused[1], plain[1]) and np.abs(fused[0] - plain[0]).max() < 1e-4
