@@ -465,9 +465,12 @@ def cpu_baseline(cfg, weights, wl, budget_s):
         nw = rng.standard_normal((nb, 2, Tx)).astype(np.float32)
         nz = rng.standard_normal((nb, cfg.inter_channels, Tx * fpi)).astype(np.float32)
 
+        last = {}
+
         def once():
             r = ora.infer(ids_c, len_c, wl.scales, sid=sid_c, noise_w=nw, noise_z=nz, forced_durations=wl.forced[:nb],
                           stage_rows=())
+            last["r"] = r
             return [audio_float_to_int16(r["audio"][b, 0, : int(r["audio_lengths"][b])]) for b in range(nb)]
 
         t_begin = time.perf_counter()
@@ -480,8 +483,22 @@ def cpu_baseline(cfg, weights, wl, budget_s):
             times.append(time.perf_counter() - t1)
         n = sum(len(p) for p in pcm)
         med = float(np.median(times)) if times else warm
+        # the checker doing its job in the same run: the engine (the handles just timed, same math mode) on the very
+        # inputs the oracle was timed on — both Gaussian draws injected — against the oracle's waveform
+        out = wl.engines[0].run(ids_c, len_c, wl.scales, sid_c, noise_w=nw, noise_z=nz, forced_durations=wl.forced[:nb],
+                                want_float=True, want_pcm16=True)
+        r = last["r"]
+        rel, same_len, worst_lsb = 0.0, True, 0
+        for b in range(nb):
+            L = int(out["lengths"][b])
+            same_len = same_len and L == int(r["audio_lengths"][b])
+            a64, r64 = out["audio"][b, :L].astype(np.float64), r["audio"][b, 0, :L].astype(np.float64)
+            rel = max(rel, float(np.sqrt(np.mean((a64 - r64) ** 2)) / max(1e-30, np.sqrt(np.mean(r64 ** 2)))))
+            worst_lsb = max(worst_lsb, int(np.abs(out["pcm"][b, :L].astype(np.int32) - pcm[b].astype(np.int32)).max()))
         return {"utterances_per_call": nb, "threads": threads, "samples": n, "runs": len(times), "ms_median": med * 1e3,
-                "samples_per_s": n / med}
+                "samples_per_s": n / med,
+                "engine_vs_oracle": {"rel_rms_worst_row": rel, "tolerance": 1e-4, "lengths_equal": same_len,
+                                     "int16_max_lsb": worst_lsb, "math": wl.math}}
 
     # more threads than ~32 only slows the small ops down (and all 128 SMT threads oversubscribe badly): the second leg
     # buys throughput by batching four utterances into one call instead
@@ -494,6 +511,7 @@ def cpu_baseline(cfg, weights, wl, budget_s):
                   f"{fpi} frames/id = {best['samples']} samples per call, median of {best['runs']} calls after 1 warm-up, "
                   "run + int16",
         "ms_median": best["ms_median"], "x_realtime": best["samples_per_s"] / SAMPLE_RATE,
+        "engine_vs_oracle": best["engine_vs_oracle"],
         "legs": legs, "host_cpus": ncpu, "cpu": _cpu_model(), "torch": torch.__version__,
     }
 

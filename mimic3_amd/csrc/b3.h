@@ -59,54 +59,109 @@ __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NA], const uint4* con
     }
 }
 
-// stage x[c0 : c0 + 16 NG, ts : ts + LD) as three bf16 planes: mask, leaky-relu and split fused.  A thread takes one
-// (group, half) and four columns: eight 16-byte loads along time (channels 16G + 4h + 0..3 and 16G + 8 + 4h + 0..3),
-// 16 pair-splits, twelve 16-byte LDS stores.
-template <int NG>
-__device__ __forceinline__ void stage_planes(const float* __restrict__ xb, long x_ld, int LD, int ts, int tend, float slope,
-                                             uint4* __restrict__ planes, int PS, int vec, int nthreads = 256) {
-    const int ld4 = LD >> 2;
-    const int n_items = NG * 2 * ld4;
-    // two items per thread and pass: their sixteen 16-byte loads are in flight together (one memory round trip per pass)
-    for (int idx0 = threadIdx.x; idx0 < n_items; idx0 += 2 * nthreads) {
-        float v[2][8][4];
+// The same loop with the B operand single-buffered: column tile j's three plane fragments are refilled for the next
+// group right after the MFMAs of column tile j have issued (the other column tiles' MFMAs cover the LDS latency), so a
+// wave holds NT x 3 instead of 2 x NT x 3 B fragments: 36 VGPRs fewer at NT = 3, which is what lets eight waves (two
+// per SIMD, 256 VGPRs each) carry 2 x 3 accumulator tiles.  Same products in the same order per accumulator.
+template <int MT, int NT, int NG, bool W1 = false>
+__device__ __forceinline__ void b3_chunk_lean(f32x16 (&acc)[MT][NT], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS, int LD,
+                                              int K, int groups_per_tap, int dil) {
+    uint4 ra[2][MT][3];
+    uint4 rb[NT][3];
+    constexpr int NPA = W1 ? 1 : 3;
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
         MI355_UNROLL
-        for (int u = 0; u < 2; ++u) {
-            const int idx = idx0 + u * nthreads;
-            const int idc = idx < n_items ? idx : idx0;  // a missing second item re-reads the first (discarded)
-            const int gh = idc / ld4, c4 = idc - gh * ld4;  // gh = group * 2 + half
-            const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
-            const int tt = ts + 4 * c4;
-            // the in-range test depends on the columns only: one branch around all eight rows, so that the eight loads
-            // are in flight together (a test per row makes hipcc wait for every load before it issues the next)
-            if (vec && tt >= 0 && tt + 3 < tend) {
-                float4 r4[8];
+        for (int p = 0; p < NPA; ++p) ra[0][i][p] = wp[i][p * 64];
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j)
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) rb[j][p] = xq[p * PS + j * 32];
+    for (int k = 0; k < K; ++k) {
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            const bool wrap = g + 1 == NG;
+            const long woff = (wrap ? (last_tap ? (long)k * groups_per_tap + g : (long)(k + 1) * groups_per_tap) : (long)k * groups_per_tap + g + 1) * 192;
+            const int xoff = wrap ? (last_tap ? k * dil + g * 2 * LD : (k + 1) * dil) : k * dil + (g + 1) * 2 * LD;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
                 MI355_UNROLL
-                for (int e = 0; e < 8; ++e) r4[e] = *reinterpret_cast<const float4*>(xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld + tt);
-                MI355_UNROLL
-                for (int e = 0; e < 8; ++e) { v[u][e][0] = r4[e].x; v[u][e][1] = r4[e].y; v[u][e][2] = r4[e].z; v[u][e][3] = r4[e].w; }
-            } else {
-                MI355_UNROLL
-                for (int e = 0; e < 8; ++e) {
-                    const float* row = xb + (long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld;
+                for (int p = 0; p < NPA; ++p) ra[nxt][i][p] = wp[i][woff + p * 64];
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) {
+                // the MT accumulators of this column tile are independent chains: product by product across them
+                if constexpr (!W1) {
                     MI355_UNROLL
-                    for (int j = 0; j < 4; ++j) v[u][e][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
+                    for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[cur][i][2], rb[j][0], acc[i][j]);  // small terms first
                 }
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[cur][i][0], rb[j][2], acc[i][j]);
+                if constexpr (!W1) {
+                    MI355_UNROLL
+                    for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[cur][i][1], rb[j][1], acc[i][j]);
+                    MI355_UNROLL
+                    for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[cur][i][1], rb[j][0], acc[i][j]);
+                }
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[cur][i][0], rb[j][1], acc[i][j]);
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[cur][i][0], rb[j][0], acc[i][j]);
+                SCHED_FENCE();
+                MI355_UNROLL
+                for (int p = 0; p < 3; ++p) rb[j][p] = xq[p * PS + xoff + j * 32];
+                SCHED_FENCE();
             }
         }
-        MI355_UNROLL
-        for (int u = 0; u < 2; ++u) {
-            const int idx = idx0 + u * nthreads;
-            if (idx >= n_items) continue;
-            const int gh = idx / ld4, c4 = idx - gh * ld4;
+    }
+}
+
+// stage x[c0 : c0 + 16 NG, ts : ts + LD) as three bf16 planes: mask, leaky-relu and split fused.  A thread takes one
+// column; per (group, half) it loads that column's eight channels (16G + 4h + 0..3 and 16G + 8 + 4h + 0..3: eight
+// 4-byte loads, 256 contiguous bytes per wave and row), splits four pairs and stores one 16-byte slot per plane.
+// Consecutive lanes store consecutive slots, so every ds_write_b128 is bank-conflict free (a thread owning four
+// columns — 16-byte loads along time — stores 64 bytes apart from its neighbour: a four-way conflict on each of its
+// twelve stores, as expensive as the loop's ds_read_b128 traffic).  No alignment demands.  GB (group, half) rows are
+// loaded per batch = GB * 8 loads in flight per thread.
+template <int NG, int GB = 4>
+__device__ __forceinline__ void stage_planes(const float* __restrict__ xb, long x_ld, int LD, int ts, int tend, float slope,
+                                             uint4* __restrict__ planes, int PS, int tid, int nthreads) {
+    static_assert((NG * 2) % GB == 0, "batches of GB (group, half) rows");
+    const int last = tend > 0 ? tend - 1 : 0;
+    // narrow tiles (LD <= nthreads / 2): the threads form nthreads / LD column sets that share the rows' batches, so
+    // that all of them load (a 104-column WaveNet tile on 256 threads: 2 sets x 12 rows instead of 104 threads x 24)
+    int nparts = 1, part = 0, col0 = tid;
+    if (nthreads >= 2 * LD) {
+        nparts = nthreads / LD;
+        part = tid / LD;
+        col0 = tid - part * LD;
+        if (part >= nparts) return;
+    }
+    for (int col = col0; col < LD; col += nthreads) {
+        const int tt = ts + col;
+        const bool in = tt >= 0 && tt < tend;
+        const int tc = tt < 0 ? 0 : (tt > last ? last : tt);  // every load unconditional (clamped), masked afterwards
+        for (int g0 = part * GB; g0 < NG * 2; g0 += nparts * GB) {
+            float v[GB][8];
             MI355_UNROLL
-            for (int j = 0; j < 4; ++j) {
+            for (int u = 0; u < GB; ++u) {
+                const int gh = g0 + u, cbase = (gh >> 1) * 16 + (gh & 1) * 4;
+                MI355_UNROLL
+                for (int e = 0; e < 8; ++e) v[u][e] = xb[(long)(cbase + 8 * (e >> 2) + (e & 3)) * x_ld + tc];
+            }
+            SCHED_FENCE();  // the GB * 8 loads stay in flight together
+            MI355_UNROLL
+            for (int u = 0; u < GB; ++u) {
+                MI355_UNROLL
+                for (int e = 0; e < 8; ++e) v[u][e] = in ? lrelu_f(v[u][e], slope) : 0.0f;
                 uint4 h, m, l;
-                split3_pk(lrelu_f(v[u][0][j], slope), lrelu_f(v[u][1][j], slope), h.x, m.x, l.x);
-                split3_pk(lrelu_f(v[u][2][j], slope), lrelu_f(v[u][3][j], slope), h.y, m.y, l.y);
-                split3_pk(lrelu_f(v[u][4][j], slope), lrelu_f(v[u][5][j], slope), h.z, m.z, l.z);
-                split3_pk(lrelu_f(v[u][6][j], slope), lrelu_f(v[u][7][j], slope), h.w, m.w, l.w);
-                const int o = gh * LD + 4 * c4 + j;
+                split3_pk(v[u][0], v[u][1], h.x, m.x, l.x);
+                split3_pk(v[u][2], v[u][3], h.y, m.y, l.y);
+                split3_pk(v[u][4], v[u][5], h.z, m.z, l.z);
+                split3_pk(v[u][6], v[u][7], h.w, m.w, l.w);
+                const int o = (g0 + u) * LD + col;
                 planes[o] = h;
                 planes[PS + o] = m;
                 planes[2 * PS + o] = l;

@@ -282,8 +282,9 @@ int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Co
         const size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tin * stride, nw = (size_t)Cin * Cout * K;
         DevBuf dx(nx * 4), dy(ny * 4), dw(nw * 4), db(Cout * 4);
         HIP_CHECK(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
-        if (impl == 1) {
-            // polyphase filters on the MFMA conv kernel (the path Engine uses)
+        if (impl == 1 || impl == 2) {
+            // polyphase filters on the MFMA conv kernel (the path Engine uses); impl 2: the split-bf16 staged kernels
+            // (MATH_BF16X3; 64-channel chunks run the persistent producer / consumer form)
             const int taps = convt_taps(K, stride);
             std::vector<float> wv((size_t)stride * Cout * Cin * taps), bv((size_t)stride * Cout);
             convt_to_polyphase(w, bias, Cin, Cout, K, stride, wv.data(), bv.data());
@@ -301,6 +302,18 @@ int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Co
             u.in_slope = in_slope; u.pad = taps - 1; u.Tin = Tin;
             u.shuf_s = stride; u.shuf_p = (K - stride) / 2; u.shuf_cout = Cout; u.shuf_T = Tin * stride;
             u.B = B; u.T = Tin + taps - 1;
+            std::vector<uint32_t> b3;
+            std::unique_ptr<DevBuf> db3;
+            if (impl == 2) {
+                if (!conv1d_b3_supported(Cin, stride * Cout, taps, 1, 1 << 30)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the split-bf16 kernel");
+                b3.resize(bf16x3_packed_words_mode(stride * Cout, Cin, taps, EPI_STD));
+                pack_conv_weights_bf16x3_mode(wv.data(), stride * Cout, Cin, taps, EPI_STD, 1, b3.data());
+                db3.reset(new DevBuf(b3.size() * 4));
+                HIP_CHECK(hipMemcpy(db3->p, b3.data(), b3.size() * 4, hipMemcpyHostToDevice));
+                u.wb3 = db3->as<float>();
+                u.math = MATH_BF16X3;
+                u.fixed_rule = 1;
+            }
             launch_conv1d_mfma(u, nullptr);
             HIP_CHECK(hipDeviceSynchronize());
         } else {

@@ -999,7 +999,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 bool all_b3s = math_ == MATH_BF16X3;  // (pre-split variant: BF16X3 only)
                 for (int j = 0; j < nk && all_b3s; ++j)
                     for (int q = 0; q < 2; ++q) all_b3s = all_b3s && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3s != NO_OFF;
-                if (all_b3s && !no_mrf_b3_ && mrf_b3_supported(ch, nk, m.k, m.d1, m.d2)) {
+                if (all_b3s && ((!no_mrf_b3_ && mrf_b3_supported(ch, nk, m.k, m.d1, m.d2)) || mrf_b3w_supported(ch, nk, m.k, m.d1, m.d2))) {
                     double flops = 0;
                     for (int j = 0; j < nk; ++j) {
                         for (int q = 0; q < 2; ++q) {

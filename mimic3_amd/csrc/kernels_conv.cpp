@@ -17,6 +17,8 @@
 #include <cstring>
 
 #include "kernels.h"
+#include <atomic>
+#include <type_traits>
 #include "b3.h"
 
 namespace m355 {
@@ -241,9 +243,11 @@ __device__ __forceinline__ void epi_gate_tile(const ConvArgs& a, int b, int c0, 
 // (channel-major / phase-minor), so the 4 consecutive rows a lane holds per register group are 4 consecutive phases of
 // one channel = 4 consecutive output samples: a 16-byte store per lane, 1 KiB contiguous per store instruction.
 template <int MT, int NT>
-__device__ __forceinline__ void epi_polyphase_regs(const ConvArgs& a, const f32x16 (&acc)[MT][NT], int b, int tcol0, int tile0,
+__device__ __forceinline__ void epi_polyphase_regs(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int tcol0, int tile0,
                                                    int brow) {
-    // this lane's 16 biases per row tile, loaded under one test (a test per element serialises the loads)
+    // this lane's 16 biases per row tile, loaded under one test (a test per element serialises the loads) and waited
+    // for before the first store: a load the compiler sinks between the stores has to wait, through the in-order
+    // vmcnt, for every store issued before it — one write round trip per register group
     float bv[MT][16];
     MI355_UNROLL
     for (int i = 0; i < MT; ++i)
@@ -257,6 +261,49 @@ __device__ __forceinline__ void epi_polyphase_regs(const ConvArgs& a, const f32x
                 const int cop = 32 * (tile0 + i) + 8 * (r >> 2) + 4 * brow + (r & 3);
                 bv[i][r] = a.bias[cop < a.Cout ? cop : a.Cout - 1];
             }
+    }
+    // bias added in place (the accumulators are dead after the epilogue), so every load is consumed before the fence
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int j = 0; j < NT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv[i][r];
+    SCHED_FENCE();
+    const int bcol = threadIdx.x & 31;
+    const int tw = WAVE_UNIFORM(tcol0 - bcol);  // the wave's first column
+    const int al = (-a.shuf_p) & 3;             // alignment class of every store of this launch (s % 4 == 0, rows in fours)
+    // interior tile (whole wave, all NT column tiles, every row tile complete): straight-line stores, no per-lane tests
+    const bool interior = a.yvec && (al == 0 || al == 2) && (a.Cout & 31) == 0 && 32 * (tile0 + MT) <= a.Cout && tw + NT * 32 <= a.T &&
+                          (long)tw * a.shuf_s - a.shuf_p >= 0 && (long)(tw + NT * 32) * a.shuf_s - a.shuf_p <= a.shuf_T;
+    if (interior) {
+        // the alignment class is decided once, outside the loops (inside, hipcc merges the two store shapes into a
+        // dword + dwordx3 pair for both)
+        auto store_all = [&](auto AL) {
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i) {
+                MI355_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const int cop = 32 * (tile0 + i) + 8 * g + 4 * brow;
+                    const int c = cop / a.shuf_s, r0 = cop - c * a.shuf_s;
+                    float* yrow = a.y + (long)b * a.y_bs + (long)c * a.y_ld + (r0 - a.shuf_p) + (long)tcol0 * a.shuf_s;
+                    MI355_UNROLL
+                    for (int j = 0; j < NT; ++j) {
+                        float* yp = yrow + (long)j * 32 * a.shuf_s;
+                        const float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                        if constexpr (decltype(AL)::value == 0) {
+                            *reinterpret_cast<float4*>(yp) = make_float4(v0, v1, v2, v3);
+                        } else {
+                            *reinterpret_cast<float2*>(yp) = make_float2(v0, v1);
+                            *reinterpret_cast<float2*>(yp + 2) = make_float2(v2, v3);
+                        }
+                    }
+                }
+            }
+        };
+        if (al == 0) store_all(std::integral_constant<int, 0>{});
+        else store_all(std::integral_constant<int, 2>{});
+        return;
     }
     MI355_UNROLL
     for (int j = 0; j < NT; ++j) {
@@ -272,7 +319,7 @@ __device__ __forceinline__ void epi_polyphase_regs(const ConvArgs& a, const f32x
                 const int n0 = t * a.shuf_s + r0 - a.shuf_p;
                 float v[4];
                 MI355_UNROLL
-                for (int m = 0; m < 4; ++m) v[m] = acc[i][j][4 * g + m] + bv[i][4 * g + m];
+                for (int m = 0; m < 4; ++m) v[m] = acc[i][j][4 * g + m];
                 float* yp = a.y + (long)b * a.y_bs + (long)c * a.y_ld + n0;
                 if (n0 >= 0 && n0 + 3 < a.shuf_T && (n0 & 3) == 0 && a.yvec) {
                     *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -794,7 +841,7 @@ __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
 
     const int brow = lane >> 5, bcol = lane & 31;
     for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
-        if (!(a.ablate & 2)) stage_planes<NG>(xb + (long)c0 * a.x_ld, a.x_ld, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, planes, PS, a.vec);
+        if (!(a.ablate & 2)) stage_planes<NG>(xb + (long)c0 * a.x_ld, a.x_ld, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, planes, PS, tid, 256);
         __syncthreads();
         if (!(a.ablate & 1)) {
             const uint4* wp[MT];
@@ -809,6 +856,95 @@ __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
         __syncthreads();
     }
     conv_epilogue<MT, NT, WM, WN, EPI>(a, acc, xs, b, t0, tile0, n_tiles, wm, wn, brow, bcol, tid, out_len);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent producer / consumer form of k_conv1d_b3 for the polyphase upsamplers (few taps, so little matrix-core work
+// per staged chunk: a workgroup that stages, computes and stores in turn leaves the CU idle through two memory round
+// trips per tile; measured 0.25 matrix-core busy, 68 - 100 TFLOP/s).  Eight waves: waves 0-3 own the accumulators and
+// run b3_chunk + the register scatter epilogue on LDS buffer s & 1 while waves 4-7 stage step s + 1 (next chunk, or the
+// first chunk of this workgroup's next tile) into the other buffer; one barrier per step.  The grid is one workgroup per
+// CU; tiles are dealt round-robin with the row block fastest, so the row blocks sharing an input tile run side by side.
+// The chunk order of an output is the same as in k_conv1d_b3 (results identical).
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int WM, int WN, int NG, bool W1 = false>
+__global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 consumer waves per workgroup");
+    DYN_SMEM(float, xs);
+    constexpr int T_B = 32 * NT * WN;
+    constexpr int CI_C = 16 * NG;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const bool producer = wid >= 4;
+    const int wm = (wid & 3) / WN, wn = (wid & 3) % WN;
+    const int LD = (T_B + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    const int PS = NG * 2 * LD;  // uint4 per plane
+    const int n_tiles = (a.Cout + 31) / 32;
+    const int gpt = a.Cin >> 4;
+    const int Tin = a.Tin >= 0 ? a.Tin : a.T;
+    const int col_tiles = (a.T + T_B - 1) / T_B;
+    const int row_blocks = (n_tiles + MT * WM - 1) / (MT * WM);
+    const long total = (long)col_tiles * row_blocks * a.B;
+    const int nchunks = a.Cin / CI_C;
+    const long n_mine = blockIdx.x < total ? (total - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long steps = n_mine * nchunks;
+    uint4* planes = reinterpret_cast<uint4*>(xs);
+    const int brow = lane >> 5, bcol = lane & 31;
+
+    auto stage = [&](long s, int stid, int nthreads) {
+        const long i = s / nchunks;
+        const int chunk = (int)(s - i * nchunks);
+        const long tile = blockIdx.x + i * gridDim.x;
+        const long q = tile / row_blocks;
+        const int ct = (int)(q % col_tiles), b = (int)(q / col_tiles);
+        const int in_len = a.in_len ? a.in_len[b] : Tin;
+        // all 8 x 2 NG loads of a thread in one batch: the CU's vector-memory path returns data in issue order across
+        // waves, so while the producers' HBM loads are in flight the consumers' weight-fragment loads (L2 hits) wait
+        // behind them — one miss train per step costs the consumers one memory latency, two cost two
+        stage_planes<NG, NG * 2>(a.x + (long)b * a.x_bs + (long)chunk * CI_C * a.x_ld, a.x_ld, LD, ct * T_B - a.pad, Tin < in_len ? Tin : in_len,
+                                 a.in_slope, planes + (s & 1) * 3 * PS, PS, stid, nthreads);
+    };
+
+    if (steps > 0) stage(0, tid, 512);
+    __syncthreads();
+    // two loops, one per role, with the same number of barriers: the accumulators exist in the consumer waves' loop only
+    // (in one loop with a role branch inside they would be live through the producer branch as well)
+    if (producer) {
+        for (long s = 0; s < steps; ++s) {
+            if (s + 1 < steps && !(a.ablate & 2)) stage(s + 1, tid - 256, 256);
+            __syncthreads();
+        }
+        return;
+    }
+    f32x16 acc[MT][NT];
+    for (long s = 0; s < steps; ++s) {
+        const long i = s / nchunks;
+        const int chunk = (int)(s - i * nchunks);
+        const long tile = blockIdx.x + i * gridDim.x;
+        const int rb = (int)(tile % row_blocks);
+        const int tile0 = (rb * WM + wm) * MT;
+        if (chunk == 0) {
+            MI355_UNROLL
+            for (int ii = 0; ii < MT; ++ii)
+                MI355_UNROLL
+                for (int jj = 0; jj < NT; ++jj)
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[ii][jj][r] = 0.0f;
+        }
+        const uint4* wp[MT];
+        MI355_UNROLL
+        for (int ii = 0; ii < MT; ++ii) {
+            int t = tile0 + ii;
+            if (t >= n_tiles) t = n_tiles - 1;
+            wp[ii] = reinterpret_cast<const uint4*>(a.wb3) + ((long)t * a.K * gpt + (chunk * CI_C >> 4)) * 192 + lane;
+        }
+        if (!(a.ablate & 1)) b3_chunk_lean<MT, NT, NG, W1>(acc, wp, planes + (s & 1) * 3 * PS + brow * LD + bcol + wn * NT * 32, PS, LD, a.K, gpt, a.dil);
+        if (chunk == nchunks - 1 && (!(a.ablate & 4) || acc[0][0][0] == 1.2345f)) {
+            const long q = tile / row_blocks;
+            const int ct = (int)(q % col_tiles), b = (int)(q / col_tiles);
+            epi_polyphase_regs<MT, NT>(a, acc, b, ct * T_B + wn * NT * 32 + bcol, tile0, brow);
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1030,6 +1166,20 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
 // (the polyphase upsamplers) take 64-channel chunks when C_in allows — with so few taps a 32-channel chunk is only 72 - 144
 // MFMAs per wave between two stage / barrier cycles.  The chunk size is a function of the layer alone (never of the batch),
 // so the summation order of an output does not depend on what it is batched with.
+// compute units of the current device (persistent grids), looked up once per device
+static int device_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipDeviceProp_t p;
+        n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 template <int MT, int NT, int WM, int WN, int EPI>
 void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
     constexpr int T_B = 32 * NT * WN;
@@ -1057,6 +1207,24 @@ void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av);
     };
     if constexpr (EPI == EPI_STD) {
+        static const bool no_pc = getenv("MI355VITS_NO_B3_PC") != nullptr;
+        if (wide && a.shuf_s && (a.shuf_s & 3) == 0 && !no_pc && 2 * shmem <= 160 * 1024) {
+            // persistent producer / consumer form: two staging buffers, one workgroup per CU
+            const long total = (long)grid.x * grid.y * grid.z;
+            const int cus = device_cu_count();
+            shmem *= 2;
+            grid = dim3((unsigned)(total < cus ? total : cus), 1, 1);
+            auto gop = [&](auto kfn) {
+#ifndef MI355_EMU
+                static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)once;
+#endif
+                LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, av);
+            };
+            if (a.math == MATH_BF16W) gop(k_conv1d_b3_pc<MT, NT, WM, WN, 4, true>);
+            else gop(k_conv1d_b3_pc<MT, NT, WM, WN, 4, false>);
+            return;
+        }
         if (wide) {
             if (a.math == MATH_BF16W) go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, true>);
             else go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, false>);

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_mrf_b3(MrfArgs a) {
     int len = a.len ? a.len[b] : a.T;
     if (len > a.T) len = a.T;
 
-    if (!(a.ablate & 2)) stage_planes<NG>(a.x + (long)b * a.x_bs, a.x_ld, LDX, t0 - R, len, 0.1f, Xp, PSX, a.vec);
+    if (!(a.ablate & 2)) stage_planes<NG>(a.x + (long)b * a.x_bs, a.x_ld, LDX, t0 - R, len, 0.1f, Xp, PSX, tid, 256);
     __syncthreads();
 
     f32x16 out[1][NT2];
@@ -537,6 +537,188 @@ __global__ __launch_bounds__(256) void k_mrf_b3(MrfArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 32 channels (the last stage: one 32-row tile, so a weight fragment feeds only the column tiles of its own wave, and
+// eight waves fetching every fragment from L2 for every workgroup is more traffic than the CU's vector-memory path
+// carries next to the matrix cores).  Here the weights of the running conv sit in LDS as well:
+//   * LDS: x planes + x1 planes (pre-split, as k_mrf_b3) + a segment (<= kp taps) of the running conv's bf16x3 fragments
+//     (2 groups x 3 KiB per tap); both MFMA operands are ds_read_b128, the loops carry no VALU and no global loads at
+//     all, so a wave alone on its SIMD (whole register file) runs them back to back with one group of look-ahead;
+//   * the next segment and the next bias travel into registers under the running loop (nothing in the loop waits on
+//     the vector-memory counter) and are written to LDS between the barriers that separate two segments;
+//   * four waves; conv2 computes 8 column tiles (2 per wave), conv1 the extended range tb + 2 r2 in 8..12 tiles dealt in
+//     contiguous runs of 2 or 3; tb <= 256 is chosen so that the widest conv1 is a whole number of tiles
+//     (the "_low" voices, r2 = 2 / 12 / 36: tb = 248, conv1 tiles 8 / 9 / 10).
+// ------------------------------------------------------------------------------------------------
+constexpr int MW_KMAX = 11, MW_N1MAX = 10, MW_WREGS = 8;  // taps per conv; conv1 column tiles; uint4 per thread and segment (kp <= 5)
+
+__global__ __launch_bounds__(256) void k_mrf_b3w(MrfArgs a) {
+    constexpr int NG = 2, NT2 = 2, NT1 = 3;
+    DYN_SMEM(float, smem);
+    const int LDX = a.ldx, LD1 = a.ld1, R = a.R, T_B = a.tb, KP = a.kp;
+    const int PSX = NG * 2 * LDX, PS1 = NG * 2 * LD1;
+    uint4* Xp = reinterpret_cast<uint4*>(smem);
+    uint4* X1p = Xp + 3 * PSX;
+    uint4* Wl = X1p + 3 * PS1;  // [taps of the segment][NG][3 planes][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wt = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * T_B;
+    int len = a.len ? a.len[b] : a.T;
+    if (len > a.T) len = a.T;
+
+    // a conv of K taps runs in ceil(K / KP) segments of (nearly) equal length
+    auto seg_taps = [&](int K) { const int np = (K + KP - 1) / KP; return (K + np - 1) / np; };
+    uint4 wr[MW_WREGS];
+    auto w_fetch = [&](const float* wsrc, int k0, int taps) {  // clamped: every load unconditional
+        const uint4* src = reinterpret_cast<const uint4*>(wsrc) + (long)k0 * NG * 192;
+        const int n = taps * NG * 192;
+        MI355_UNROLL
+        for (int i = 0; i < MW_WREGS; ++i) {
+            const int idx = tid + 256 * i;
+            wr[i] = src[idx < n ? idx : n - 1];
+        }
+    };
+    auto w_store = [&](int taps) {
+        const int n = taps * NG * 192;
+        MI355_UNROLL
+        for (int i = 0; i < MW_WREGS; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < n) Wl[idx] = wr[i];
+        }
+    };
+    auto bias_load = [&](const float* bp, float (&bv)[16]) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2) + 4 * brow];
+    };
+    // fetch the segment that follows (j, q, k0 .. k0 + taps): the same conv's next taps, the other conv, the next resblock
+    auto fetch_next = [&](int j, int q, int k0, int taps) {
+        const int K = a.k[j];
+        if (k0 + taps < K) {
+            const int st = seg_taps(K);
+            w_fetch(a.w[j][q], k0 + taps, K - (k0 + taps) < st ? K - (k0 + taps) : st);
+        } else if (q == 0) {
+            w_fetch(a.w[j][1], 0, seg_taps(K));
+        } else {
+            const int jn = j + 1 < a.nrb ? j + 1 : j;  // after the last conv: a harmless re-read
+            w_fetch(a.w[jn][0], 0, seg_taps(a.k[jn]));
+        }
+    };
+    auto next_taps = [&](int j, int q, int k0, int taps) {
+        const int K = a.k[j];
+        if (k0 + taps < K) { const int st = seg_taps(K); return K - (k0 + taps) < st ? K - (k0 + taps) : st; }
+        if (q == 0) return seg_taps(K);
+        return seg_taps(a.k[j + 1 < a.nrb ? j + 1 : j]);
+    };
+
+    w_fetch(a.w[0][0], 0, seg_taps(a.k[0]));
+    if (!(a.ablate & 2)) stage_planes<NG>(a.x + (long)b * a.x_bs, a.x_ld, LDX, t0 - R, len, 0.1f, Xp, PSX, tid, 256);
+    w_store(seg_taps(a.k[0]));
+    float bias_n[16];
+    bias_load(a.bias[0][0], bias_n);
+    __syncthreads();
+
+    f32x16 out[1][NT2];
+    MI355_UNROLL
+    for (int i = 0; i < NT2; ++i)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) out[0][i][r] = 0.0f;
+    const uint4* wl[1] = {Wl + lane};
+
+    for (int j = 0; j < a.nrb; ++j) {
+        const int K = a.k[j], d1 = a.d1[j], d2 = a.d2[j];
+        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
+        const int st = seg_taps(K);
+        // ---- conv1 over the extended range e in [0, tb + 2 r2): column tile q <-> t = t0 - r2 + 32 q + bcol; this wave: a
+        // contiguous run of cnt (2 or 3) tiles from `start`
+        const int n1 = (T_B + 2 * r2 + 31) / 32;
+        const int base = n1 >> 2, rem = n1 & 3;
+        const int cnt = base + (wt < rem ? 1 : 0), start = wt * base + (wt < rem ? wt : rem);
+        float bias[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
+        bias_load(a.bias[j][1], bias_n);
+        f32x16 acc1[1][NT1];
+        MI355_UNROLL
+        for (int i = 0; i < NT1; ++i) {
+            if (i < cnt) {
+                float v[16];
+                planes_to_rows(Xp, PSX, LDX, 0, brow, (R - r2) + (start + i) * 32 + bcol, v);
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) acc1[0][i][r] = unlrelu(v[rec_index(r)]) + bias[r];
+            }
+        }
+        for (int k0 = 0; k0 < K; k0 += st) {
+            const int taps = K - k0 < st ? K - k0 : st;
+            fetch_next(j, 0, k0, taps);
+            const uint4* xq = Xp + brow * LDX + bcol + (R - r2 - r1) + start * 32 + k0 * d1;
+            if (!(a.ablate & 1)) {
+                if (cnt >= 3) b3_chunk<1, 3, NG, NT1>(acc1, wl, xq, PSX, LDX, taps, NG, d1);
+                else if (cnt == 2) b3_chunk<1, 2, NG, NT1>(acc1, wl, xq, PSX, LDX, taps, NG, d1);
+                else if (cnt == 1) b3_chunk<1, 1, NG, NT1>(acc1, wl, xq, PSX, LDX, taps, NG, d1);
+            }
+            __syncthreads();  // every wave is done with this segment (last one: and with the previous resblock's x1)
+            if (k0 + taps >= K) {
+                // conv1 epilogue: x1 (zero outside the row), leaky-relu, split -> planes
+                MI355_UNROLL
+                for (int i = 0; i < NT1; ++i) {
+                    if (i < cnt) {
+                        const int e = (start + i) * 32 + bcol;
+                        const int t = t0 - r2 + e;
+                        const bool live = t >= 0 && t < len;
+                        float v[16];
+                        MI355_UNROLL
+                        for (int r = 0; r < 16; ++r) {
+                            const float x1 = acc1[0][i][r];
+                            v[rec_index(r)] = live ? fmaxf(x1, 0.1f * x1) : 0.0f;
+                        }
+                        if (e < LD1) rows_to_planes(X1p, PS1, LD1, 0, brow, e, v);
+                    }
+                }
+            }
+            w_store(next_taps(j, 0, k0, taps));
+            __syncthreads();
+        }
+        // ---- conv2 into the output registers: out += x1 + bias + conv(lrelu(x1)); this wave: output tiles 2 wt, 2 wt + 1
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
+        bias_load(a.bias[j + 1 < a.nrb ? j + 1 : j][0], bias_n);
+        MI355_UNROLL
+        for (int i = 0; i < NT2; ++i) {
+            float v[16];
+            planes_to_rows(X1p, PS1, LD1, 0, brow, r2 + (wt * NT2 + i) * 32 + bcol, v);
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) out[0][i][r] += unlrelu(v[rec_index(r)]) + bias[r];
+        }
+        for (int k0 = 0; k0 < K; k0 += st) {
+            const int taps = K - k0 < st ? K - k0 : st;
+            const bool last_seg = j + 1 == a.nrb && k0 + taps >= K;
+            if (!last_seg) fetch_next(j, 1, k0, taps);
+            if (!(a.ablate & 1)) b3_chunk<1, NT2, NG>(out, wl, X1p + brow * LD1 + bcol + wt * NT2 * 32 + k0 * d2, PS1, LD1, taps, NG, d2);
+            if (!last_seg) {
+                __syncthreads();
+                w_store(next_taps(j, 1, k0, taps));
+                __syncthreads();
+            }
+        }
+    }
+
+    const bool mean = !(a.out_scale > 0.0f);
+    const float n = (float)a.nrb;
+    MI355_UNROLL
+    for (int i = 0; i < NT2; ++i) {
+        const int c0 = (wt * NT2 + i) * 32 + bcol;
+        const int t = t0 + c0;
+        if (c0 < T_B && t < a.T && !(a.ablate & 4)) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * brow;
+                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = mean ? out[0][i][r] / n : out[0][i][r] * a.out_scale;
+            }
+        }
+    }
+}
+
 namespace {
 struct GeoB3 { int C, T_B, WT, NT1MAX; };
 inline bool geometry_b3(int C, GeoB3* g) {
@@ -561,7 +743,47 @@ inline void shape_b3(const GeoB3& g, int nrb, const int* k, const int* d1, const
 }
 }  // namespace
 
+namespace {
+// geometry of k_mrf_b3w: halo R, row pitches, output columns per workgroup, LDS bytes
+inline bool shape_b3w(int nrb, const int* k, const int* d1, const int* d2, int* R, int* ldx, int* ld1, int* tb, int* kp, size_t* lds) {
+    int Rm = 0, r2max = 0, over = 0, kmax = 1;
+    for (int j = 0; j < nrb; ++j) {
+        if (k[j] < 1 || (k[j] % 2) == 0 || k[j] > MW_KMAX || d1[j] < 1 || d2[j] < 1) return false;
+        const int r1 = (k[j] - 1) / 2 * d1[j], r2 = (k[j] - 1) / 2 * d2[j];
+        Rm = Rm > r1 + r2 ? Rm : r1 + r2;
+        r2max = r2max > r2 ? r2max : r2;
+        over = over > r1 - r2 ? over : r1 - r2;
+        kmax = kmax > k[j] ? kmax : k[j];
+    }
+    // output columns: at most 8 tiles (2 per wave), and the widest conv1 (tb + 2 max r2) a whole number of tiles <= 10
+    int t = 32 * MW_N1MAX - 2 * r2max;
+    if (t > 256) t = 256;
+    if (t < 128) return false;
+    const int n1max = (t + 2 * r2max + 31) / 32;
+    *R = Rm;
+    *tb = t;
+    *ldx = (Rm + 32 * n1max + over + 3) & ~3;
+    *ld1 = (32 * ((t + 31) / 32) + 2 * r2max + 3) & ~3;
+    const size_t planes = (size_t)192 * (*ldx + *ld1);
+    if (planes + 2 * 6144 > LDS_LIMIT) return false;
+    int p = (int)((LDS_LIMIT - planes) / 6144);  // taps of weight fragments that fit next to the planes
+    if (p > 5) p = 5;                            // MW_WREGS uint4 per thread = 5 taps
+    if (p > kmax) p = kmax;
+    *kp = p;
+    *lds = planes + (size_t)p * 6144;
+    return true;
+}
+inline bool no_b3w() { return getenv("MI355VITS_MRF_NO_B3W") != nullptr; }  // read per call: tests flip it inside one process
+}  // namespace
+
+bool mrf_b3w_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
+    int R, ldx, ld1, tb, kp;
+    size_t lds;
+    return C == 32 && nrb >= 1 && nrb <= MRF_MAX_RB && !no_b3w() && shape_b3w(nrb, k, d1, d2, &R, &ldx, &ld1, &tb, &kp, &lds);
+}
+
 bool mrf_b3_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
+    if (mrf_b3w_supported(C, nrb, k, d1, d2)) return true;
     GeoB3 g;
     if (!geometry_b3(C, &g) || nrb < 1 || nrb > MRF_MAX_RB) return false;
     int R, ldx, ld1;
@@ -572,6 +794,19 @@ bool mrf_b3_supported(int C, int nrb, const int* k, const int* d1, const int* d2
 
 void launch_mrf_b3(MrfArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
+    if (mrf_b3w_supported(a.C, a.nrb, a.k, a.d1, a.d2)) {
+        size_t shmem;
+        shape_b3w(a.nrb, a.k, a.d1, a.d2, &a.R, &a.ldx, &a.ld1, &a.tb, &a.kp, &shmem);
+        const char* ab = getenv("MI355VITS_MRF_ABLATE");
+        a.ablate = ab ? atoi(ab) : 0;
+        dim3 grid((a.T + a.tb - 1) / a.tb, a.B);
+#ifndef MI355_EMU
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mrf_b3w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+        (void)once;
+#endif
+        LAUNCH_KERNEL(k_mrf_b3w, grid, dim3(256), shmem, s, a);
+        return;
+    }
     GeoB3 g;
     if (!geometry_b3(a.C, &g) || !mrf_b3_supported(a.C, a.nrb, a.k, a.d1, a.d2)) throw std::runtime_error("mrf_b3: unsupported stage shape");
     bool ok;

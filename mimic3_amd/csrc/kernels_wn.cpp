@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     const int PS = NG * 2 * LD;    // uint4 per plane
     const bool two = a.Crs == 2 * H;
 
-    if (!(a.ablate & 2)) stage_planes<NG>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, a.vec);
+    if (!(a.ablate & 2)) stage_planes<NG, NG>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, 256);  // 2 column sets x 12 rows: one round trip
     __syncthreads();
 
     // ---- in-layer conv: wave w owns row tiles w, w + 4, w + 8 (rows 32 q .. 32 q + 31 of the 2H), all 3 column tiles
@@ -570,41 +570,59 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
         }
     }
     if ((a.ablate & 4) && acc[0][0][0] != 1.2345f) return;
-    // ---- epilogue: rows < H (two-output layers): h' = (h + rs) * mask; the others: skip (+)= rs.  Per 32 x 32 tile the 16
-    // old values of a lane are loaded under one wave-uniform test (all in flight together), then combined and stored.
+    // ---- epilogue: rows < H (two-output layers): h' = (h + rs) * mask; the others: skip (+)= rs.  The 16 old values a
+    // lane needs per 32 x 32 tile are loaded unconditionally (clamped column) and one tile ahead of the stores: the
+    // memory counter retires in order, so a load issued after a store cannot be waited for without waiting for that
+    // store's acknowledgement too — with tile k + 1's loads in front of tile k's stores no wait includes a fresh store.
+    const float* src[3];
+    float* dst[3];
+    long ldr[3];
+    bool valid[3], use_old[3], to_h[3];
     MI355_UNROLL
     for (int i = 0; i < 3; ++i) {
         const int q = w + 4 * i;
-        if (q >= ntr) continue;
-        const bool to_h = two && 32 * q < H;  // wave-uniform
-        MI355_UNROLL
-        for (int j = 0; j < NT; ++j) {
-            const int t = t0 + j * 32 + bcol;
-            const int tc = t < a.T ? t : a.T - 1;  // clamped: loads stay unconditional, stores are guarded
-            const bool live = t < len;
-            float old[16];
-            if (to_h) {
-                MI355_UNROLL
-                for (int r = 0; r < 16; ++r) old[r] = a.h_in[(long)b * a.h_bs + (long)(32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.h_ld + tc];
-                if (t < a.T) {
-                    MI355_UNROLL
-                    for (int r = 0; r < 16; ++r)
-                        a.h_out[(long)b * a.h_bs + (long)(32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.h_ld + t] = live ? old[r] + acc[i][j][r] : 0.0f;
-                }
-            } else {
-                const int sub = two ? H : 0;
-                if (!a.skip_init) {
-                    MI355_UNROLL
-                    for (int r = 0; r < 16; ++r) old[r] = a.skip[(long)b * a.s_bs + (long)(32 * q - sub + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.s_ld + tc];
-                }
-                if (t < a.T) {
-                    MI355_UNROLL
-                    for (int r = 0; r < 16; ++r)
-                        a.skip[(long)b * a.s_bs + (long)(32 * q - sub + (r & 3) + 8 * (r >> 2) + 4 * brow) * a.s_ld + t] =
-                            a.skip_init ? acc[i][j][r] : old[r] + acc[i][j][r];
-                }
-            }
+        valid[i] = q < ntr;
+        const int qc = valid[i] ? q : ntr - 1;
+        to_h[i] = two && 32 * qc < H;  // wave-uniform
+        if (to_h[i]) {
+            src[i] = a.h_in + (long)b * a.h_bs + (long)(32 * qc) * a.h_ld;
+            dst[i] = a.h_out + (long)b * a.h_bs + (long)(32 * qc) * a.h_ld;
+            ldr[i] = a.h_ld;
+            use_old[i] = true;
+        } else {
+            const int sub = two ? H : 0;
+            src[i] = a.skip + (long)b * a.s_bs + (long)(32 * qc - sub) * a.s_ld;
+            dst[i] = a.skip + (long)b * a.s_bs + (long)(32 * qc - sub) * a.s_ld;
+            ldr[i] = a.s_ld;
+            use_old[i] = !a.skip_init;
         }
+    }
+    auto load_tile = [&](int i, int j, float (&old)[16]) {
+        const int t = t0 + j * 32 + bcol;
+        const int tc = t < a.T ? t : a.T - 1;
+        if (valid[i] && use_old[i]) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) old[r] = src[i][(long)((r & 3) + 8 * (r >> 2) + 4 * brow) * ldr[i] + tc];
+        } else {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) old[r] = 0.0f;
+        }
+    };
+    auto store_tile = [&](int i, int j, const float (&old)[16]) {
+        const int t = t0 + j * 32 + bcol;
+        if (!valid[i] || t >= a.T) return;
+        const bool live = t < len || !to_h[i];  // h' is masked, skip is not (its consumer masks)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) dst[i][(long)((r & 3) + 8 * (r >> 2) + 4 * brow) * ldr[i] + t] = live ? old[r] + acc[i][j][r] : 0.0f;
+    };
+    float old[2][16];
+    load_tile(0, 0, old[0]);
+    MI355_UNROLL
+    for (int k = 0; k < 3 * NT; ++k) {
+        if (k + 1 < 3 * NT) load_tile((k + 1) / NT, (k + 1) % NT, old[(k + 1) & 1]);
+        SCHED_FENCE();
+        store_tile(k / NT, k % NT, old[k & 1]);
+        SCHED_FENCE();
     }
 }
 

@@ -77,6 +77,28 @@ def test_conv_transpose1d(emu_lib, case, impl):
     assert np.abs(y - ref).max() < 1e-5
 
 
+@pytest.mark.parametrize("case", [(2, 64, 32, 450, 8, 4), (1, 128, 64, 210, 16, 8), (3, 64, 16, 70, 8, 4)])
+def test_conv_transpose1d_split_bf16_persistent(emu_lib, case):
+    """impl 2: the polyphase upsampler on the split-bf16 staged kernel; with 64-channel chunks that is the persistent
+    producer / consumer form (k_conv1d_b3_pc: 8 "CUs" in the CPU model, so workgroups loop over several tiles, one and
+    two chunks per tile, a ragged last column tile, more row blocks than one).  Against fp64, and bit-identical to the
+    one-tile-per-workgroup kernel (same chunk order)."""
+    import os
+
+    B, Cin, Cout, Tin, K, s = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(2 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = emu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1, impl=2)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(),
+                             torch.from_numpy(b).double(), stride=s, padding=(K - s) // 2).numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 5e-6
+    y1 = emu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1, impl=1)
+    assert np.abs(y - ref).max() <= 1.5 * np.abs(y1 - ref).max() + 1e-7
+
+
 def test_engine_matches_oracle_tiny_ragged(emu_lib):
     check_parity(emu_lib, VitsConfig.tiny(), B=3, Tx=11, seed=1)
 
@@ -395,6 +417,43 @@ def test_bf16x3_engine_path_long_utterance_uses_the_staged_split_kernels(emu_lib
                           sid=np.array([0, 2]), weights=w, engine=eng)
     assert int(out["lengths"][0]) == 560 * cfg.hop_length
     eng.close()
+
+
+@pytest.mark.parametrize("dils", [((1, 2), (2, 6), (3, 12)), ((1, 3), (1, 3), (1, 3)), ((3, 1), (2, 1), (1, 2))])
+def test_bf16x3_last_stage_mrf_with_weights_in_lds(emu_lib, dils):
+    """k_mrf_b3w (32-channel stage, MATH_BF16X3): x / x1 as pre-split planes and the running conv's weight fragments in
+    LDS in segments of a few taps.  The "_low" voices' dilations (248 output columns per workgroup, conv1 in 8 / 9 / 10 column
+    tiles, the 7-tap convs in two segments), a narrow set (256 columns) and one with r1 > r2; ragged batch over several
+    workgroups; decoder stage taps and the waveform vs the oracle, and vs the on-the-fly kernel."""
+    import os
+
+    cfg = VitsConfig.tiny_wide()
+    cfg.resblock_dilation_sizes = dils
+    w = W.synthetic_weights(cfg, seed=77, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 24
+    forced = np.full((2, Tx), 3, np.int32)  # 72 frames -> 576 columns in the 32-channel stage: 3 workgroups per row
+    ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (2, Tx))
+    lengths = np.array([Tx, Tx - 7])
+    outs = {}
+    for tag, env in (("b3w", None), ("fused", "MI355VITS_MRF_NO_B3W")):
+        if env:
+            os.environ[env] = "1"
+        try:
+            eng = Engine(blob, library=emu_lib)
+            eng.set_math("bf16x3")
+            eng.profile_enable(True)
+            outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=77, weights=w, engine=eng)
+            labels = set(eng.profile_report())
+            assert ("dec.mrf_b3.s1" in labels) == (tag == "b3w") and ("dec.mrf_fused.s1" in labels) == (tag == "fused"), labels
+            eng.close()
+        finally:
+            if env:
+                del os.environ[env]
+    # same products, same order, f32 accumulate in both: the split-once kernel reproduces the split-per-use kernel's bits
+    for bi in range(2):
+        L = int(outs["fused"]["lengths"][bi])
+        assert rel_rms(outs["b3w"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
 
 
 @pytest.mark.parametrize("n_speakers", [1, 3])

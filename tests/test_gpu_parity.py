@@ -62,6 +62,21 @@ def test_conv_transpose1d(gpu_lib, case, impl):
     assert np.abs(y - ref).max() < 5e-5
 
 
+@pytest.mark.parametrize("case", [(1, 256, 128, 100, 16, 8), (2, 128, 64, 333, 16, 8), (3, 64, 32, 20000, 8, 4), (32, 64, 32, 1500, 8, 4)])
+def test_conv_transpose1d_split_bf16_persistent(gpu_lib, case):
+    """impl 2: polyphase upsampler on the split-bf16 persistent producer / consumer kernel (k_conv1d_b3_pc): fewer tiles
+    than CUs, and several tiles per workgroup (the last two cases: 315 and 768 tiles on 256 CUs), vs fp64."""
+    B, Cin, Cout, Tin, K, s = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(2 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = gpu_lib.test_conv_transpose1d(x, w, b, s, in_slope=0.1, impl=2)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(),
+                             torch.from_numpy(b).double(), stride=s, padding=(K - s) // 2).numpy()
+    assert np.abs(y - ref).max() < 5e-6
+
+
 @pytest.mark.parametrize("cfgname", ["tiny", "tiny_ms", "tiny_rb1"])
 def test_tiny_graphs_match_oracle(gpu_lib, cfgname):
     cfg = {"tiny": VitsConfig.tiny(), "tiny_ms": VitsConfig.tiny(n_speakers=4), "tiny_rb1": VitsConfig.tiny(resblock="1")}[cfgname]
