@@ -49,21 +49,29 @@ __device__ __forceinline__ void epi_std(const ConvArgs& a, int b, int co, int t,
 }
 
 // epi_std on four consecutive time samples t .. t+3 (all < T, rows 16-byte aligned): 16-byte loads / stores
-__device__ __forceinline__ void epi_std4(const ConvArgs& a, int b, int co, int t, float4 v, int out_len) {
+// what the 4-wide standard epilogue reads from global memory, apart from the conv result: loaded for a batch of items
+// before the first of them is stored (a load issued after a store cannot be waited for without waiting for the store's
+// acknowledgement as well — the memory counter retires in order)
+struct EpiStd4In { float bias, cond; float4 r4, y4; };
+__device__ __forceinline__ EpiStd4In epi_std4_load(const ConvArgs& a, int b, int co, int t) {
+    EpiStd4In L;
+    L.bias = a.bias ? a.bias[co] : 0.0f;
+    L.cond = a.cond ? a.cond[(long)b * a.cond_bs + co] : 0.0f;
+    L.r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.res) L.r4 = *reinterpret_cast<const float4*>(a.res + (long)b * a.res_bs + (long)co * a.res_ld + t);
+    L.y4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.accumulate) L.y4 = *reinterpret_cast<const float4*>(a.y + (long)b * a.y_bs + (long)co * a.y_ld + t);
+    return L;
+}
+__device__ __forceinline__ void epi_std4_finish(const ConvArgs& a, int b, int co, int t, float4 v, int out_len, const EpiStd4In& L) {
     float x[4] = {v.x, v.y, v.z, v.w};
-    const float bias = (a.bias ? a.bias[co] : 0.0f) + (a.cond ? a.cond[(long)b * a.cond_bs + co] : 0.0f);
-    float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (a.res) r4 = *reinterpret_cast<const float4*>(a.res + (long)b * a.res_bs + (long)co * a.res_ld + t);
-    const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
-    float* yp = a.y + (long)b * a.y_bs + (long)co * a.y_ld + t;
-    float4 y4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (a.accumulate) y4 = *reinterpret_cast<const float4*>(yp);
-    const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+    const float rr[4] = {L.r4.x, L.r4.y, L.r4.z, L.r4.w};
+    const float yy[4] = {L.y4.x, L.y4.y, L.y4.z, L.y4.w};
     MI355_UNROLL
     for (int m = 0; m < 4; ++m) {
         float q = x[m];
-        if (a.bias) q += a.bias[co];  // same order of additions as epi_std: bias, then cond
-        if (a.cond) q += a.cond[(long)b * a.cond_bs + co];
+        if (a.bias) q += L.bias;  // same order of additions as epi_std: bias, then cond
+        if (a.cond) q += L.cond;
         if (a.relu) q = fmaxf(q, 0.0f);
         if (a.mask_before_res && t + m >= out_len) q = 0.0f;
         if (a.res) q = a.res_sub ? rr[m] - q : rr[m] + q;
@@ -72,8 +80,10 @@ __device__ __forceinline__ void epi_std4(const ConvArgs& a, int b, int co, int t
         if (a.accumulate) q += yy[m];
         x[m] = q;
     }
-    (void)bias;
-    *reinterpret_cast<float4*>(yp) = make_float4(x[0], x[1], x[2], x[3]);
+    *reinterpret_cast<float4*>(a.y + (long)b * a.y_bs + (long)co * a.y_ld + t) = make_float4(x[0], x[1], x[2], x[3]);
+}
+__device__ __forceinline__ void epi_std4(const ConvArgs& a, int b, int co, int t, float4 v, int out_len) {
+    epi_std4_finish(a, b, co, t, v, out_len, epi_std4_load(a, b, co, t));
 }
 
 // WaveNet gate (A.9): u = tanh(a[:H] + cond) * sigmoid(a[H:] + cond)
@@ -694,6 +704,50 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 }
             }
             __syncthreads();
+            if (!a.shuf_s) {
+                // plain conv: four items per thread and batch — their global reads (bias, residual, accumulate) first,
+                // then the four stores
+                constexpr int U = 4;
+                const int total = rows_o * quads;
+                for (int idx0 = tid; idx0 < total; idx0 += 256 * U) {
+                    EpiStd4In L[U];
+                    int copv[U];
+                    long nv[U];
+                    int kind[U];  // 0: nothing, 1: whole quad inside, 2: edge quad
+                    MI355_UNROLL
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = idx0 + 256 * u;
+                        kind[u] = 0;
+                        if (idx < total) {
+                            const int rr = idx / quads, q = idx - rr * quads;
+                            copv[u] = 32 * ((blockIdx.y * WM + rr / 32) * MT + i) + rr % 32;
+                            nv[u] = n4_lo + 4L * q;
+                            if (copv[u] < a.Cout) kind[u] = (nv[u] >= n_lo && nv[u] + 3 < n_end) ? 1 : 2;
+                            if (kind[u] == 1) L[u] = epi_std4_load(a, b, copv[u], (int)nv[u]);
+                        }
+                    }
+                    SCHED_FENCE();
+                    MI355_UNROLL
+                    for (int u = 0; u < U; ++u) {
+                        if (kind[u] == 0) continue;
+                        const int idx = idx0 + 256 * u;
+                        const int rr = idx / quads;
+                        const long n = nv[u];
+                        const float* src = xs + rr * LDO + (n - n_lo);
+                        if (kind[u] == 1) {
+                            float4 v;
+                            if (((n - n_lo) & 3) == 0) v = *reinterpret_cast<const float4*>(src);
+                            else v = make_float4(src[0], src[1], src[2], src[3]);
+                            epi_std4_finish(a, b, copv[u], (int)n, v, out_len, L[u]);
+                        } else {
+                            for (int m = 0; m < 4; ++m) {
+                                if (n + m < n_lo || n + m < 0 || n + m >= n_end) continue;
+                                epi_std(a, b, copv[u], (int)(n + m), src[m], out_len);
+                            }
+                        }
+                    }
+                }
+            } else
             for (int idx = tid; idx < rows_o * quads; idx += 256) {
                 const int rr = idx / quads, q = idx - rr * quads;
                 const int wmr = (rr * s_) / 32;                                    // which wave row this came from

@@ -773,7 +773,10 @@ inline bool shape_b3w(int nrb, const int* k, const int* d1, const int* d2, int* 
     *lds = planes + (size_t)p * 6144;
     return true;
 }
-inline bool no_b3w() { return getenv("MI355VITS_MRF_NO_B3W") != nullptr; }  // read per call: tests flip it inside one process
+// opt-in (MI355VITS_MRF_B3W=1): measured 5.4 ms against the on-the-fly kernel's 2.9 ms on the bench workload — with one
+// 32-row tile every MFMA needs 0.67 KiB of LDS operands (the loops run at the LDS port's pace, not the matrix cores'),
+// the 248-column tile makes ten short weight segments whose L2 fetches are exposed, and the halo costs 11 % more tiles
+inline bool no_b3w() { return getenv("MI355VITS_MRF_B3W") == nullptr; }  // read per call: tests flip it inside one process
 }  // namespace
 
 bool mrf_b3w_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {

@@ -421,7 +421,7 @@ def test_bf16x3_engine_path_long_utterance_uses_the_staged_split_kernels(emu_lib
 
 @pytest.mark.parametrize("dils", [((1, 2), (2, 6), (3, 12)), ((1, 3), (1, 3), (1, 3)), ((3, 1), (2, 1), (1, 2))])
 def test_bf16x3_last_stage_mrf_with_weights_in_lds(emu_lib, dils):
-    """k_mrf_b3w (32-channel stage, MATH_BF16X3): x / x1 as pre-split planes and the running conv's weight fragments in
+    """k_mrf_b3w (32-channel stage, MATH_BF16X3; opt-in, MI355VITS_MRF_B3W=1): x / x1 as pre-split planes and the running conv's weight fragments in
     LDS in segments of a few taps.  The "_low" voices' dilations (248 output columns per workgroup, conv1 in 8 / 9 / 10 column
     tiles, the 7-tap convs in two segments), a narrow set (256 columns) and one with r1 > r2; ragged batch over several
     workgroups; decoder stage taps and the waveform vs the oracle, and vs the on-the-fly kernel."""
@@ -436,7 +436,7 @@ def test_bf16x3_last_stage_mrf_with_weights_in_lds(emu_lib, dils):
     ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (2, Tx))
     lengths = np.array([Tx, Tx - 7])
     outs = {}
-    for tag, env in (("b3w", None), ("fused", "MI355VITS_MRF_NO_B3W")):
+    for tag, env in (("b3w", "MI355VITS_MRF_B3W"), ("fused", None)):
         if env:
             os.environ[env] = "1"
         try:
