@@ -349,6 +349,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         wn_b3_ = lane0.wn_b3_;
         no_mrf_b3_ = lane0.no_mrf_b3_;
         no_fused_dds_ = lane0.no_fused_dds_;
+        no_post_fusion_ = lane0.no_post_fusion_;
     } catch (...) {
         release();
         throw;
@@ -378,6 +379,9 @@ void Engine::open_device(int device) {
     // 2.82 / 2.71 ms per step: four waves cannot hide the plane <-> row conversions of the epilogues), so it is opt-in
     no_mrf_b3_ = getenv("MI355VITS_MRF_PRESPLIT") == nullptr;
     no_fused_dds_ = getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
+    // opt-in: measured no faster (bench workload: 3.16 ms fused vs 2.96 + 0.22 ms) — the 32-channel MRF kernel runs one
+    // workgroup per CU, so its tail (result to LDS, barrier, 7-tap conv, store drain) is as exposed as the plain store was
+    no_post_fusion_ = getenv("MI355VITS_POST_FUSION") == nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
     const char* mm = getenv("MI355VITS_MATH");
     if (mm && mm[0]) {
@@ -954,6 +958,8 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
     int ch = C0;
     long T = Ty;
     const int nk = c.n_resblock_kernels;
+    bool post_fused = false;  // conv_post + tanh + peak done inside the last stage's MRF kernel
+    HIP_CHECK(hipMemsetAsync(d_peaks_, 0, sizeof(unsigned) * B, stream_));
     for (int i = 0; i < c.n_upsamples; ++i) {
         const int r = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
         const ConvW& up = cw(S("dec.ups.%d.poly", i));
@@ -1040,8 +1046,20 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
                     m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
+                    // last stage, whole MRF in the kernel: conv_post + tanh + peak ride along (the stage output is never
+                    // written; with debug taps on it is, through the separate kernel)
+                    double bytes = 8.0 * B * (double)T * ch;
+                    if (i == c.n_upsamples - 1 && p == nk && !taps_on_ && !no_post_fusion_ && mrf_fused_post_supported(ch, p, m.k, m.d1, m.d2)) {
+                        m.post_w = vec("dec.conv_post.weight");
+                        m.audio = d_audio_; m.audio_bs = T;
+                        m.audio_len = d_alen_;
+                        m.peak_bits = d_peaks_;
+                        post_fused = true;
+                        flops += 2.0 * B * (double)T * ch * MRF_POST_K;
+                        bytes = 4.0 * B * (double)T * (ch + 1);
+                    }
                     ProfScope ps(prof_, i == 1 ? "dec.mrf_fused.s1" : (i == 2 ? "dec.mrf_fused.s2" : (i == 0 ? "dec.mrf_fused.s0" : "dec.mrf_fused")), flops,
-                                 8.0 * B * (double)T * ch);
+                                 bytes);
                     launch_mrf_fused(m, stream_);
                     n_fused = p;
                 }
@@ -1093,8 +1111,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         }
         tap(S("dec.mrf.%d", i).c_str(), d_bufC_, {B, ch, T});
     }
-    HIP_CHECK(hipMemsetAsync(d_peaks_, 0, sizeof(unsigned) * B, stream_));
-    {
+    if (!post_fused) {
         ProfScope ps(prof_, "dec.conv_post_tanh", 2.0 * B * (double)T * ch * 7, 4.0 * B * (double)T * (ch + 1));
         launch_conv_post_tanh(d_bufC_, (long)ch * T, (int)T, vec("dec.conv_post.weight"), ch, 7, B, (int)T, d_alen_, d_audio_,
                               T, d_peaks_, stream_);

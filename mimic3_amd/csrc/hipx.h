@@ -171,35 +171,42 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ xb, long x_
 __device__ __forceinline__ int pk(int c, int col, int ld) { return ((((c >> 3) * 2 + (c & 1)) * ld + col) << 2) + ((c >> 1) & 3); }
 __device__ __forceinline__ float f4c(const float4& v, int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
 
-// global [rows][x_ld] -> packed LDS tile: a thread moves a 4 x 4 block — four 16-byte loads along time (channels
-// 8g + 2q + brow), leaky-relu, register transpose, four 16-byte LDS stores (one per column).  rows % 8 == 0, LD % 4 == 0.
-template <int NTH>
+// global [rows][x_ld] -> packed LDS tile: a thread takes one column of one (g, brow) record — four 4-byte loads (channels
+// 8g + 2q + brow; 256 contiguous bytes per wave and row), leaky-relu, one 16-byte LDS store.  Consecutive lanes store
+// consecutive records: conflict-free (a thread owning four columns stores 64 bytes apart from its neighbour, a
+// four-way bank conflict per store).  U items per thread and batch: 4 U loads in flight.  rows % 8 == 0.
+template <int NTH, int U = 5>
 __device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
                                               float slope, float* __restrict__ dst, int vec) {
-    const int ld4 = LD >> 2;
-    for (int idx = threadIdx.x; idx < (rows >> 2) * ld4; idx += NTH) {
-        const int gb = idx / ld4, c4 = idx - gb * ld4;  // gb = g * 2 + brow
-        const int c0 = (gb >> 1) * 8 + (gb & 1);
-        const int tt = ts + 4 * c4;
-        float v[4][4];
-        if (vec && tt >= 0 && tt + 3 < tend) {  // one branch around all four rows: the loads are in flight together
-            float4 r4[4];
-            MI355_UNROLL
-            for (int q = 0; q < 4; ++q) r4[q] = *reinterpret_cast<const float4*>(xb + (long)(c0 + 2 * q) * x_ld + tt);
-            MI355_UNROLL
-            for (int q = 0; q < 4; ++q) { v[q][0] = r4[q].x; v[q][1] = r4[q].y; v[q][2] = r4[q].z; v[q][3] = r4[q].w; }
-        } else {
-            MI355_UNROLL
-            for (int q = 0; q < 4; ++q) {
-                const float* row = xb + (long)(c0 + 2 * q) * x_ld;
-                MI355_UNROLL
-                for (int j = 0; j < 4; ++j) v[q][j] = (tt + j >= 0 && tt + j < tend) ? row[tt + j] : 0.0f;
-            }
-        }
+    (void)vec;
+    const int n = (rows >> 2) * LD;
+    const int last = tend > 0 ? tend - 1 : 0;
+    for (int idx0 = threadIdx.x; idx0 < n; idx0 += NTH * U) {
+        float v[U][4];
         MI355_UNROLL
-        for (int j = 0; j < 4; ++j)
-            reinterpret_cast<float4*>(dst)[gb * LD + 4 * c4 + j] =
-                make_float4(lrelu_f(v[0][j], slope), lrelu_f(v[1][j], slope), lrelu_f(v[2][j], slope), lrelu_f(v[3][j], slope));
+        for (int u = 0; u < U; ++u) {
+            const int idx = idx0 + NTH * u;
+            const int idc = idx < n ? idx : idx0;  // a missing item re-reads the first (discarded)
+            const int gb = idc / LD, col = idc - gb * LD;  // gb = g * 2 + brow
+            const int c0 = (gb >> 1) * 8 + (gb & 1);
+            const int tt = ts + col;
+            const int tc = tt < 0 ? 0 : (tt > last ? last : tt);  // clamped: every load unconditional, masked below
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) v[u][q] = xb[(long)(c0 + 2 * q) * x_ld + tc];
+        }
+        SCHED_FENCE();
+        MI355_UNROLL
+        for (int u = 0; u < U; ++u) {
+            const int idx = idx0 + NTH * u;
+            if (idx >= n) continue;
+            const int gb = idx / LD, col = idx - gb * LD;
+            const int tt = ts + col;
+            const bool in = tt >= 0 && tt < tend;
+            reinterpret_cast<float4*>(dst)[idx] = in ? make_float4(lrelu_f(v[u][0], slope), lrelu_f(v[u][1], slope), lrelu_f(v[u][2], slope),
+                                                                   lrelu_f(v[u][3], slope))
+                                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            (void)gb;
+        }
     }
 }
 

@@ -108,7 +108,15 @@ struct MrfArgs {
     float out_scale = 0.0f;  // 0: y = mean of the nrb resblocks; > 0: y = out_scale * sum (a stage fused only in part:
                              // the remaining resblocks are accumulated onto y by the conv-by-conv path)
     int ablate = 0;  // profiling only (MI355VITS_MRF_ABLATE): 1 = skip MFMA loops, 2 = skip staging, 4 = skip output
+    // last stage, 32 channels: conv_post (C -> 1, 7 taps, no bias) + tanh + per-row peak fused behind the resblocks'
+    // mean; the stage output is never written.  post_w = [C][7]; y is unused when set.
+    const float* post_w = nullptr;
+    float* audio = nullptr; long audio_bs = 0;
+    const int* audio_len = nullptr;  // [B] valid samples (peak and input mask), or null = T
+    unsigned* peak_bits = nullptr;   // [B], atomicMax of |audio| as float bits (zeroed by the caller)
 };
+constexpr int MRF_POST_K = 7;
+bool mrf_fused_post_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);
 // MATH_BF16X3 with pre-split LDS planes (C = 32 or 64); w[][] = pack_conv_weights_bf16x3_mode(..., EPI_STD, layout 1)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include <type_traits>
 #include "b3.h"
 
 namespace m355 {
@@ -192,9 +193,14 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
 // ds_read of an unrolled k-step group then carries its offset as an immediate; 0 = take them from the arguments.
 // MATH: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f32 operands split 3 x bf16, six products on the bf16 MFMA,
 // 2 = the same with the weights' leading bf16 term only (three products; "bf16 weights").
-template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0, int MATH = 0>
+// POST (32 channels, the last stage): the workgroup's 512 columns of mean(resblocks) go to LDS (the x tile's space)
+// instead of global memory, and 504 of them — the tile minus conv_post's halo of 3 (4, to keep the staging aligned) per
+// side — become audio samples: leaky-relu(0.01), 7-tap 32 -> 1 conv in the order of k_conv_post_tanh_vec (same bits),
+// tanh, per-row peak.  Saves the stage output's write, its re-read and a launch.
+template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0, int MATH = 0, bool POST = false>
 __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 8, "8 waves per workgroup");
+    static_assert(!POST || WM == 1, "conv_post is fused behind the 32-channel stage only");
     static_assert(NT1MAX == 3 && NT2MAX == 2, "static dispatch below");
     constexpr int C = 32 * WM;
     constexpr int T_B = 32 * N2;
@@ -210,13 +216,18 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     const int wt = (WM == 1) ? wid : (WM == 2 ? ((wid >> 2) * 2 + (wid & 1)) : ((wid & 1) ^ (wid >> 2)));
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * T_B;
+    const int t0 = POST ? blockIdx.x * (T_B - 8) - 4 : blockIdx.x * T_B;
     int len = a.len ? a.len[b] : a.T;
     if (len > a.T) len = a.T;
 
     for (int i = tid; i < a.nrb * 2 * C; i += 512) {
         const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
         BS[i] = a.bias[j][q][c];
+    }
+    // POST: conv_post's weights as [C][8] (7 taps + a zero; 32-byte rows, 16-byte aligned: two broadcast ds_read_b128 per channel)
+    float* PW = BS + ((a.nrb * 2 * C + 3) & ~3);
+    if constexpr (POST) {
+        if (tid < C * 8) PW[tid] = (tid & 7) < MRF_POST_K ? a.post_w[(tid >> 3) * MRF_POST_K + (tid & 7)] : 0.0f;
     }
     if (!(a.ablate & 2)) stage_tile_pk<512>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec);
     __syncthreads();
@@ -273,17 +284,87 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     }
 
     const float n = (float)a.nrb;
-    MI355_UNROLL
-    for (int i = 0; i < NT2MAX; ++i) {
-        const int t = t0 + (wt + WT * i) * 32 + bcol;
-        if (i < nt2 && t < a.T && !(a.ablate & 4)) {
+    if constexpr (POST) {
+        // X is free: its last readers (conv1 of the last resblock) passed the barrier in front of the last conv2
+        constexpr int YLD = T_B + 8;  // +8: the two half-waves (rows 4 apart) land on different banks
+        float* Y = X;
+        int vl = a.audio_len ? a.audio_len[b] : a.T;
+        if (vl > a.T) vl = a.T;
+        auto put = [&](auto MEAN) {  // the mean / scale choice once, outside the loops
             MI355_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = a.out_scale > 0.0f ? out[i][r] * a.out_scale : out[i][r] / n;
+            for (int i = 0; i < NT2MAX; ++i) {
+                if (i < nt2) {
+                    const int c0 = (wt + WT * i) * 32 + bcol;
+                    const int t = t0 + c0;
+                    const bool live = t >= 0 && t < vl;
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = (r & 3) + 8 * (r >> 2) + 4 * brow;
+                        const float v = decltype(MEAN)::value ? out[i][r] / n : out[i][r] * a.out_scale;
+                        Y[co * YLD + c0 + 1] = live ? (v >= 0.0f ? v : v * 0.01f) : 0.0f;
+                    }
+                }
+            }
+        };
+        if (a.out_scale > 0.0f) put(std::false_type{});
+        else put(std::true_type{});
+        __syncthreads();
+        // two consecutive output samples per thread, t = t0 + 4 + q and the next (q even, q < T_B - 8): their eight input
+        // columns q + 1 .. q + 8 are four 8-byte LDS reads per channel (Y is stored one column to the right: 8-byte aligned)
+        const int q = 2 * tid;
+        const int t = t0 + 4 + q;
+        float pk = 0.0f;
+        if (q < T_B - 8 && t < a.T && !(a.ablate & 4)) {
+            float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 4
+            for (int c = 0; c < C; ++c) {
+                const float2* yr = reinterpret_cast<const float2*>(Y + c * YLD + q + 2);
+                const float2 p0 = yr[0], p1 = yr[1], p2 = yr[2], p3 = yr[3];
+                const float yv[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+                const float4 w0 = reinterpret_cast<const float4*>(PW)[2 * c], w1 = reinterpret_cast<const float4*>(PW)[2 * c + 1];
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                MI355_UNROLL
+                for (int k = 0; k < MRF_POST_K; ++k) {
+                    acc0 = fmaf(wv[k], yv[k], acc0);
+                    acc1 = fmaf(wv[k], yv[k + 1], acc1);
+                }
+            }
+            const float y0 = tanhf(acc0), y1 = tanhf(acc1);
+            if (t < vl) pk = fabsf(y0);
+            if (t + 1 < vl) pk = fmaxf(pk, fabsf(y1));
+            float* ap = a.audio + (long)b * a.audio_bs + t;
+            if (t + 1 < a.T && (a.audio_bs & 1) == 0) {
+                *reinterpret_cast<float2*>(ap) = make_float2(y0, y1);
+            } else {
+                ap[0] = y0;
+                if (t + 1 < a.T) ap[1] = y1;
             }
         }
+        pk = wave_reduce_max(pk);
+        if (lane == 0) BS[wid] = pk;  // the biases are no longer needed
+        __syncthreads();
+        if (tid == 0) {
+            float m = BS[0];
+            MI355_UNROLL
+            for (int w8 = 1; w8 < 8; ++w8) m = fmaxf(m, BS[w8]);
+            atomicMax(a.peak_bits + b, __float_as_uint(m));
+        }
+        return;
     }
+    auto store_all = [&](auto MEAN) {  // the mean / scale choice once, outside the loops
+        MI355_UNROLL
+        for (int i = 0; i < NT2MAX; ++i) {
+            const int t = t0 + (wt + WT * i) * 32 + bcol;
+            if (i < nt2 && t < a.T && !(a.ablate & 4)) {
+                float* yp = a.y + (long)b * a.y_bs + (long)(wm * 32 + 4 * brow) * a.y_ld + t;
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    yp[(long)((r & 3) + 8 * (r >> 2)) * a.y_ld] = decltype(MEAN)::value ? out[i][r] / n : out[i][r] * a.out_scale;
+            }
+        }
+    };
+    if (a.out_scale > 0.0f) store_all(std::false_type{});
+    else store_all(std::true_type{});
 }
 
 namespace {
@@ -317,6 +398,10 @@ bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int*
     return ((size_t)C * (ldx + ld1) + (size_t)nrb * 2 * C) * sizeof(float) <= LDS_LIMIT;
 }
 
+bool mrf_fused_post_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
+    return C == 32 && mrf_fused_supported(C, nrb, k, d1, d2);
+}
+
 void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     Geo g;
@@ -336,8 +421,11 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
         const char* ab = getenv("MI355VITS_MRF_ABLATE");
         a.ablate = ab ? atoi(ab) : 0;
     }
-    const size_t shmem = ((size_t)a.C * (a.ldx + a.ld1) + (size_t)a.nrb * 2 * a.C) * sizeof(float);
-    dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
+    const bool post = a.post_w != nullptr;
+    const size_t shmem = ((size_t)a.C * (a.ldx + a.ld1) + (size_t)a.nrb * 2 * a.C + (post ? a.C * 8 + 4 : 0)) * sizeof(float);
+    if (post && !(a.C == 32 && a.audio && a.peak_bits && (size_t)a.C * (g.T_B + 8) <= (size_t)a.C * a.ldx && shmem <= LDS_LIMIT))
+        throw std::runtime_error("mrf_fused: conv_post fusion needs the 32-channel stage");
+    dim3 grid(post ? (a.T + g.T_B - 9) / (g.T_B - 8) : (a.T + g.T_B - 1) / g.T_B, a.B);
     auto go = [&](auto kfn) {
 #ifndef MI355_EMU
         static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
@@ -345,6 +433,18 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     };
+    if (post) {  // generic row pitches except for the default math on the "_low" shapes
+        if (a.math == MATH_BF16X3) {
+            if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1, true>);
+            else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 1, true>);
+        } else if (a.math == MATH_BF16W) {
+            go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 2, true>);
+        } else {
+            if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 0, true>);
+            else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 0, true>);
+        }
+        return;
+    }
     if (a.math == MATH_BF16X3) {
         if (a.C == 32) {
             if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1>);

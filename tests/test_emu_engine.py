@@ -456,6 +456,41 @@ def test_bf16x3_last_stage_mrf_with_weights_in_lds(emu_lib, dils):
         assert rel_rms(outs["b3w"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
 
 
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+def test_conv_post_fused_behind_the_last_mrf_stage(emu_lib, math):
+    """Opt-in MI355VITS_POST_FUSION=1.  Last stage (32 channels): conv_post + tanh + peak inside the fused MRF kernel (504 samples per 512-column tile, no stage
+    output in global memory) must give the bits of the separate kernel (same summation order) — waveform, int16 and
+    lengths; ragged batch, more than one tile per row; and the separate kernel is what runs when debug taps are on."""
+    import os
+
+    cfg = VitsConfig.tiny_wide()
+    w = W.synthetic_weights(cfg, seed=78, frames_per_id=2.0)
+    os.environ["MI355VITS_POST_FUSION"] = "1"  # opt-in (read when a handle is created)
+    try:
+        eng = Engine(W.pack(cfg, w), library=emu_lib)
+    finally:
+        del os.environ["MI355VITS_POST_FUSION"]
+    eng.set_math(math)
+    eng.profile_enable(True)
+    Tx = 40
+    forced = np.full((3, Tx), 4, np.int32)  # 160 frames -> 1280 samples: three tiles per full row
+    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (3, Tx))
+    lengths = np.array([Tx, Tx - 13, 3])
+    scales = (0.667, 1.0, 0.8)
+    fused = eng.run(ids, lengths, scales, forced_durations=forced, seed=5, want_pcm16=True)
+    assert "dec.conv_post_tanh" not in eng.profile_report()
+    eng.profile_reset()
+    plain = eng.run(ids, lengths, scales, forced_durations=forced, seed=5, want_pcm16=True, debug_taps=True)
+    assert "dec.conv_post_tanh" in eng.profile_report()
+    assert np.array_equal(fused["lengths"], plain["lengths"]) and np.array_equal(fused["peaks"], plain["peaks"])
+    for b in range(3):
+        L = int(fused["lengths"][b])
+        assert np.array_equal(fused["audio"][b, :L], plain["audio"][b, :L])
+        assert np.array_equal(fused["pcm"][b], plain["pcm"][b])
+    eng.close()
+    check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=78, weights=w)
+
+
 @pytest.mark.parametrize("n_speakers", [1, 3])
 def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
     """k_wn_layer_b3 (H = 192: 96 columns x all 384 rows per workgroup, operands split 3 x bf16, raw result gated through
