@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--math", choices=["bf16x3", "f32"], default=None,
                     help="matrix-core path of the dense convs (default: the engine's, MI355VITS_MATH or bf16x3 = f32 operands "
                          "split exactly into 3 bf16 terms, six MFMA products, f32 accumulate; f32 = v_mfma_f32 only)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "3")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "2")),
                     help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
     ap.add_argument("--single-process", action="store_true",
                     help="drive all --gpus devices from this one process (threads), no torch.distributed")

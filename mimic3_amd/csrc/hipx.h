@@ -232,11 +232,24 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {
 __device__ __forceinline__ void split3_pk(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
     h = pack_hi16(u0, u1);
+#ifdef MI355_EMU
     const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
     const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
     m = pack_hi16(v0, v1);
     const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
     l = pack_hi16(__float_as_uint(s0), __float_as_uint(s1));
+#else
+    // the pair's two subtractions of a level as one packed op (v_pk_add_f32, neg modifiers): 9 VALU per pair, not 11
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f a = {a0, a1};
+    const v2f ta = {__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
+    const v2f r = a - ta;
+    const unsigned v0 = __float_as_uint(r.x), v1 = __float_as_uint(r.y);
+    m = pack_hi16(v0, v1);
+    const v2f tr = {__uint_as_float(v0 & 0xffff0000u), __uint_as_float(v1 & 0xffff0000u)};
+    const v2f q = r - tr;
+    l = pack_hi16(__float_as_uint(q.x), __float_as_uint(q.y));
+#endif
 }
 // eight k-slots of one lane (two packed-tile float4: channels 16G + brow + 2e | 16G + 8 + brow + 2e) -> three planes
 __device__ __forceinline__ void split3_x8(const float4& lo4, const float4& hi4, uint4& h, uint4& m, uint4& l) {

@@ -60,14 +60,14 @@ def pmc(dirs, min_us=20.0):
 # bench.py profiler label -> (kernel name as rocprofv3 prints it, algorithmic bytes per launch for B x Tx x fpi)
 def _labels(B, Tx, fpi):
     Ty = Tx * fpi
-    # the needles name the MATH_BF16X3 variants (last template argument 1 / k_wn_layer_b3): the default path bench.py times;
+    # the needles name the MATH_BF16X3 variants (math template argument 1 / k_wn_layer_b3): the default path bench.py times;
     # MI355VITS_MATH=f32 runs match the ", 0>" / k_wn_layer_h192 entries
     return {
-        "dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 1>", 2 * 4 * B * 64 * Ty * 64),      # read x + write y, [64, 64 Ty]
-        "dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1>", 2 * 4 * B * 32 * Ty * 256),    # [32, 256 Ty]
+        "dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 1, false>", 2 * 4 * B * 64 * Ty * 64),      # read x + write y, [64, 64 Ty]
+        "dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1, false>", 2 * 4 * B * 32 * Ty * 256),    # [32, 256 Ty]
         "flow.wn_layer_b3": ("k_wn_layer_b3<false, 3>", 4 * 4 * B * 192 * Ty + 6 * (384 * 192 * 5 + 384 * 192)),  # h r+w, skip r+w, bf16x3 weights
-        "f32:dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 0>", 2 * 4 * B * 64 * Ty * 64),
-        "f32:dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 0>", 2 * 4 * B * 32 * Ty * 256),
+        "f32:dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 0, false>", 2 * 4 * B * 64 * Ty * 64),
+        "f32:dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 0, false>", 2 * 4 * B * 32 * Ty * 256),
         "f32:flow.wn_layer": ("k_wn_layer_h192<4>", 4 * 4 * B * 192 * Ty + 4 * (384 * 192 * 5 + 384 * 192)),
     }
 
@@ -104,7 +104,64 @@ def traffic(dirs, out_path, B=32, Tx=128, fpi=6):
     print(json.dumps(out, indent=1))
 
 
+def traffic_from_text(txt_path, out_path, B=32, Tx=128, fpi=6):
+    """The same table from a `pmc` text summary (per-launch means of FETCH_SIZE / WRITE_SIZE in KiB)."""
+    import json
+    import re
+
+    rows = {}
+    for line in open(txt_path):
+        f = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
+        w = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
+        n = re.search(r"\)\s+(\d+)\s+[0-9.]+\s+[A-Z]", line)
+        if f and w:
+            rows[line] = (float(f.group(1)), float(w.group(1)), int(n.group(1)) if n else 0)
+    out = {}
+    for label, (needle, algo) in _labels(B, Tx, fpi).items():
+        for line, (f, w, n) in rows.items():
+            if needle in line:
+                out[label] = {"workload": [B, Tx, fpi], "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+                              "algorithmic_bytes_per_launch": int(algo), "fetch_size_kib": f, "write_size_kib": w, "launches": n,
+                              "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of {needle}: "
+                                        f"2 x FETCH_SIZE + WRITE_SIZE, per launch (gfx950 FETCH_SIZE counts 64 B per 128 B request)"}
+    with open(out_path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+def derived(txt_path, min_us=20.0):
+    """Per-kernel ratios from a `pmc` text summary: mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024
+    SIMDs); wait_any / wait_inst / active / valu = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, SQ_ACTIVE_INST_VALU over
+    SQ_WAVE_CYCLES; valu/mfma = SQ_INSTS_VALU / SQ_INSTS_MFMA; lds_confl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;
+    read_MiB = 2 x FETCH_SIZE KiB / 1024 (gfx950: 64 B tallied per 128-B request), write_MiB = WRITE_SIZE KiB / 1024, per launch."""
+    import re
+
+    print(f"{'kernel':74s} {'calls':>6s} {'avg_us':>9s} {'mfma_busy':>9s} {'wait_any':>8s} {'wait_inst':>9s} {'active':>7s} {'valu':>6s} "
+          f"{'valu/mfma':>9s} {'lds_confl':>9s} {'read_MiB':>9s} {'write_MiB':>9s}")
+    for line in open(txt_path):
+        m = re.match(r"(.{80})\s+(\d+)\s+([0-9.]+)\s+(.*)", line)
+        if not m or "=" not in m.group(4):
+            continue
+        c = {k: float(v) for k, v in re.findall(r"(\w+)=([0-9.e+-]+)", m.group(4))}
+        avg = float(m.group(3))
+        if avg < min_us:
+            continue
+        g = lambda k: c.get(k, float("nan"))
+        wc = g("SQ_WAVE_CYCLES")
+        ratio = lambda a, b: a / b if b and b == b else float("nan")
+        print(f"{m.group(1)[:74]:74s} {int(m.group(2)):6d} {avg:9.1f} {ratio(g('SQ_VALU_MFMA_BUSY_CYCLES'), g('GRBM_GUI_ACTIVE') / 8 * 1024):9.3f} "
+              f"{ratio(g('SQ_WAIT_ANY'), wc):8.3f} {ratio(g('SQ_WAIT_INST_ANY'), wc):9.3f} {ratio(g('SQ_ACTIVE_INST_ANY'), wc):7.3f} "
+              f"{ratio(g('SQ_ACTIVE_INST_VALU'), wc):6.3f} {ratio(g('SQ_INSTS_VALU'), g('SQ_INSTS_MFMA')):9.1f} "
+              f"{ratio(g('SQ_LDS_BANK_CONFLICT'), g('SQ_LDS_IDX_ACTIVE')):9.3f} {2 * g('FETCH_SIZE') / 1024:9.1f} {g('WRITE_SIZE') / 1024:9.1f}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "derived":
+        derived(sys.argv[2])
+        raise SystemExit(0)
+    if len(sys.argv) >= 4 and sys.argv[1] == "traffic-from-text":
+        traffic_from_text(sys.argv[3], sys.argv[2])
+        raise SystemExit(0)
     if len(sys.argv) < 3 or sys.argv[1] not in ("stats", "pmc", "traffic"):
         raise SystemExit(__doc__)
     if sys.argv[1] == "stats":
