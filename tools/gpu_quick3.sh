@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash tools/gpu_ab.sh
-timeout 200 python bench.py --steps 30 --streams 1 --no-cpu-baseline --no-extra --no-b1 2>&1 >/dev/null | grep "headline\|mrf\|rb.s0\|wn_layer\|upsample\|conv_pre"
+for A in 0 8; do echo "== mrf ablate $A"; MI355VITS_MRF_ABLATE=$A timeout 100 python bench.py --steps 20 --streams 1 --no-cpu-baseline --no-extra --no-b1 2>&1 >/dev/null | grep "mrf_fused"; done
