@@ -350,6 +350,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         no_mrf_b3_ = lane0.no_mrf_b3_;
         no_fused_dds_ = lane0.no_fused_dds_;
         no_post_fusion_ = lane0.no_post_fusion_;
+        enc_b3_ = lane0.enc_b3_;
     } catch (...) {
         release();
         throw;
@@ -382,6 +383,7 @@ void Engine::open_device(int device) {
     // opt-in: measured no faster (bench workload: 3.16 ms fused vs 2.96 + 0.22 ms) — the 32-channel MRF kernel runs one
     // workgroup per CU, so its tail (result to LDS, barrier, 7-tap conv, store drain) is as exposed as the plain store was
     no_post_fusion_ = getenv("MI355VITS_POST_FUSION") == nullptr;
+    enc_b3_ = getenv("MI355VITS_NO_ENC_B3") == nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
     const char* mm = getenv("MI355VITS_MATH");
     if (mm && mm[0]) {
@@ -581,7 +583,11 @@ Engine::~Engine() { release(); }
 // launch helpers
 // =================================================================================================
 void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
-    a.fixed_rule = phase_b_ ? 1 : 0;  // frames-sized tensors: the kernel is a function of the layer, not of the batch's padding
+    // frames-sized tensors: the kernel is a function of the layer, not of the batch's padding.  Phoneme-sized ones (the text
+    // encoder) stay on the f32 kernels except the wide FFN conv (192 -> 768, k3: K Cin >= 512 and >= 4 row blocks), whose
+    // grid fills most of the chip even at one column tile per row — again a rule of the layer alone
+    const bool wide_enc = !phase_b_ && enc_b3_ && w.K * w.Cin >= 512 && w.Cout >= 512 && a.epi == EPI_STD;
+    a.fixed_rule = (phase_b_ || wide_enc) ? 1 : 0;
     a.Cin = w.Cin;
     a.Cout = w.Cout;
     a.K = w.K;

@@ -168,6 +168,7 @@ class Engine {
     int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
     bool no_fused_dds_ = false;  // MI355VITS_NO_FUSED_DDS=1: DDS layers as three launches (A/B + fallback)
     bool no_post_fusion_ = true;   // MI355VITS_POST_FUSION=1 (opt-in): conv_post + tanh + peak inside the last MRF stage's kernel
+    bool enc_b3_ = true;           // the encoder's wide FFN conv on the split-bf16 staged kernel (MI355VITS_NO_ENC_B3=1: f32 kernel)
     bool no_mrf_b3_ = false;     // MATH_BF16X3: keep the on-the-fly split MRF kernel (A/B against the pre-split one)
     bool wn_b3_ = false;         // MATH_BF16X3: WaveNet layers as two staged split-bf16 convs instead of the fused f32 layer
     int math_ = MATH_BF16X3;     // which matrix-core path the dense convs take (include/mi355vits.h: MI355VITS_MATH_*)

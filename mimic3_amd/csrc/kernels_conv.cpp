@@ -1322,8 +1322,15 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
             if (n_tiles >= 4) launch_b3<2, 3, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
             else launch_b3<1, 3, 2, 2, EPI_RESSKIP>(a, n_tiles, s);
         } else {
-            if (n_tiles >= 4) launch_b3<2, 3, 2, 2, EPI_STD>(a, n_tiles, s);
-            else if (n_tiles >= 2) launch_b3<1, 3, 2, 2, EPI_STD>(a, n_tiles, s);
+            // the largest tile whose grid still covers a good part of the chip, else the finest.  The three shapes walk
+            // chunks, taps and groups in the same order: an output element gets the same bits from each, so the choice
+            // may depend on the grid (batch 1 vs batch 32) without breaking "batched == unbatched"
+            auto nwg = [&](int MT, int NT, int WM, int WN) {
+                const long tb = 32L * NT * WN;
+                return ((a.T + tb - 1) / tb) * ((n_tiles + MT * WM - 1) / (MT * WM)) * (long)a.B;
+            };
+            if (n_tiles >= 4 && nwg(2, 3, 2, 2) >= 96) launch_b3<2, 3, 2, 2, EPI_STD>(a, n_tiles, s);
+            else if (n_tiles >= 2 && nwg(1, 3, 2, 2) >= 96) launch_b3<1, 3, 2, 2, EPI_STD>(a, n_tiles, s);
             else launch_b3<1, 2, 1, 4, EPI_STD>(a, n_tiles, s);
         }
         return;

@@ -491,6 +491,43 @@ def test_conv_post_fused_behind_the_last_mrf_stage(emu_lib, math):
     check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=78, weights=w)
 
 
+def test_wide_encoder_ffn_conv_on_the_split_kernel(emu_lib):
+    """The text encoder's 192 -> 768, k = 3 FFN conv (K Cin >= 512, >= 4 row blocks) runs on the split-bf16 staged kernel in
+    MATH_BF16X3 — a rule of the layer alone, so a row's bits do not depend on what it is batched with even though the
+    tile shape follows the grid size.  Encoder taps and waveform vs the oracle; batched == unbatched bitwise; and the
+    f32 kernel (MI355VITS_NO_ENC_B3=1) stays within the same tolerance of it."""
+    import os
+
+    cfg = VitsConfig.tiny_h192()
+    cfg.filter_channels = 768
+    w = W.synthetic_weights(cfg, seed=41, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    ids = np.random.default_rng(8).integers(1, cfg.num_symbols, (3, 70))
+    lengths = np.array([70, 33, 51])
+    forced = np.full((3, 70), 2, np.int32)
+    eng = Engine(blob, library=emu_lib)
+    eng.set_math("bf16x3")
+    eng.profile_enable(True)
+    out, _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=41, weights=w, engine=eng)
+    one = eng.run(ids[1:2], lengths[1:2], (0.667, 1.0, 0.8), forced_durations=forced[1:2], seed=41, utterance_base=1)
+    full = eng.run(ids, lengths, (0.667, 1.0, 0.8), forced_durations=forced, seed=41)
+    L = int(one["lengths"][0])
+    assert np.array_equal(full["audio"][1, :L], one["audio"][0, :L])
+    eng.close()
+    os.environ["MI355VITS_NO_ENC_B3"] = "1"
+    try:
+        eng = Engine(blob, library=emu_lib)
+    finally:
+        del os.environ["MI355VITS_NO_ENC_B3"]
+    eng.set_math("bf16x3")
+    ref = eng.run(ids, lengths, (0.667, 1.0, 0.8), forced_durations=forced, seed=41)
+    eng.close()
+    assert not np.array_equal(ref["audio"], full["audio"])  # two different kernels
+    for b in range(3):
+        Lb = int(full["lengths"][b])
+        assert rel_rms(full["audio"][b, :Lb], ref["audio"][b, :Lb]) < 2e-5
+
+
 @pytest.mark.parametrize("n_speakers", [1, 3])
 def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
     """k_wn_layer_b3 (H = 192: 96 columns x all 384 rows per workgroup, operands split 3 x bf16, raw result gated through
