@@ -939,7 +939,12 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
     const int row_blocks = (n_tiles + MT * WM - 1) / (MT * WM);
     const long total = (long)col_tiles * row_blocks * a.B;
     const int nchunks = a.Cin / CI_C;
-    const long n_mine = blockIdx.x < total ? (total - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // Workgroup w is observed to run on XCD w % 8 (its own L2).  Renumber the workgroups XCD-major so that the row blocks
+    // of one column tile — consecutive tile numbers, read the same input tile at the same time — share an L2 instead of
+    // fetching it once per XCD (the 256 -> 128 layer has 8 row blocks per input tile).  Placement only: any mapping is correct.
+    const unsigned G = gridDim.x;
+    const unsigned vid = (G % 8 == 0 && !(a.ablate & 16)) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    const long n_mine = vid < total ? (total - vid + G - 1) / G : 0;
     const long steps = n_mine * nchunks;
     uint4* planes = reinterpret_cast<uint4*>(xs);
     const int brow = lane >> 5, bcol = lane & 31;
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
     auto stage = [&](long s, int stid, int nthreads) {
         const long i = s / nchunks;
         const int chunk = (int)(s - i * nchunks);
-        const long tile = blockIdx.x + i * gridDim.x;
+        const long tile = vid + i * G;
         const long q = tile / row_blocks;
         const int ct = (int)(q % col_tiles), b = (int)(q / col_tiles);
         const int in_len = a.in_len ? a.in_len[b] : Tin;
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
     for (long s = 0; s < steps; ++s) {
         const long i = s / nchunks;
         const int chunk = (int)(s - i * nchunks);
-        const long tile = blockIdx.x + i * gridDim.x;
+        const long tile = vid + i * G;
         const int rb = (int)(tile % row_blocks);
         const int tile0 = (rb * WM + wm) * MT;
         if (chunk == 0) {
