@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do for E in 0 1; do
-  if [ $E = 1 ]; then export MI355VITS_MRF_S2_4W=1; else unset MI355VITS_MRF_S2_4W; fi
-  echo "== s2_4w=$E"; timeout 100 python bench.py --steps 30 --streams 1 --no-cpu-baseline --no-extra --no-b1 2>&1 >/dev/null | grep "mrf_fused.s2\|headline"
-  timeout 100 python bench.py --steps 100 --no-cpu-baseline --no-extra --no-b1 --no-roofline 2>&1 >/dev/null | grep "headline"
-done; done
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | grep "passed\|failed" | tail -2
+timeout 300 python bench.py --steps 200 --no-extra 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d['cpu_baseline']['engine_vs_oracle'])"
