@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--frames-per-id", type=int, default=6)
     ap.add_argument("--voice", choices=["apope_low", "vctk_low"], default="apope_low",
                     help="headline voice (BASELINE metric: apope_low; vctk_low is measured as an extra leg either way)")
-    ap.add_argument("--math", choices=["bf16x3", "f32"], default=None,
+    ap.add_argument("--math", choices=["bf16x3", "f32", "f16x2"], default=None,
                     help="matrix-core path of the dense convs (default: the engine's, MI355VITS_MATH or bf16x3 = f32 operands "
                          "split exactly into 3 bf16 terms, six MFMA products, f32 accumulate; f32 = v_mfma_f32 only)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "2")),
@@ -433,6 +433,21 @@ def main():
                 bw_leg["roofline"] = rl
             result["extra"]["bf16_weights"] = bw_leg
             bw.close()
+            # ---- experimental: the fused MRF stages with operands as two fp16 terms (22 significant bits, three products);
+            # same tolerances as the default in the tests, but not f32-grade by construction — reported beside, never the headline
+            hw = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
+                          math="f16x2")
+            hw.size_workspaces()
+            el_h, out_h = timed(hw, fsteps, 5)
+            h2_leg = {"math": "f16x2", "dtype": "f32 in / out / accumulate; MRF-stage operands as 2 x fp16 (22 bits), 3 MFMA products",
+                      "value": int(out_h["lengths"].sum()) * fsteps / el_h, "unit": "samples/s", "steps": fsteps,
+                      "ms_per_step": el_h / fsteps * 1e3,
+                      "note": "same workload; only the fused MRF decoder stages change (everything else as bf16x3)"}
+            if not args.no_roofline:
+                reph, tableh, toth = kernel_table(hw.engines[0], lambda i: hw.step(i, device_only=True), 3)
+                h2_leg["kernels_ms_per_step"] = {r["kernel"]: round(r["ms_per_step"], 4) for r in tableh[:8]}
+            result["extra"]["f16x2_mrf"] = h2_leg
+            hw.close()
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, wl, args.cpu_seconds)

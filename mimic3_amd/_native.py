@@ -340,11 +340,13 @@ class Engine:
         del keep
         return self._take(r)
 
-    MATH_MODES = {"f32": 0, "bf16x3": 1, "bf16w": 2}
+    MATH_MODES = {"f32": 0, "bf16x3": 1, "bf16w": 2, "f16x2": 3}
 
     def set_math(self, mode) -> None:
         """``"f32"`` (f32 MFMA), ``"bf16x3"`` (f32 operands split 3 x bf16, six bf16-MFMA products, f32 accumulate; the
-        default) or ``"bf16w"`` (bf16-rounded weights x exact activations: reduced precision, BASELINE configs[4])."""
+        default), ``"bf16w"`` (bf16-rounded weights x exact activations: reduced precision, BASELINE configs[4]) or ``"f16x2"``
+        (experimental: the fused MRF stages with operands as two fp16 terms = 22 significant bits, three products; everything
+        else as bf16x3)."""
         self._check(self.native.lib.mi355vits_set_math(self._h, self.MATH_MODES.get(mode, mode)))
 
     @property

@@ -225,6 +225,10 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             pack_conv_weights_bf16x3(w.data(), Cout, Cin, K, b3.data());
             static_assert(sizeof(uint32_t) == sizeof(float), "bit patterns travel in the float arena");
             c.packed_b3 = stage(reinterpret_cast<const float*>(b3.data()), b3.size());
+            // ... and as two fp16 planes (MATH_F16X2, experimental), unless a weight is too large for the fixed scale
+            std::vector<uint32_t> h2(f16x2_packed_words(Cout, Cin, K));
+            if (pack_conv_weights_f16x2(w.data(), Cout, Cin, K, h2.data()))
+                c.packed_h2 = stage(reinterpret_cast<const float*>(h2.data()), h2.size());
         }
         if (Cin % 32 == 0 && (epi == EPI_GATE ? (Cout / 2) % 32 == 0 : true)) {
             // ... and for the staged split-bf16 kernel (every dense conv with a multiple of 32 input channels)
@@ -390,12 +394,13 @@ void Engine::open_device(int device) {
         if (!strcmp(mm, "bf16x3")) math_ = MATH_BF16X3;
         else if (!strcmp(mm, "f32")) math_ = MATH_F32;
         else if (!strcmp(mm, "bf16w")) math_ = MATH_BF16W;
-        else throw EngineError(MI355VITS_ERR_INVALID, std::string("MI355VITS_MATH: unknown mode '") + mm + "' (f32 | bf16x3 | bf16w)");
+        else if (!strcmp(mm, "f16x2")) math_ = MATH_F16X2;
+        else throw EngineError(MI355VITS_ERR_INVALID, std::string("MI355VITS_MATH: unknown mode '") + mm + "' (f32 | bf16x3 | bf16w | f16x2)");
     }
 }
 
 void Engine::set_math(int mode) {
-    if (mode != MATH_F32 && mode != MATH_BF16X3 && mode != MATH_BF16W) throw EngineError(MI355VITS_ERR_INVALID, "unknown math mode");
+    if (mode != MATH_F32 && mode != MATH_BF16X3 && mode != MATH_BF16W && mode != MATH_F16X2) throw EngineError(MI355VITS_ERR_INVALID, "unknown math mode");
     math_ = mode;
 }
 
@@ -606,10 +611,10 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
         // split-bf16 staged kernel where it pays: convs with little work per staged chunk (1x1 convs, the last
         // upsampler: K * Cin < 256) spend more on splitting the chunk than the faster matrix-core loop saves
         // (measured: flow.pre / post, res_skip, upsample 64 -> 32); MI355VITS_B3_MIN_WORK overrides the threshold (tests)
-        if (math_on_bf16(math_) && w.packed_b3s != NO_OFF &&
+        if (math_on_bf16(kmath()) && w.packed_b3s != NO_OFF &&
             (math_on_bf16(a.math) || ((w.K * w.Cin >= b3_min_work_ || (a.shuf_s && w.Cin % 64 == 0)) && a.epi == EPI_STD))) {
             a.wb3 = P(w.packed_b3s);
-            a.math = math_;
+            a.math = kmath();
         } else {
             a.math = MATH_F32;
         }
@@ -883,9 +888,9 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             // through HBM: 38 MB per layer, nothing next to the matrix-core time saved); the fused kernel is f32-MFMA
             // in-layer + res/skip through the staged split-bf16 kernel instead of the fused f32 layer: measured 2.09 + 1.70 ms
             // vs 3.65 ms per step — no gain (small grids, scalar res/skip epilogue); opt-in for A/B and for the tests
-            const bool wn_b3 = wn_b3_ && math_on_bf16(math_) && win.packed_b3s != NO_OFF && wrs.packed_b3s != NO_OFF &&
+            const bool wn_b3 = wn_b3_ && math_on_bf16(kmath()) && win.packed_b3s != NO_OFF && wrs.packed_b3s != NO_OFF &&
                                conv1d_b3_supported(win.Cin, win.Cout, win.K, dil, Ty) && !force_generic_;
-            if (!force_generic_ && !no_fused_wn_ && !wn_b3 && math_on_bf16(math_) && win.packed_b3w != NO_OFF &&
+            if (!force_generic_ && !no_fused_wn_ && !wn_b3 && math_on_bf16(kmath()) && win.packed_b3w != NO_OFF &&
                 wrs.packed_b3s != NO_OFF && wn_layer_b3_supported(H, win.K, dil)) {
                 // fused layer on the bf16 matrix cores.  Chosen by the layer shape alone (never by the grid size), so a
                 // row's bits do not depend on what it is batched with.
@@ -897,7 +902,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 w.cond = cond_l; w.cond_bs = 2L * H * c.flow_wn_layers;
                 w.len = d_ylen_;
                 w.B = B; w.H = H; w.T = Ty; w.K = win.K; w.dil = dil; w.Crs = wrs.Cout; w.skip_init = (l == 0);
-                w.math = math_;
+                w.math = kmath();
                 const double fl = 2.0 * B * (double)Ty * H * ((double)win.Cout * win.K + wrs.Cout);
                 ProfScope ps(prof_, "flow.wn_layer_b3", fl, 4.0 * B * (double)Ty * H * 4);
                 launch_wn_layer_b3(w, stream_);
@@ -928,7 +933,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 in.cond_bs = 2L * H * c.flow_wn_layers;
             }
             in.B = B; in.T = Ty;
-            if (wn_b3) in.math = math_;
+            if (wn_b3) in.math = kmath();
             conv("flow.in_gate", win, in);
             ConvArgs rs;
             rs.x = d_fu_; rs.x_bs = hbs; rs.x_ld = Ty;
@@ -937,7 +942,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
             rs.epi = EPI_RESSKIP; rs.H = H; rs.skip_init = (l == 0);
             rs.out_len = d_ylen_;
             rs.B = B; rs.T = Ty;
-            if (wn_b3) rs.math = math_;
+            if (wn_b3) rs.math = kmath();
             conv("flow.res_skip", wrs, rs);
         }
         ConvArgs post;
@@ -1035,14 +1040,18 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 while (p > 0 && !(mrf_fused_supported(ch, p, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF)) --p;
                 if (p > 0) {
                     double flops = 0;
-                    bool b3 = math_on_bf16(math_);
+                    bool b3 = math_on_bf16(kmath());
+                    bool h2 = math_ == MATH_F16X2;
                     for (int j = 0; j < p; ++j)
-                        for (int q = 0; q < 2; ++q) b3 = b3 && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3 != NO_OFF;
-                    m.math = b3 ? math_ : MATH_F32;
+                        for (int q = 0; q < 2; ++q) {
+                            b3 = b3 && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3 != NO_OFF;
+                            h2 = h2 && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_h2 != NO_OFF;
+                        }
+                    m.math = h2 ? (int)MATH_F16X2 : (b3 ? kmath() : (int)MATH_F32);
                     for (int j = 0; j < p; ++j) {
                         for (int q = 0; q < 2; ++q) {
                             const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
-                            m.w[j][q] = P(b3 ? w.packed_b3 : w.packed4);
+                            m.w[j][q] = P(h2 ? w.packed_h2 : (b3 ? w.packed_b3 : w.packed4));
                             m.bias[j][q] = P(w.bias);
                         }
                         flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];
@@ -1055,7 +1064,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     // last stage, whole MRF in the kernel: conv_post + tanh + peak ride along (the stage output is never
                     // written; with debug taps on it is, through the separate kernel)
                     double bytes = 8.0 * B * (double)T * ch;
-                    if (i == c.n_upsamples - 1 && p == nk && !taps_on_ && !no_post_fusion_ && mrf_fused_post_supported(ch, p, m.k, m.d1, m.d2)) {
+                    if (i == c.n_upsamples - 1 && p == nk && !taps_on_ && !no_post_fusion_ && m.math != MATH_F16X2 && mrf_fused_post_supported(ch, p, m.k, m.d1, m.d2)) {
                         m.post_w = vec("dec.conv_post.weight");
                         m.audio = d_audio_; m.audio_bs = T;
                         m.audio_len = d_alen_;

@@ -94,6 +94,7 @@ struct ConvW {
     size_t packed_b3 = NO_OFF;  // three bf16 planes in bf16-MFMA fragment order (pack_conv_weights_bf16x3), 32-bit words
     size_t packed_b3s = NO_OFF; // the same for the staged split-bf16 conv kernel (layout 1, this conv's tile map)
     size_t packed_b3w = NO_OFF; // WaveNet in-layer convs: layout 1 in plain row order (fused split-bf16 layer kernel)
+    size_t packed_h2 = NO_OFF;    // fused-MRF convs: two fp16 planes, weights x 2^13 (MATH_F16X2), when every |w| < 7.99
     size_t bias = NO_OFF;
     int Cout = 0, Cin = 0, K = 1;
     int epi = EPI_STD;  // tile map the packed copy was built for
@@ -168,6 +169,7 @@ class Engine {
     int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
     bool no_fused_dds_ = false;  // MI355VITS_NO_FUSED_DDS=1: DDS layers as three launches (A/B + fallback)
     bool no_post_fusion_ = true;   // MI355VITS_POST_FUSION=1 (opt-in): conv_post + tanh + peak inside the last MRF stage's kernel
+    int kmath() const { return math_ == MATH_F16X2 ? (int)MATH_BF16X3 : math_; }  // F16X2 covers the fused MRF stages only
     bool enc_b3_ = true;           // the encoder's wide FFN conv on the split-bf16 staged kernel (MI355VITS_NO_ENC_B3=1: f32 kernel)
     bool no_mrf_b3_ = false;     // MATH_BF16X3: keep the on-the-fly split MRF kernel (A/B against the pre-split one)
     bool wn_b3_ = false;         // MATH_BF16X3: WaveNet layers as two staged split-bf16 convs instead of the fused f32 layer

@@ -13,6 +13,7 @@ typedef hipemu_f32x4 f32x4;
 #define MFMA_32x32x2_F32(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
 #define MFMA_16x16x4_F32(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
 #define MFMA_32x32x16_BF16(a, b, c) hipemu_mfma_32x32x16_bf16((a), (b), (c))
+#define MFMA_32x32x16_F16(a, b, c) hipemu_mfma_32x32x16_f16((a), (b), (c))
 #define CVT_PK_BF16_F32(lo, hi) hipemu_cvt_pk_bf16_f32((lo), (hi))
 #define LAUNCH_KERNEL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((kernel), (grid), (block), (size_t)(shmem), __VA_ARGS__)
@@ -36,6 +37,10 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 #define MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), (c), 0, 0, 0)
+// v_mfma_f32_32x32x16_f16: the same shape and rate with eight IEEE halves per lane
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8_t as_f16x8(const uint4& v) { return __builtin_bit_cast(f16x8_t, v); }
+#define MFMA_32x32x16_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a), as_f16x8(b), (c), 0, 0, 0)
 // v_cvt_pk_bf16_f32: two f32 -> two bf16 (round to nearest even) in one register, `lo` in bits [15:0]
 __device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
     f32x2_t v = {lo, hi};
@@ -177,7 +182,7 @@ __device__ __forceinline__ float f4c(const float4& v, int q) { return q == 0 ? v
 // four-way bank conflict per store).  U items per thread and batch: 4 U loads in flight.  rows % 8 == 0.
 template <int NTH, int U = 5>
 __device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,
-                                              float slope, float* __restrict__ dst, int vec) {
+                                              float slope, float* __restrict__ dst, int vec, float scale = 1.0f) {
     (void)vec;
     const int n = (rows >> 2) * LD;
     const int last = tend > 0 ? tend - 1 : 0;
@@ -202,8 +207,8 @@ __device__ __forceinline__ void stage_tile_pk(const float* __restrict__ xb, long
             const int gb = idx / LD, col = idx - gb * LD;
             const int tt = ts + col;
             const bool in = tt >= 0 && tt < tend;
-            reinterpret_cast<float4*>(dst)[idx] = in ? make_float4(lrelu_f(v[u][0], slope), lrelu_f(v[u][1], slope), lrelu_f(v[u][2], slope),
-                                                                   lrelu_f(v[u][3], slope))
+            reinterpret_cast<float4*>(dst)[idx] = in ? make_float4(lrelu_f(v[u][0], slope) * scale, lrelu_f(v[u][1], slope) * scale,
+                                                                   lrelu_f(v[u][2], slope) * scale, lrelu_f(v[u][3], slope) * scale)
                                                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             (void)gb;
         }
@@ -251,6 +256,32 @@ __device__ __forceinline__ void split3_pk(float a0, float a1, unsigned& h, unsig
     l = pack_hi16(__float_as_uint(q.x), __float_as_uint(q.y));
 #endif
 }
+// ---- MATH_F16X2: two fp16 terms per operand (11 + 11 significant bits), x ~ h + m with |x - h - m| <= 2^-22 |x| while both
+// terms are normal halves.  Round-toward-zero conversions (v_cvt_pkrtz_f16_f32: a pair per instruction, saturating, so
+// an out-of-range value stays finite); x - float(h) is exact.  5 VALU per pair (9 for the three-term bf16 split).
+__device__ __forceinline__ void split2_pk(float a0, float a1, unsigned& h, unsigned& m) {
+#ifdef MI355_EMU
+    const unsigned h0 = hipemu_f32_to_f16_rtz(a0), h1 = hipemu_f32_to_f16_rtz(a1);
+    h = h0 | (h1 << 16);
+    const float r0 = a0 - hipemu_f16_to_f32(h0), r1 = a1 - hipemu_f16_to_f32(h1);
+    m = hipemu_f32_to_f16_rtz(r0) | (hipemu_f32_to_f16_rtz(r1) << 16);
+#else
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const auto hv = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+    h = __builtin_bit_cast(unsigned, hv);
+    const v2f a = {a0, a1};
+    const v2f hf = {(float)hv[0], (float)hv[1]};
+    const v2f r = a - hf;
+    m = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r.x, r.y));
+#endif
+}
+__device__ __forceinline__ void split2_x8(const float4& lo4, const float4& hi4, uint4& h, uint4& m) {
+    split2_pk(lo4.x, lo4.y, h.x, m.x);
+    split2_pk(lo4.z, lo4.w, h.y, m.y);
+    split2_pk(hi4.x, hi4.y, h.z, m.z);
+    split2_pk(hi4.z, hi4.w, h.w, m.w);
+}
+
 // eight k-slots of one lane (two packed-tile float4: channels 16G + brow + 2e | 16G + 8 + brow + 2e) -> three planes
 __device__ __forceinline__ void split3_x8(const float4& lo4, const float4& hi4, uint4& h, uint4& m, uint4& l) {
     split3_pk(lo4.x, lo4.y, h.x, m.x, l.x);

@@ -11,6 +11,7 @@
 //                       work (bias, speaker conditioning, relu, residual, WaveNet gate, res/skip update,
 //                       coupling subtract, masks, MRF mean) is fused into the epilogue.
 //   * k_conv1d_generic — plain VALU/LDS tiled kernel for any shape; reference for tests and A/B.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -545,6 +546,74 @@ void pack_conv_weights_bf16x3_mode(const float* w, int Cout, int Cin, int K, int
                         for (int j = 0; j < 4; ++j) o[j] = plane[p][2 * j] | (plane[p][2 * j + 1] << 16);
                     }
                 }
+}
+
+// IEEE half bits of a float, round to nearest even (host-side weight packing of MATH_F16X2)
+static inline uint32_t f16_rne_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, ax = u & 0x7fffffffu;
+    if (ax > 0x7f800000u) return sign | 0x7e00u;
+    if (ax >= 0x477ff000u) return sign | 0x7c00u;  // rounds to infinity (callers keep |w| far below)
+    const int e = (int)(ax >> 23) - 127;
+    if (e < -25) return sign;
+    if (e >= -14) {
+        uint32_t r = ax + 0xfffu + ((ax >> 13) & 1u);  // round the 13 dropped bits to nearest even
+        return sign | (((r >> 23) - 112) << 10) | ((r >> 13) & 0x3ffu);
+    }
+    // subnormal half: unit 2^-24
+    const double v = (double)f < 0 ? -(double)f : (double)f;
+    const double q = v * 16777216.0;
+    uint32_t n = (uint32_t)q;
+    const double frac = q - n;
+    if (frac > 0.5 || (frac == 0.5 && (n & 1))) ++n;
+    return sign | n;  // n == 1024 is the smallest normal: the bit pattern is right as it is
+}
+static inline float f16_bits_to_float(uint32_t h) {
+    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    float f;
+    if (e == 0) {
+        f = (float)m * 5.9604644775390625e-08f;
+        memcpy(&u, &f, 4);
+        u |= sign;
+    } else if (e == 31) {
+        u = sign | 0x7f800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112) << 23) | (m << 13);
+    }
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+size_t f16x2_packed_words(int Cout, int Cin, int K) { return (size_t)(Cout / 32) * K * (Cin / 16) * 2 * 64 * 4; }
+
+// MATH_F16X2 fragments of the fused MRF stage: [tile][tap][16-channel group][plane h | m][lane] x 16 B, k-slot order of
+// layout 0 (the packed f32 activation tiles), weights scaled by 2^13 first (exact), h = half(w'), m = half(w' - h).
+bool pack_conv_weights_f16x2(const float* w, int Cout, int Cin, int K, uint32_t* out) {
+    const size_t n = (size_t)Cout * Cin * K;
+    for (size_t i = 0; i < n; ++i)
+        if (!(std::fabs(w[i]) < 7.99f)) return false;
+    const int ng = Cin / 16, nt = Cout / 32;
+    for (int tile = 0; tile < nt; ++tile)
+        for (int k = 0; k < K; ++k)
+            for (int g = 0; g < ng; ++g)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = 32 * tile + (l & 31), half = l >> 5;
+                    uint32_t plane[2][8];
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 16 * g + b3_slot_channel(0, half, e);
+                        const float v = w[((size_t)co * Cin + ci) * K + k] * F16X2_W_SCALE;
+                        const uint32_t h = f16_rne_bits(v);
+                        plane[0][e] = h;
+                        plane[1][e] = f16_rne_bits(v - f16_bits_to_float(h));
+                    }
+                    for (int p = 0; p < 2; ++p) {
+                        uint32_t* o = out + (((((size_t)tile * K + k) * ng + g) * 2 + p) * 64 + l) * 4;
+                        for (int j = 0; j < 4; ++j) o[j] = plane[p][2 * j] | (plane[p][2 * j + 1] << 16);
+                    }
+                }
+    return true;
 }
 
 void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out) {

@@ -132,11 +132,63 @@ __device__ __forceinline__ void mfma_conv_tiles_b3(f32x16 (&acc)[NA], const uint
     }
 }
 
+// MATH_F16X2: the same share of a conv with both operands as two fp16 terms (hipx.h: split2) and three products on
+// v_mfma_f32_32x32x16_f16.  Weight fragments: [tile][tap][16-ch group][plane h | m][lane] x 16 B (pack_conv_weights_f16x2),
+// pre-scaled by 2^13; the activation tiles hold values pre-scaled by 2^4 — the accumulators live scaled by 2^17.
+template <int NTL, int NA, int CP>
+__device__ __forceinline__ void mfma_conv_tiles_h2(f32x16 (&acc)[NA], const uint4* __restrict__ wp, const float4* __restrict__ x4,
+                                                   int tstride, int LD, int K, int dil, int ablate) {
+    static_assert(NTL <= NA, "tile count");
+    static_assert(CP % 16 == 0, "channel pairs per tap must be a multiple of 16");
+    if (ablate & 1) return;
+    constexpr int NG = CP / 8;  // 16-channel groups per tap (even)
+    uint4 ra[2][2];
+    MI355_UNROLL
+    for (int p = 0; p < 2; ++p) ra[0][p] = wp[p * 64];
+    float4 xb[2][NTL][2];
+    MI355_UNROLL
+    for (int i = 0; i < NTL; ++i) {
+        xb[0][i][0] = x4[i * tstride];
+        xb[0][i][1] = x4[i * tstride + 2 * LD];
+    }
+    for (int k = 0; k < K; ++k) {
+        const uint4* wk = wp + (long)k * NG * 128;
+        const float4* xk = x4 + k * dil;
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            const uint4* wa = (last_tap && g + 1 >= NG) ? wk + g * 128 : wk + (g + 1) * 128;
+            MI355_UNROLL
+            for (int p = 0; p < 2; ++p) ra[(g + 1) & 1][p] = wa[p * 64];
+            const float4* xn = (g + 1 < NG) ? xk + (g + 1) * 4 * LD : (last_tap ? xk + g * 4 * LD : xk + dil);
+            MI355_UNROLL
+            for (int i = 0; i < NTL; ++i) {
+                xb[(g + 1) & 1][i][0] = xn[i * tstride];
+                xb[(g + 1) & 1][i][1] = xn[i * tstride + 2 * LD];
+            }
+            SCHED_FENCE();
+            const uint4 ah = ra[g & 1][0], am = ra[g & 1][1];
+            MI355_UNROLL
+            for (int i = 0; i < NTL; ++i) {
+                uint4 bh, bm;
+                split2_x8(xb[g & 1][i][0], xb[g & 1][i][1], bh, bm);
+                acc[i] = MFMA_32x32x16_F16(am, bh, acc[i]);  // small terms first
+                acc[i] = MFMA_32x32x16_F16(ah, bm, acc[i]);
+                acc[i] = MFMA_32x32x16_F16(ah, bh, acc[i]);
+            }
+            SCHED_FENCE();
+        }
+    }
+}
+
 // weight fragments of row tile `wm` of a conv, lane offset included, and the matching inner loop
 template <int MATH, int NTL, int NA, int CP>
 __device__ __forceinline__ void conv_tiles(f32x16 (&acc)[NA], const float* __restrict__ w, int wm, int lane, const float4* __restrict__ x4,
                                            int tstride, int LD, int K, int dil, int ablate) {
-    if constexpr (MATH == 1 || MATH == 2) {
+    if constexpr (MATH == 3) {
+        const uint4* wp = reinterpret_cast<const uint4*>(w) + (long)wm * K * (CP / 8) * 128 + lane;
+        mfma_conv_tiles_h2<NTL, NA, CP>(acc, wp, x4, tstride, LD, K, dil, ablate);
+    } else if constexpr (MATH == 1 || MATH == 2) {
         const uint4* wp = reinterpret_cast<const uint4*>(w) + (long)wm * K * (CP / 8) * 192 + lane;
         mfma_conv_tiles_b3<NTL, NA, CP, MATH == 2>(acc, wp, x4, tstride, LD, K, dil, ablate);
     } else {
@@ -160,11 +212,18 @@ __device__ __forceinline__ void mrf_conv1_compute(f32x16 (&acc)[NA], const float
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            acc[i][r] = unlrelu(X[pk(co, (R - r2) + e, LDX)]) + bs[co];
+            if constexpr (MATH == 3) acc[i][r] = (unlrelu(X[pk(co, (R - r2) + e, LDX)]) * (1.0f / F16X2_X_SCALE) + bs[co]) * F16X2_ACC_SCALE;
+            else acc[i][r] = unlrelu(X[pk(co, (R - r2) + e, LDX)]) + bs[co];
         }
     }
     const float4* xw = reinterpret_cast<const float4*>(X) + brow * LDX + (R - r2 - r1) + bcol + wt * 32;
     conv_tiles<MATH, NTL, NA, CP>(acc, w, wm, brow * 32 + bcol, xw, WT * 32, LDX, K, d1, ablate);
+    if constexpr (MATH == 3) {  // back to the unscaled domain (exact): the epilogue is the same for every mode
+        MI355_UNROLL
+        for (int i = 0; i < NTL; ++i)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][r] *= 1.0f / F16X2_ACC_SCALE;
+    }
 }
 
 // conv2 for a wave that owns NTL output tiles p = wt + WT*i:  out += x1 + bias + conv(lrelu(x1)), accumulated
@@ -178,7 +237,8 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-            out[i][r] += unlrelu(X1[pk(co, c0 + r2, LD1)]) + bs[co];
+            if constexpr (MATH == 3) out[i][r] += (unlrelu(X1[pk(co, c0 + r2, LD1)]) * (1.0f / F16X2_X_SCALE) + bs[co]) * F16X2_ACC_SCALE;
+            else out[i][r] += unlrelu(X1[pk(co, c0 + r2, LD1)]) + bs[co];
         }
     }
     const float4* xw = reinterpret_cast<const float4*>(X1) + brow * LD1 + bcol + wt * 32;
@@ -201,6 +261,9 @@ template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C
 __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 8, "8 waves per workgroup");
     static_assert(!POST || WM == 1, "conv_post is fused behind the 32-channel stage only");
+    static_assert(!POST || MATH != 3, "MATH_F16X2 keeps its output accumulators scaled: no conv_post fusion");
+    constexpr float XS = MATH == 3 ? F16X2_X_SCALE : 1.0f;          // scale of the values kept in the LDS tiles
+    constexpr float OUT_UNSCALE = MATH == 3 ? 1.0f / F16X2_ACC_SCALE : 1.0f;
     static_assert(NT1MAX == 3 && NT2MAX == 2, "static dispatch below");
     constexpr int C = 32 * WM;
     constexpr int T_B = 32 * N2;
@@ -229,7 +292,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     if constexpr (POST) {
         if (tid < C * 8) PW[tid] = (tid & 7) < MRF_POST_K ? a.post_w[(tid >> 3) * MRF_POST_K + (tid & 7)] : 0.0f;
     }
-    if (!(a.ablate & 2)) stage_tile_pk<512>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec);
+    if (!(a.ablate & 2)) stage_tile_pk<512>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec, XS);
     __syncthreads();
 
     f32x16 out[NT2MAX];
@@ -268,7 +331,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                    X1[pk(co, e, LD1)] = live ? fmaxf(acc1[i][r], 0.1f * acc1[i][r]) : 0.0f;
+                    X1[pk(co, e, LD1)] = live ? fmaxf(acc1[i][r], 0.1f * acc1[i][r]) * XS : 0.0f;
                 }
             }
         }
@@ -358,8 +421,10 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
             if (i < nt2 && t < a.T && !(a.ablate & 4)) {
                 float* yp = a.y + (long)b * a.y_bs + (long)(wm * 32 + 4 * brow) * a.y_ld + t;
                 MI355_UNROLL
-                for (int r = 0; r < 16; ++r)
-                    yp[(long)((r & 3) + 8 * (r >> 2)) * a.y_ld] = decltype(MEAN)::value ? out[i][r] / n : out[i][r] * a.out_scale;
+                for (int r = 0; r < 16; ++r) {
+                    const float o = out[i][r] * OUT_UNSCALE;  // exact
+                    yp[(long)((r & 3) + 8 * (r >> 2)) * a.y_ld] = decltype(MEAN)::value ? o / n : o * a.out_scale;
+                }
             }
         }
     };
@@ -442,6 +507,19 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
         } else {
             if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 0, true>);
             else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 0, true>);
+        }
+        return;
+    }
+    if (a.math == MATH_F16X2) {
+        if (a.C == 32) {
+            if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 3>);
+            else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 3>);
+        } else if (a.C == 128) {
+            if (a.ldx == 160 && a.ld1 == 128) go(k_mrf_fused<4, 2, 3, 3, 2, 160, 128, 3>);
+            else go(k_mrf_fused<4, 2, 3, 3, 2, 0, 0, 3>);
+        } else {
+            if (a.ldx == 320 && a.ld1 == 288) go(k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 3>);
+            else go(k_mrf_fused<2, 4, 6, 3, 2, 0, 0, 3>);
         }
         return;
     }

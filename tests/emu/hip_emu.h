@@ -488,6 +488,63 @@ static inline unsigned hipemu_cvt_pk_bf16_f32(float lo, float hi) { return hipem
 // v_mfma_f32_32x32x16_bf16: lane l holds row (A) / column (B) l & 31 and the eight k-slots of half l >> 5 (slot e in
 // bits [16 (e & 1) ...] of register e >> 1); C/D as the f32 32x32 form.  Products are exact; the sixteen of them are
 // summed in double and added to c with one rounding (the hardware's internal order is unspecified; tests are toleranced).
+// IEEE half <-> float in software (the f16 MFMA and v_cvt_pkrtz_f16_f32 of MATH_F16X2): round toward zero, saturating
+static inline unsigned hipemu_f32_to_f16_rtz(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const unsigned ax = u & 0x7fffffffu;
+    if (ax > 0x7f800000u) return sign | 0x7e00u;                 // NaN
+    if (ax >= 0x477fe000u) return sign | (ax == 0x7f800000u ? 0x7c00u : 0x7bffu);  // >= 65504: inf stays inf, the rest saturates
+    const int e = (int)(ax >> 23) - 127;
+    if (e >= -14) return sign | (unsigned)(((e + 15) << 10) | ((ax >> 13) & 0x3ffu));  // normal: drop 13 mantissa bits
+    if (e < -24) return sign;                                    // below the smallest subnormal
+    const unsigned mant = (ax & 0x7fffffu) | 0x800000u;          // subnormal: value = mant * 2^(e - 23), unit 2^-24
+    return sign | (mant >> (-e - 1));
+}
+static inline float hipemu_f16_to_f32(unsigned h) {
+    const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    unsigned u;
+    if (e == 0) {
+        const float v = (float)m * 5.9604644775390625e-08f;  // 2^-24
+        memcpy(&u, &v, 4);
+        u |= sign;
+    } else if (e == 31) {
+        u = sign | 0x7f800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(uint4 a, uint4 b, hipemu_f32x16 c) {
+    hipemu::Worker* w = hipemu::tl_worker;
+    hipemu::Fiber* f = w->cur;
+    const int wave = f->lin / 64, lane = f->lin % 64;
+    const int slot = (f->wave_ops++) & 1;
+    const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 4; ++j) {
+        w->mfma_a16[wave][slot][lane][j] = av[j];
+        w->mfma_b16[wave][slot][lane][j] = bv[j];
+    }
+    hipemu::wave_sync();
+    const int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        double d = 0.0;
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) {
+                const unsigned ua = w->mfma_a16[wave][slot][row + 32 * h][e >> 1], ub = w->mfma_b16[wave][slot][col + 32 * h][e >> 1];
+                const float fa = hipemu_f16_to_f32((e & 1) ? (ua >> 16) : (ua & 0xffffu));
+                const float fb = hipemu_f16_to_f32((e & 1) ? (ub >> 16) : (ub & 0xffffu));
+                d += (double)fa * (double)fb;
+            }
+        c[r] = (float)((double)c[r] + d);
+    }
+    return c;
+}
+
 static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(uint4 a, uint4 b, hipemu_f32x16 c) {
     hipemu::Worker* w = hipemu::tl_worker;
     hipemu::Fiber* f = w->cur;

@@ -565,6 +565,32 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
     assert np.array_equal(by_nt["1"], by_nt["3"])
 
 
+def test_f16x2_mode_fused_mrf_stages(emu_lib):
+    """MATH_F16X2 (experimental): the fused MRF stages with both operands split into two fp16 terms (power-of-two pre-scaled,
+    three products on the f16 MFMA, accumulators kept scaled by 2^17 and unscaled exactly).  Decoder stage taps and the
+    waveform vs the oracle at the default tolerances, ragged batch over several workgroups, batched == unbatched bitwise;
+    within f32 rounding of the bf16x3 path (and not identical to it: the mode really switches kernels)."""
+    cfg = VitsConfig.tiny_wide()
+    w = W.synthetic_weights(cfg, seed=83, frames_per_id=2.0)
+    eng = Engine(W.pack(cfg, w), library=emu_lib)
+    eng.set_math("f16x2")
+    assert eng.math == "f16x2"
+    Tx = 40
+    forced = np.full((3, Tx), 3, np.int32)
+    ids = np.random.default_rng(9).integers(1, cfg.num_symbols, (3, Tx))
+    lengths = np.array([Tx, Tx - 11, 4])
+    out, _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=83, weights=w, engine=eng)
+    one = eng.run(ids[1:2], lengths[1:2], (0.667, 1.0, 0.8), forced_durations=forced[1:2], seed=83, utterance_base=1)
+    full = eng.run(ids, lengths, (0.667, 1.0, 0.8), forced_durations=forced, seed=83)
+    L = int(one["lengths"][0])
+    assert np.array_equal(full["audio"][1, :L], one["audio"][0, :L])
+    eng.set_math("bf16x3")
+    ref = eng.run(ids, lengths, (0.667, 1.0, 0.8), forced_durations=forced, seed=83)
+    assert not np.array_equal(ref["audio"], full["audio"])
+    assert rel_rms(full["audio"][0, : int(full["lengths"][0])], ref["audio"][0, : int(ref["lengths"][0])]) < 2e-5
+    eng.close()
+
+
 def test_bf16_weights_mode_separate_tolerance(emu_lib):
     """MATH_BF16W (BASELINE configs[4] "bf16 weights"): weights rounded to bf16 (their leading split term only), activations
     exact, f32 accumulate — a reduced-precision variant with its own tolerance (rel. RMS <= 2e-2 vs the f32 oracle), and

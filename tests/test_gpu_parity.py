@@ -342,6 +342,23 @@ def test_split_bf16_staged_conv_kernel_vs_fp64(gpu_lib, case):
     assert err[2] < 2e-6 and err[2] <= 1.25 * err[1] + 2e-8, err
 
 
+def test_f16x2_mode_bench_workload_matches_oracle(gpu_lib):
+    """MATH_F16X2 (experimental: fused MRF stages on two-term fp16 operands) at the benchmarked shape, every decoder stage
+    tapped, default tolerances; and batched == unbatched bitwise."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234, frames_per_id=6.0)
+    eng = Engine(W.pack(cfg, w))
+    eng.set_math("f16x2")
+    B, Tx = 32, 128
+    ids = np.stack([np.random.default_rng(1234 + b).integers(1, 50, Tx) for b in range(B)]).astype(np.int64)
+    forced = np.full((B, Tx), 6, np.int32)
+    out, _ = check_parity(gpu_lib, cfg, ids=ids, forced=forced, noise=True, seed=1234, weights=w, engine=eng, stage_rows=(0, 31))
+    one = eng.run(ids[7:8], np.array([Tx]), [0.667, 1.0, 0.8], forced_durations=forced[7:8], seed=5, utterance_base=7)
+    full = eng.run(ids, np.full(B, Tx), [0.667, 1.0, 0.8], forced_durations=forced, seed=5)
+    assert np.array_equal(full["audio"][7], one["audio"][0])
+    eng.close()
+
+
 def test_bf16_weights_mode_at_its_own_tolerance(gpu_lib):
     """BASELINE.json configs[4] first slice: MATH_BF16W — bf16-rounded weights (leading split term), exact f32 activations,
     f32 accumulate on v_mfma_f32_32x32x16_bf16 — on the full-size apope_low graph, bench-shaped rows.  Reduced precision:
