@@ -151,8 +151,9 @@ def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32"):
     traffic = _pmc_traffic(dom["kernel"], workload_key, voice)
     # the roof of the dominant kernel: kernels named *_b3 / running in MATH_BF16X3 execute six bf16 MFMA products per
     # algorithmic f32 multiply-add, so their matrix-core roof is 2500 / 6 TFLOP/s of ALGORITHMIC f32 work
-    on_bf16 = math == "bf16x3" and any(t in dom["kernel"] for t in ("mrf", "wn_layer_b3", "dec.rb", "upsample.s0", "upsample.s1", "conv_pre"))
-    peak = PEAK_BF16X3_TFLOPS if on_bf16 else PEAK_FP32_TFLOPS
+    on_bf16 = math in ("bf16x3", "f16x2") and any(t in dom["kernel"] for t in ("mrf", "wn_layer_b3", "dec.rb", "upsample.s0", "upsample.s1", "conv_pre"))
+    on_f16x2 = math == "f16x2" and "mrf_fused" in dom["kernel"]  # three f16 MFMA products per multiply-add (same MFMA rate)
+    peak = PEAK_BF16_TFLOPS / 3.0 if on_f16x2 else (PEAK_BF16X3_TFLOPS if on_bf16 else PEAK_FP32_TFLOPS)
     return {
         "kernel": dom["kernel"],
         "bound": "mfma",
@@ -160,8 +161,10 @@ def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32"):
         "peak": peak,
         "unit": "TFLOP/s",
         "frac": drec["flops"] / dsec / 1e12 / peak,
-        "matrix_core_path": ("v_mfma_f32_32x32x16_bf16 x 6 partial products per f32 multiply-add (operands split 3 x bf16, f32 "
-                             "accumulate): peak = 2500 TFLOP/s dense bf16 / 6") if on_bf16 else "v_mfma_f32_32x32x2_f32: peak = 157.3 TFLOP/s",
+        "matrix_core_path": ("v_mfma_f32_32x32x16_f16 x 3 partial products per multiply-add (operands as 2 x fp16 terms): peak = 2500 / 3 TFLOP/s"
+                             if on_f16x2 else
+                             ("v_mfma_f32_32x32x16_bf16 x 6 partial products per f32 multiply-add (operands split 3 x bf16, f32 "
+                              "accumulate): peak = 2500 TFLOP/s dense bf16 / 6") if on_bf16 else "v_mfma_f32_32x32x2_f32: peak = 157.3 TFLOP/s"),
         "frac_of_f32_mfma_peak": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
         "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
         "traffic_detail": traffic,
@@ -295,8 +298,11 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if math == "f32" else "f32 (dense convs: operands split exactly into 3 x bf16, 6 bf16-MFMA products per "
-                                             "multiply-add, f32 accumulate; f32 in / f32 out, parity at the f32 tolerances)",
+        "dtype": "f32" if math == "f32" else (
+            "f32 in / out / accumulate; MRF-stage operands as 2 x fp16 terms (22 significant bits, 3 f16-MFMA products per multiply-add), "
+            "the other dense convs as 3 x bf16 (exact, 6 products); experimental mode, parity at the f32 tolerances" if math == "f16x2" else
+            "f32 (dense convs: operands split exactly into 3 x bf16, 6 bf16-MFMA products per "
+            "multiply-add, f32 accumulate; f32 in / f32 out, parity at the f32 tolerances)"),
         "math": math,
         "data": f"synthetic (seeded random-init weights of the {args.voice} shapes, seeded phoneme ids)",
         "config": {
