@@ -59,6 +59,53 @@ __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NA], const uint4* con
     }
 }
 
+// MATH_F16X2 form of b3_chunk: two fp16 planes per operand (hipx.h: split2), three products on v_mfma_f32_32x32x16_f16.
+// A group of weight fragments is 128 uint4 (two planes x 64 lanes); the activation planes are [2][group][half][column].
+template <int MT, int NT, int NG, int NA = NT>
+__device__ __forceinline__ void h2_chunk(f32x16 (&acc)[MT][NA], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS, int LD, int K,
+                                         int groups_per_tap, int dil) {
+    uint4 ra[2][MT][2];
+    uint4 rb[2][NT][2];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int p = 0; p < 2; ++p) ra[0][i][p] = wp[i][p * 64];
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j)
+        MI355_UNROLL
+        for (int p = 0; p < 2; ++p) rb[0][j][p] = xq[p * PS + j * 32];
+    for (int k = 0; k < K; ++k) {
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            const bool wrap = g + 1 == NG;
+            const long woff = (wrap ? (last_tap ? (long)k * groups_per_tap + g : (long)(k + 1) * groups_per_tap) : (long)k * groups_per_tap + g + 1) * 128;
+            const int xoff = wrap ? (last_tap ? k * dil + g * 2 * LD : (k + 1) * dil) : k * dil + (g + 1) * 2 * LD;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int p = 0; p < 2; ++p) ra[nxt][i][p] = wp[i][woff + p * 64];
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j)
+                MI355_UNROLL
+                for (int p = 0; p < 2; ++p) rb[nxt][j][p] = xq[p * PS + xoff + j * 32];
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = MFMA_32x32x16_F16(ra[cur][i][1], rb[cur][j][0], c);  // small terms first
+                    c = MFMA_32x32x16_F16(ra[cur][i][0], rb[cur][j][1], c);
+                    c = MFMA_32x32x16_F16(ra[cur][i][0], rb[cur][j][0], c);
+                    acc[i][j] = c;
+                }
+            SCHED_FENCE();
+        }
+    }
+}
+
 // The same loop with the B operand single-buffered: column tile j's three plane fragments are refilled for the next
 // group right after the MFMAs of column tile j have issued (the other column tiles' MFMAs cover the LDS latency), so a
 // wave holds NT x 3 instead of 2 x NT x 3 B fragments: 36 VGPRs fewer at NT = 3, which is what lets eight waves (two
@@ -125,7 +172,8 @@ __device__ __forceinline__ void b3_chunk_lean(f32x16 (&acc)[MT][NT], const uint4
 // columns — 16-byte loads along time — stores 64 bytes apart from its neighbour: a four-way conflict on each of its
 // twelve stores, as expensive as the loop's ds_read_b128 traffic).  No alignment demands.  GB (group, half) rows are
 // loaded per batch = GB * 8 loads in flight per thread.
-template <int NG, int GB = 4>
+// F16 (MATH_F16X2): two fp16 planes of the value scaled by F16X2_X_SCALE instead of three bf16 planes.
+template <int NG, int GB = 4, bool F16 = false>
 __device__ __forceinline__ void stage_planes(const float* __restrict__ xb, long x_ld, int LD, int ts, int tend, float slope,
                                              uint4* __restrict__ planes, int PS, int tid, int nthreads) {
     static_assert((NG * 2) % GB == 0, "batches of GB (group, half) rows");
@@ -156,15 +204,27 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ xb, long 
             for (int u = 0; u < GB; ++u) {
                 MI355_UNROLL
                 for (int e = 0; e < 8; ++e) v[u][e] = in ? lrelu_f(v[u][e], slope) : 0.0f;
-                uint4 h, m, l;
-                split3_pk(v[u][0], v[u][1], h.x, m.x, l.x);
-                split3_pk(v[u][2], v[u][3], h.y, m.y, l.y);
-                split3_pk(v[u][4], v[u][5], h.z, m.z, l.z);
-                split3_pk(v[u][6], v[u][7], h.w, m.w, l.w);
                 const int o = (g0 + u) * LD + col;
-                planes[o] = h;
-                planes[PS + o] = m;
-                planes[2 * PS + o] = l;
+                if constexpr (F16) {
+                    MI355_UNROLL
+                    for (int e = 0; e < 8; ++e) v[u][e] *= F16X2_X_SCALE;
+                    uint4 h, m;
+                    split2_pk(v[u][0], v[u][1], h.x, m.x);
+                    split2_pk(v[u][2], v[u][3], h.y, m.y);
+                    split2_pk(v[u][4], v[u][5], h.z, m.z);
+                    split2_pk(v[u][6], v[u][7], h.w, m.w);
+                    planes[o] = h;
+                    planes[PS + o] = m;
+                } else {
+                    uint4 h, m, l;
+                    split3_pk(v[u][0], v[u][1], h.x, m.x, l.x);
+                    split3_pk(v[u][2], v[u][3], h.y, m.y, l.y);
+                    split3_pk(v[u][4], v[u][5], h.z, m.z, l.z);
+                    split3_pk(v[u][6], v[u][7], h.w, m.w, l.w);
+                    planes[o] = h;
+                    planes[PS + o] = m;
+                    planes[2 * PS + o] = l;
+                }
             }
         }
     }

@@ -241,6 +241,11 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
                 pack_conv_weights_bf16x3_mode(w.data(), Cout, Cin, K, EPI_STD, 1, bw.data());
                 c.packed_b3w = stage(reinterpret_cast<const float*>(bw.data()), bw.size());
             }
+            if (key.rfind("flow.", 0) == 0 && Cin % 16 == 0 && Cout % 32 == 0) {  // WaveNet layers in MATH_F16X2
+                std::vector<uint32_t> h2(f16x2_packed_words(Cout, Cin, K));
+                if (pack_conv_weights_f16x2(w.data(), Cout, Cin, K, h2.data(), 1))
+                    c.packed_h2s = stage(reinterpret_cast<const float*>(h2.data()), h2.size());
+            }
         }
     }
     return model_->convs[key] = c;
@@ -903,6 +908,11 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 w.len = d_ylen_;
                 w.B = B; w.H = H; w.T = Ty; w.K = win.K; w.dil = dil; w.Crs = wrs.Cout; w.skip_init = (l == 0);
                 w.math = kmath();
+                if (math_ == MATH_F16X2 && win.packed_h2s != NO_OFF && wrs.packed_h2s != NO_OFF) {  // two fp16 terms per operand
+                    w.w_in = P(win.packed_h2s);
+                    w.w_rs = P(wrs.packed_h2s);
+                    w.math = MATH_F16X2;
+                }
                 const double fl = 2.0 * B * (double)Ty * H * ((double)win.Cout * win.K + wrs.Cout);
                 ProfScope ps(prof_, "flow.wn_layer_b3", fl, 4.0 * B * (double)Ty * H * 4);
                 launch_wn_layer_b3(w, stream_);

@@ -59,7 +59,7 @@ void regroup_packed_x4(const float* packed, size_t n_floats, float* out);  // fu
 // v_mfma_f32_32x32x16_bf16: [Cout/32][K][Cin/16][plane h,m,l][64 lanes][8 bf16]; lane l = (half l >> 5, row l & 31)
 // holds the k-slots e < 4: channel 16G + half + 2e, e >= 4: 16G + 8 + half + 2(e - 4) — the channels a lane's two
 // ds_read_b128 of a packed activation tile deliver.  Needs Cin % 16 == 0 and Cout % 32 == 0; sizes in 32-bit words.
-// BF16W: BF16X3 with the weights' leading bf16 term only.  F16X2 (experimental, fused MRF stages only; every other kernel
+// BF16W: BF16X3 with the weights' leading bf16 term only.  F16X2 (experimental, fused MRF stages and fused WaveNet layers; every other kernel
 // runs as in BF16X3): operands split into two fp16 terms (22 significant bits), three products per multiply-add.
 enum MathMode { MATH_F32 = 0, MATH_BF16X3 = 1, MATH_BF16W = 2, MATH_F16X2 = 3 };
 inline bool math_on_bf16(int m) { return m == MATH_BF16X3 || m == MATH_BF16W; }
@@ -68,7 +68,7 @@ inline bool math_on_bf16(int m) { return m == MATH_BF16X3 || m == MATH_BF16W; }
 constexpr float F16X2_W_SCALE = 8192.0f, F16X2_X_SCALE = 16.0f, F16X2_ACC_SCALE = 131072.0f;
 size_t f16x2_packed_words(int Cout, int Cin, int K);
 // false (nothing written) when a weight is too large for the fixed scale
-bool pack_conv_weights_f16x2(const float* w, int Cout, int Cin, int K, uint32_t* out);
+bool pack_conv_weights_f16x2(const float* w, int Cout, int Cin, int K, uint32_t* out, int layout = 0);  // layout as for bf16x3
 size_t bf16x3_packed_words(int Cout, int Cin, int K);
 void pack_conv_weights_bf16x3(const float* w, int Cout, int Cin, int K, uint32_t* out);
 // general form: epi selects the tile -> output-channel map (EPI_GATE: tile pairs (c, H + c)), layout the k-slot ->

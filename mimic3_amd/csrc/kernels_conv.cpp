@@ -589,8 +589,9 @@ static inline float f16_bits_to_float(uint32_t h) {
 size_t f16x2_packed_words(int Cout, int Cin, int K) { return (size_t)(Cout / 32) * K * (Cin / 16) * 2 * 64 * 4; }
 
 // MATH_F16X2 fragments of the fused MRF stage: [tile][tap][16-channel group][plane h | m][lane] x 16 B, k-slot order of
-// layout 0 (the packed f32 activation tiles), weights scaled by 2^13 first (exact), h = half(w'), m = half(w' - h).
-bool pack_conv_weights_f16x2(const float* w, int Cout, int Cin, int K, uint32_t* out) {
+// layout 0 (the packed f32 activation tiles; 1 = the staged planes), weights scaled by 2^13 first (exact), h = half(w'),
+// m = half(w' - h); rows in plain order.
+bool pack_conv_weights_f16x2(const float* w, int Cout, int Cin, int K, uint32_t* out, int layout) {
     const size_t n = (size_t)Cout * Cin * K;
     for (size_t i = 0; i < n; ++i)
         if (!(std::fabs(w[i]) < 7.99f)) return false;
@@ -602,7 +603,7 @@ bool pack_conv_weights_f16x2(const float* w, int Cout, int Cin, int K, uint32_t*
                     const int co = 32 * tile + (l & 31), half = l >> 5;
                     uint32_t plane[2][8];
                     for (int e = 0; e < 8; ++e) {
-                        const int ci = 16 * g + b3_slot_channel(0, half, e);
+                        const int ci = 16 * g + b3_slot_channel(layout, half, e);
                         const float v = w[((size_t)co * Cin + ci) * K + k] * F16X2_W_SCALE;
                         const uint32_t h = f16_rne_bits(v);
                         plane[0][e] = h;

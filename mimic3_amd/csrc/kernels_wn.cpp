@@ -448,9 +448,15 @@ constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
 // element — chunk, tap, group and product order — is the same in both, so the results are bit-identical and the choice
 // may depend on the grid size.
 
-template <bool W1, int NT>
+// H2 (MATH_F16X2): operands as two fp16 planes (activations x 2^4 while they are split, weights x 2^13 when packed), three
+// products per multiply-add; the accumulators run scaled by 2^17 (bias and conditioning enter scaled) and are unscaled,
+// exactly, where they leave the matrix cores — the gate and the residual / skip updates see the same values as before.
+template <bool W1, int NT, bool H2 = false>
 __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
+    static_assert(!(W1 && H2), "one reduced-operand variant at a time");
     constexpr int H = WNB_H, T_B = 32 * NT, NG = WNB_NG;
+    constexpr int NP = H2 ? 2 : 3, GW = H2 ? 128 : 192;  // planes per operand; uint4 per weight-fragment group
+    constexpr float ACC = H2 ? F16X2_ACC_SCALE : 1.0f, UNACC = H2 ? 1.0f / F16X2_ACC_SCALE : 1.0f;
     DYN_SMEM(float, smem);
     uint4* planes = reinterpret_cast<uint4*>(smem);
     float* R = smem;  // [2H][T_B] raw in-layer result, later scratch of the epilogue
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     const int PS = NG * 2 * LD;    // uint4 per plane
     const bool two = a.Crs == 2 * H;
 
-    if (!(a.ablate & 2)) stage_planes<NG, NG>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, 256);  // 2 column sets x 12 rows: one round trip
+    if (!(a.ablate & 2)) stage_planes<NG, NG, H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, 256);  // 2 column sets x 12 rows: one round trip
     __syncthreads();
 
     // ---- in-layer conv: wave w owns row tiles w, w + 4, w + 8 (rows 32 q .. 32 q + 31 of the 2H), all 3 column tiles
@@ -484,13 +490,16 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                const float v = a.b_in[c] + cond_on * condp[c];  // unconditional loads: all 48 in flight together
+                const float v = (a.b_in[c] + cond_on * condp[c]) * ACC;  // unconditional loads: all 48 in flight together
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) acc[i][j][r] = v;
             }
-            wp[i] = reinterpret_cast<const uint4*>(a.w_in) + (long)q * a.K * NG * 192 + lane;
+            wp[i] = reinterpret_cast<const uint4*>(a.w_in) + (long)q * a.K * NG * GW + lane;
         }
-        if (!(a.ablate & 1)) b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+        if (!(a.ablate & 1)) {
+            if constexpr (H2) h2_chunk<3, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+            else b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+        }
         __syncthreads();  // every wave is done with the h planes: the raw result takes their place
         MI355_UNROLL
         for (int i = 0; i < 3; ++i)
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             for (int j = 0; j < NT; ++j)
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r)
-                    R[(32 * (w + 4 * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r];
+                    R[(32 * (w + 4 * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r] * UNACC;
     }
     __syncthreads();
     // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
@@ -524,14 +533,24 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     MI355_UNROLL
     for (int it = 0; it < ITEMS; ++it) {
         const int idx = tid + 256 * it;  // = gh * T_B + col
-        uint4 h4, m4, l4;
-        split3_pk(u[it][0], u[it][1], h4.x, m4.x, l4.x);
-        split3_pk(u[it][2], u[it][3], h4.y, m4.y, l4.y);
-        split3_pk(u[it][4], u[it][5], h4.z, m4.z, l4.z);
-        split3_pk(u[it][6], u[it][7], h4.w, m4.w, l4.w);
-        planes[idx] = h4;
-        planes[PSU + idx] = m4;
-        planes[2 * PSU + idx] = l4;
+        if constexpr (H2) {
+            uint4 h4, m4;
+            split2_pk(u[it][0] * F16X2_X_SCALE, u[it][1] * F16X2_X_SCALE, h4.x, m4.x);
+            split2_pk(u[it][2] * F16X2_X_SCALE, u[it][3] * F16X2_X_SCALE, h4.y, m4.y);
+            split2_pk(u[it][4] * F16X2_X_SCALE, u[it][5] * F16X2_X_SCALE, h4.z, m4.z);
+            split2_pk(u[it][6] * F16X2_X_SCALE, u[it][7] * F16X2_X_SCALE, h4.w, m4.w);
+            planes[idx] = h4;
+            planes[PSU + idx] = m4;
+        } else {
+            uint4 h4, m4, l4;
+            split3_pk(u[it][0], u[it][1], h4.x, m4.x, l4.x);
+            split3_pk(u[it][2], u[it][3], h4.y, m4.y, l4.y);
+            split3_pk(u[it][4], u[it][5], h4.z, m4.z, l4.z);
+            split3_pk(u[it][6], u[it][7], h4.w, m4.w, l4.w);
+            planes[idx] = h4;
+            planes[PSU + idx] = m4;
+            planes[2 * PSU + idx] = l4;
+        }
     }
     __syncthreads();
     // ---- res/skip 1x1 conv: Crs / 32 row tiles (12, last layer 6), tile q on wave q % 4
@@ -545,15 +564,16 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             if (q >= ntr) q = ntr - 1;  // beyond the last tile: recompute it, discarded below
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
-                const float v = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow];
+                const float v = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow] * ACC;
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) acc[i][j][r] = v;
             }
-            wp[i] = reinterpret_cast<const uint4*>(a.w_rs) + (long)q * NG * 192 + lane;
+            wp[i] = reinterpret_cast<const uint4*>(a.w_rs) + (long)q * NG * GW + lane;
         }
         if (!(a.ablate & 1)) {
             if (two) {
-                b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                if constexpr (H2) h2_chunk<3, NT, NG, NT>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                else b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
             } else {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
                 f32x16 a2[2][NT];
                 const uint4* w2[2] = {wp[0], wp[1]};
@@ -561,12 +581,21 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
                 for (int i = 0; i < 2; ++i)
                     MI355_UNROLL
                     for (int j = 0; j < NT; ++j) a2[i][j] = acc[i][j];
-                b3_chunk<2, NT, NG, NT, W1>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                if constexpr (H2) h2_chunk<2, NT, NG, NT>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                else b3_chunk<2, NT, NG, NT, W1>(a2, w2, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 MI355_UNROLL
                 for (int i = 0; i < 2; ++i)
                     MI355_UNROLL
                     for (int j = 0; j < NT; ++j) acc[i][j] = a2[i][j];
             }
+        }
+        if constexpr (H2) {  // back to the unscaled domain (exact)
+            MI355_UNROLL
+            for (int i = 0; i < 3; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j)
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= UNACC;
         }
     }
     if ((a.ablate & 4) && acc[0][0][0] != 1.2345f) return;
@@ -654,10 +683,12 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
     };
     if (nt == 1) {
-        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>);
+        if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 1, true>);
+        else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>);
         else go(k_wn_layer_b3<false, 1>);
     } else {
-        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3>);
+        if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 3, true>);
+        else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3>);
         else go(k_wn_layer_b3<false, 3>);
     }
 }

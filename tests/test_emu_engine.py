@@ -589,6 +589,20 @@ def test_f16x2_mode_fused_mrf_stages(emu_lib):
     assert not np.array_equal(ref["audio"], full["audio"])
     assert rel_rms(full["audio"][0, : int(full["lengths"][0])], ref["audio"][0, : int(ref["lengths"][0])]) < 2e-5
     eng.close()
+    # ... and the fused WaveNet layers (H = 192) in the same mode: flow output z and waveform vs the oracle, speaker conditioning
+    cfg = VitsConfig.tiny_h192(n_speakers=3)
+    w = W.synthetic_weights(cfg, seed=71, frames_per_id=2.0)
+    ids = np.random.default_rng(4).integers(1, cfg.num_symbols, (2, 30))
+    forced = np.full((2, 30), 4, np.int32)
+    outs = {}
+    for mode in ("bf16x3", "f16x2"):
+        eng = Engine(W.pack(cfg, w), library=emu_lib)
+        eng.set_math(mode)
+        outs[mode], _ = check_parity(emu_lib, cfg, ids=ids, lengths=np.array([30, 17]), forced=forced, noise=True, seed=71,
+                                     sid=np.array([2, 0]), weights=w, engine=eng)
+        eng.close()
+    assert not np.array_equal(outs["bf16x3"]["audio"], outs["f16x2"]["audio"])
+    assert rel_rms(outs["f16x2"]["audio"][0], outs["bf16x3"]["audio"][0]) < 2e-5
 
 
 def test_bf16_weights_mode_separate_tolerance(emu_lib):
