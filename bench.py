@@ -299,8 +299,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if math == "f32" else (
-            "f32 in / out / accumulate; MRF-stage and WaveNet-layer operands as 2 x fp16 terms (22 significant bits, 3 f16-MFMA products per multiply-add), "
-            "the other dense convs as 3 x bf16 (exact, 6 products); experimental mode, parity at the f32 tolerances" if math == "f16x2" else
+            "f32 in / out / accumulate; dense-conv operands as 2 x fp16 terms (22 significant bits, 3 f16-MFMA products per multiply-add), "
+            "encoder on the f32 MFMA; experimental mode, parity at the f32 tolerances" if math == "f16x2" else
             "f32 (dense convs: operands split exactly into 3 x bf16, 6 bf16-MFMA products per "
             "multiply-add, f32 accumulate; f32 in / f32 out, parity at the f32 tolerances)"),
         "math": math,
@@ -445,10 +445,10 @@ def main():
                           math="f16x2")
             hw.size_workspaces()
             el_h, out_h = timed(hw, fsteps, 5)
-            h2_leg = {"math": "f16x2", "dtype": "f32 in / out / accumulate; MRF-stage and WaveNet-layer operands as 2 x fp16 (22 bits), 3 MFMA products",
+            h2_leg = {"math": "f16x2", "dtype": "f32 in / out / accumulate; dense-conv operands as 2 x fp16 (22 bits), 3 MFMA products",
                       "value": int(out_h["lengths"].sum()) * fsteps / el_h, "unit": "samples/s", "steps": fsteps,
                       "ms_per_step": el_h / fsteps * 1e3,
-                      "note": "same workload; the fused MRF decoder stages and WaveNet layers change (everything else as bf16x3)"}
+                      "note": "same workload; every kernel of the bf16x3 split runs the two-term fp16 split instead"}
             if not args.no_roofline:
                 reph, tableh, toth = kernel_table(hw.engines[0], lambda i: hw.step(i, device_only=True), 3)
                 h2_leg["kernels_ms_per_step"] = {r["kernel"]: round(r["ms_per_step"], 4) for r in tableh[:8]}

@@ -148,7 +148,8 @@ void mi355vits_destroy(mi355vits_handle h);
  * bf16, the activations stay exact f32 (three terms), f32 accumulate: three MFMA products per multiply-add.  A REDUCED
  * precision variant: separate tolerance (rel. RMS <= 2e-2 vs the f32 oracle), never the default, reported separately. */
 #define MI355VITS_MATH_BF16W 2
-/* experimental: the fused MRF decoder stages and the fused WaveNet layers with both operands split into TWO fp16 terms (11 + 11 significant bits,
+/* experimental: every kernel of the three-term bf16 split (MRF stages, WaveNet layers, staged convs, upsamplers) with both
+ * operands split into TWO fp16 terms (11 + 11 significant bits,
  * power-of-two pre-scaling, three products per multiply-add on v_mfma_f32_32x32x16_f16); every other kernel as BF16X3.
  * A 22-bit-operand mode: between BF16W and the f32-grade default, with its own tests; never the default. */
 #define MI355VITS_MATH_F16X2 3

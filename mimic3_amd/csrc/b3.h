@@ -165,6 +165,50 @@ __device__ __forceinline__ void b3_chunk_lean(f32x16 (&acc)[MT][NT], const uint4
     }
 }
 
+// MATH_F16X2 form of b3_chunk_lean (B fragments single-buffered, two fp16 planes, three products)
+template <int MT, int NT, int NG>
+__device__ __forceinline__ void h2_chunk_lean(f32x16 (&acc)[MT][NT], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS, int LD,
+                                              int K, int groups_per_tap, int dil) {
+    uint4 ra[2][MT][2];
+    uint4 rb[NT][2];
+    MI355_UNROLL
+    for (int i = 0; i < MT; ++i)
+        MI355_UNROLL
+        for (int p = 0; p < 2; ++p) ra[0][i][p] = wp[i][p * 64];
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j)
+        MI355_UNROLL
+        for (int p = 0; p < 2; ++p) rb[j][p] = xq[p * PS + j * 32];
+    for (int k = 0; k < K; ++k) {
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            const bool wrap = g + 1 == NG;
+            const long woff = (wrap ? (last_tap ? (long)k * groups_per_tap + g : (long)(k + 1) * groups_per_tap) : (long)k * groups_per_tap + g + 1) * 128;
+            const int xoff = wrap ? (last_tap ? k * dil + g * 2 * LD : (k + 1) * dil) : k * dil + (g + 1) * 2 * LD;
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int p = 0; p < 2; ++p) ra[nxt][i][p] = wp[i][woff + p * 64];
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) {
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_F16(ra[cur][i][1], rb[j][0], acc[i][j]);  // small terms first
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_F16(ra[cur][i][0], rb[j][1], acc[i][j]);
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_F16(ra[cur][i][0], rb[j][0], acc[i][j]);
+                SCHED_FENCE();
+                MI355_UNROLL
+                for (int p = 0; p < 2; ++p) rb[j][p] = xq[p * PS + xoff + j * 32];
+                SCHED_FENCE();
+            }
+        }
+    }
+}
+
 // stage x[c0 : c0 + 16 NG, ts : ts + LD) as three bf16 planes: mask, leaky-relu and split fused.  A thread takes one
 // column; per (group, half) it loads that column's eight channels (16G + 4h + 0..3 and 16G + 8 + 4h + 0..3: eight
 // 4-byte loads, 256 contiguous bytes per wave and row), splits four pairs and stores one 16-byte slot per plane.

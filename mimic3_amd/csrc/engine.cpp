@@ -241,7 +241,7 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
                 pack_conv_weights_bf16x3_mode(w.data(), Cout, Cin, K, EPI_STD, 1, bw.data());
                 c.packed_b3w = stage(reinterpret_cast<const float*>(bw.data()), bw.size());
             }
-            if (key.rfind("flow.", 0) == 0 && Cin % 16 == 0 && Cout % 32 == 0) {  // WaveNet layers in MATH_F16X2
+            if (Cin % 16 == 0 && Cout % 32 == 0) {  // MATH_F16X2: WaveNet layers, staged convs, polyphase upsamplers (plain rows)
                 std::vector<uint32_t> h2(f16x2_packed_words(Cout, Cin, K));
                 if (pack_conv_weights_f16x2(w.data(), Cout, Cin, K, h2.data(), 1))
                     c.packed_h2s = stage(reinterpret_cast<const float*>(h2.data()), h2.size());
@@ -360,6 +360,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         no_fused_dds_ = lane0.no_fused_dds_;
         no_post_fusion_ = lane0.no_post_fusion_;
         enc_b3_ = lane0.enc_b3_;
+        no_f16x2_convs_ = lane0.no_f16x2_convs_;
     } catch (...) {
         release();
         throw;
@@ -393,6 +394,7 @@ void Engine::open_device(int device) {
     // workgroup per CU, so its tail (result to LDS, barrier, 7-tap conv, store drain) is as exposed as the plain store was
     no_post_fusion_ = getenv("MI355VITS_POST_FUSION") == nullptr;
     enc_b3_ = getenv("MI355VITS_NO_ENC_B3") == nullptr;
+    no_f16x2_convs_ = getenv("MI355VITS_F16X2_NO_CONVS") != nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
     const char* mm = getenv("MI355VITS_MATH");
     if (mm && mm[0]) {
@@ -620,6 +622,10 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
             (math_on_bf16(a.math) || ((w.K * w.Cin >= b3_min_work_ || (a.shuf_s && w.Cin % 64 == 0)) && a.epi == EPI_STD))) {
             a.wb3 = P(w.packed_b3s);
             a.math = kmath();
+            if (math_ == MATH_F16X2 && w.packed_h2s != NO_OFF && a.epi == EPI_STD && !no_f16x2_convs_) {  // two fp16 terms per operand
+                a.wb3 = P(w.packed_h2s);
+                a.math = MATH_F16X2;
+            }
         } else {
             a.math = MATH_F32;
         }

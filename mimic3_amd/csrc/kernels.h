@@ -59,7 +59,7 @@ void regroup_packed_x4(const float* packed, size_t n_floats, float* out);  // fu
 // v_mfma_f32_32x32x16_bf16: [Cout/32][K][Cin/16][plane h,m,l][64 lanes][8 bf16]; lane l = (half l >> 5, row l & 31)
 // holds the k-slots e < 4: channel 16G + half + 2e, e >= 4: 16G + 8 + half + 2(e - 4) — the channels a lane's two
 // ds_read_b128 of a packed activation tile deliver.  Needs Cin % 16 == 0 and Cout % 32 == 0; sizes in 32-bit words.
-// BF16W: BF16X3 with the weights' leading bf16 term only.  F16X2 (experimental, fused MRF stages and fused WaveNet layers; every other kernel
+// BF16W: BF16X3 with the weights' leading bf16 term only.  F16X2 (experimental: every BF16X3 kernel; every other kernel
 // runs as in BF16X3): operands split into two fp16 terms (22 significant bits), three products per multiply-add.
 enum MathMode { MATH_F32 = 0, MATH_BF16X3 = 1, MATH_BF16W = 2, MATH_F16X2 = 3 };
 inline bool math_on_bf16(int m) { return m == MATH_BF16X3 || m == MATH_BF16W; }

@@ -929,8 +929,12 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void 
 //   * MT x NT accumulator tiles per wave share every fetch (A across NT columns tiles, B across MT row tiles);
 //     the epilogues are the f32 kernel's.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int EPI, int NG, bool W1 = false>
+// H2 (MATH_F16X2): two fp16 planes per operand (a.wb3 = pack_conv_weights_f16x2 layout 1), accumulators scaled by 2^17 until
+// just before the epilogue.
+template <int MT, int NT, int WM, int WN, int EPI, int NG, bool W1 = false, bool H2 = false>
 __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
+    static_assert(!(W1 && H2), "one reduced-operand variant at a time");
+    constexpr int GW = H2 ? 128 : 192;  // uint4 per weight-fragment group
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(EPI != EPI_GATE || MT == 2, "gate needs the tile pair in one wave");
     static_assert(NG % 2 == 0, "an even number of 16-channel groups per chunk");
@@ -965,7 +969,7 @@ __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
 
     const int brow = lane >> 5, bcol = lane & 31;
     for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
-        if (!(a.ablate & 2)) stage_planes<NG>(xb + (long)c0 * a.x_ld, a.x_ld, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, planes, PS, tid, 256);
+        if (!(a.ablate & 2)) stage_planes<NG, 4, H2>(xb + (long)c0 * a.x_ld, a.x_ld, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, planes, PS, tid, 256);
         __syncthreads();
         if (!(a.ablate & 1)) {
             const uint4* wp[MT];
@@ -973,11 +977,20 @@ __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
             for (int i = 0; i < MT; ++i) {
                 int tile = tile0 + i;
                 if (tile >= n_tiles) tile = n_tiles - 1;  // out-of-range tile: recompute the last one, discarded below
-                wp[i] = reinterpret_cast<const uint4*>(a.wb3) + ((long)tile * a.K * gpt + (c0 >> 4)) * 192 + lane;
+                wp[i] = reinterpret_cast<const uint4*>(a.wb3) + ((long)tile * a.K * gpt + (c0 >> 4)) * GW + lane;
             }
-            b3_chunk<MT, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + wn * NT * 32 + toff, PS, LD, a.K, gpt, a.dil);
+            if constexpr (H2) h2_chunk<MT, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + wn * NT * 32 + toff, PS, LD, a.K, gpt, a.dil);
+            else b3_chunk<MT, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + wn * NT * 32 + toff, PS, LD, a.K, gpt, a.dil);
         }
         __syncthreads();
+    }
+    if constexpr (H2) {  // back to the unscaled domain (exact)
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i)
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j)
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= 1.0f / F16X2_ACC_SCALE;
     }
     conv_epilogue<MT, NT, WM, WN, EPI>(a, acc, xs, b, t0, tile0, n_tiles, wm, wn, brow, bcol, tid, out_len);
 }
@@ -991,9 +1004,11 @@ __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
 // CU; tiles are dealt round-robin with the row block fastest, so the row blocks sharing an input tile run side by side.
 // The chunk order of an output is the same as in k_conv1d_b3 (results identical).
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int NG, bool W1 = false>
+template <int MT, int NT, int WM, int WN, int NG, bool W1 = false, bool H2 = false>
 __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
     static_assert(WM * WN == 4, "4 consumer waves per workgroup");
+    static_assert(!(W1 && H2), "one reduced-operand variant at a time");
+    constexpr int GW = H2 ? 128 : 192;
     DYN_SMEM(float, xs);
     constexpr int T_B = 32 * NT * WN;
     constexpr int CI_C = 16 * NG;
@@ -1029,7 +1044,7 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
         // all 8 x 2 NG loads of a thread in one batch: the CU's vector-memory path returns data in issue order across
         // waves, so while the producers' HBM loads are in flight the consumers' weight-fragment loads (L2 hits) wait
         // behind them — one miss train per step costs the consumers one memory latency, two cost two
-        stage_planes<NG, NG * 2>(a.x + (long)b * a.x_bs + (long)chunk * CI_C * a.x_ld, a.x_ld, LD, ct * T_B - a.pad, Tin < in_len ? Tin : in_len,
+        stage_planes<NG, NG * 2, H2>(a.x + (long)b * a.x_bs + (long)chunk * CI_C * a.x_ld, a.x_ld, LD, ct * T_B - a.pad, Tin < in_len ? Tin : in_len,
                                  a.in_slope, planes + (s & 1) * 3 * PS, PS, stid, nthreads);
     };
 
@@ -1064,9 +1079,22 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
         for (int ii = 0; ii < MT; ++ii) {
             int t = tile0 + ii;
             if (t >= n_tiles) t = n_tiles - 1;
-            wp[ii] = reinterpret_cast<const uint4*>(a.wb3) + ((long)t * a.K * gpt + (chunk * CI_C >> 4)) * 192 + lane;
+            wp[ii] = reinterpret_cast<const uint4*>(a.wb3) + ((long)t * a.K * gpt + (chunk * CI_C >> 4)) * GW + lane;
         }
-        if (!(a.ablate & 1)) b3_chunk_lean<MT, NT, NG, W1>(acc, wp, planes + (s & 1) * 3 * PS + brow * LD + bcol + wn * NT * 32, PS, LD, a.K, gpt, a.dil);
+        if (!(a.ablate & 1)) {
+            if constexpr (H2) h2_chunk_lean<MT, NT, NG>(acc, wp, planes + (s & 1) * 3 * PS + brow * LD + bcol + wn * NT * 32, PS, LD, a.K, gpt, a.dil);
+            else b3_chunk_lean<MT, NT, NG, W1>(acc, wp, planes + (s & 1) * 3 * PS + brow * LD + bcol + wn * NT * 32, PS, LD, a.K, gpt, a.dil);
+        }
+        if constexpr (H2) {
+            if (chunk == nchunks - 1) {  // back to the unscaled domain (exact)
+                MI355_UNROLL
+                for (int ii = 0; ii < MT; ++ii)
+                    MI355_UNROLL
+                    for (int jj = 0; jj < NT; ++jj)
+                        MI355_UNROLL
+                        for (int r = 0; r < 16; ++r) acc[ii][jj][r] *= 1.0f / F16X2_ACC_SCALE;
+            }
+        }
         if (chunk == nchunks - 1 && (!(a.ablate & 4) || acc[0][0][0] == 1.2345f)) {
             const long q = tile / row_blocks;
             const int ct = (int)(q % col_tiles), b = (int)(q / col_tiles);
@@ -1350,13 +1378,19 @@ void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
 #endif
                 LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, av);
             };
-            if (a.math == MATH_BF16W) gop(k_conv1d_b3_pc<MT, NT, WM, WN, 4, true>);
+            if (a.math == MATH_F16X2) gop(k_conv1d_b3_pc<MT, NT, WM, WN, 4, false, true>);
+            else if (a.math == MATH_BF16W) gop(k_conv1d_b3_pc<MT, NT, WM, WN, 4, true>);
             else gop(k_conv1d_b3_pc<MT, NT, WM, WN, 4, false>);
             return;
         }
         if (wide) {
-            if (a.math == MATH_BF16W) go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, true>);
+            if (a.math == MATH_F16X2) go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, false, true>);
+            else if (a.math == MATH_BF16W) go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, true>);
             else go(k_conv1d_b3<MT, NT, WM, WN, EPI, 4, false>);
+            return;
+        }
+        if (a.math == MATH_F16X2) {
+            go(k_conv1d_b3<MT, NT, WM, WN, EPI, 2, false, true>);
             return;
         }
     }
@@ -1390,7 +1424,8 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     a.ablate = ablate;
     if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
     const int n_tiles = n_tiles_for(a.epi, a.Cout, a.H);
-    if (math_on_bf16(a.math) && a.wb3 && conv1d_b3_supported(a.Cin, a.Cout, a.K, a.dil, a.fixed_rule ? 1 << 30 : a.T)) {
+    if ((math_on_bf16(a.math) || (a.math == MATH_F16X2 && a.epi == EPI_STD)) && a.wb3 &&
+        conv1d_b3_supported(a.Cin, a.Cout, a.K, a.dil, a.fixed_rule ? 1 << 30 : a.T)) {
         // split-bf16 path: one tile shape per epilogue kind (fixed by the layer, never by the batch)
         if (a.epi == EPI_GATE) launch_b3<2, 3, 2, 2, EPI_GATE>(a, n_tiles, s);
         else if (a.epi == EPI_RESSKIP) {

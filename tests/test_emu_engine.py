@@ -603,6 +603,31 @@ def test_f16x2_mode_fused_mrf_stages(emu_lib):
         eng.close()
     assert not np.array_equal(outs["bf16x3"]["audio"], outs["f16x2"]["audio"])
     assert rel_rms(outs["f16x2"]["audio"][0], outs["bf16x3"]["audio"][0]) < 2e-5
+    # ... and the staged convs / the persistent upsampler kernel (more than 512 frames; MI355VITS_B3_MIN_WORK=0 routes the tiny
+    # voice's convs through them), with MI355VITS_F16X2_NO_CONVS as the A/B switch
+    import os
+
+    cfg = VitsConfig.tiny_wide()
+    w = W.synthetic_weights(cfg, seed=12, frames_per_id=2.0)
+    Tx = 140
+    forced = np.full((2, Tx), 4, np.int32)
+    ids = np.random.default_rng(2).integers(1, cfg.num_symbols, (2, Tx))
+    res = {}
+    for tag, env in (("convs", {}), ("noconvs", {"MI355VITS_F16X2_NO_CONVS": "1"})):
+        os.environ["MI355VITS_B3_MIN_WORK"] = "0"
+        os.environ.update(env)
+        try:
+            eng = Engine(W.pack(cfg, w), library=emu_lib)
+        finally:
+            del os.environ["MI355VITS_B3_MIN_WORK"]
+            for k in env:
+                del os.environ[k]
+        eng.set_math("f16x2")
+        res[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=np.array([Tx, Tx - 9]), forced=forced, noise=True, seed=12, weights=w,
+                                   engine=eng)
+        eng.close()
+    assert not np.array_equal(res["convs"]["audio"], res["noconvs"]["audio"])
+    assert rel_rms(res["convs"]["audio"][0], res["noconvs"]["audio"][0]) < 2e-5
 
 
 def test_bf16_weights_mode_separate_tolerance(emu_lib):
