@@ -452,7 +452,7 @@ def main():
             if not args.no_roofline:
                 reph, tableh, toth = kernel_table(hw.engines[0], lambda i: hw.step(i, device_only=True), 3)
                 h2_leg["kernels_ms_per_step"] = {r["kernel"]: round(r["ms_per_step"], 4) for r in tableh[:8]}
-            result["extra"]["f16x2_mrf"] = h2_leg
+            result["extra"]["f16x2"] = h2_leg
             hw.close()
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
