@@ -2,7 +2,8 @@ set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-BENCH="python $R/bench.py --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --no-extra --no-b1 --no-roofline"
+# MATH=f16x2 bash tools/profile_r02.sh profiles another math mode (default: the engine's)
+BENCH="python $R/bench.py --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --no-extra --no-b1 --no-roofline ${MATH:+--math $MATH}"
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq1 $O/prof_sq2
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats -- $BENCH > $O/rocprof_stats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/prof_fetch -- $BENCH > $O/rocprof_fetch.log 2>&1
