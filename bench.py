@@ -148,7 +148,8 @@ def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32"):
     dom = table[0]
     drec = rep[dom["kernel"]]
     dsec = drec["ms"] * 1e-3
-    traffic = _pmc_traffic(dom["kernel"], workload_key, voice)
+    # the committed counter passes are per math mode: "<label>" = bf16x3 (the default), "f32:<label>", "f16x2:<label>"
+    traffic = _pmc_traffic(("" if math == "bf16x3" else math + ":") + dom["kernel"], workload_key, voice)
     # the roof of the dominant kernel: kernels named *_b3 / running in MATH_BF16X3 execute six bf16 MFMA products per
     # algorithmic f32 multiply-add, so their matrix-core roof is 2500 / 6 TFLOP/s of ALGORITHMIC f32 work
     on_bf16 = math in ("bf16x3", "f16x2") and any(t in dom["kernel"] for t in ("mrf", "wn_layer_b3", "dec.rb", "upsample.s0", "upsample.s1", "conv_pre"))
