@@ -389,11 +389,11 @@ int mi355vits_bench_conv1d(int device, int B, int Cin, int Cout, int T, int K, i
 int mi355vits_test_mfma_layout(int device, float* err) {
     return guarded(nullptr, [&] {
         HIP_CHECK(hipSetDevice(device));
-        DevBuf d((1024 + 256) * 4);
+        DevBuf d((1024 + 256 + 256) * 4);
         launch_mfma_selftest(d.as<float>(), nullptr);
         HIP_CHECK(hipDeviceSynchronize());
-        std::vector<float> h(1280);
-        HIP_CHECK(hipMemcpy(h.data(), d.p, 1280 * 4, hipMemcpyDeviceToHost));
+        std::vector<float> h(1536);
+        HIP_CHECK(hipMemcpy(h.data(), d.p, 1536 * 4, hipMemcpyDeviceToHost));
         float worst = 0.0f;
         for (int i = 0; i < 32; ++i)
             for (int j = 0; j < 32; ++j) {
@@ -406,6 +406,12 @@ int mi355vits_test_mfma_layout(int device, float* err) {
                 float ref = 0;
                 for (int k = 0; k < 4; ++k) ref += (float)(i + 100 * k + 1) * (float)(3 * j - 7 * k + 2);
                 worst = std::max(worst, std::fabs(ref - h[1024 + i * 16 + j]));
+            }
+        for (int i = 0; i < 16; ++i)  // v_mfma_f32_16x16x32_bf16
+            for (int j = 0; j < 16; ++j) {
+                float ref = 0;
+                for (int k = 0; k < 32; ++k) ref += (float)(i + 2 * k) * (float)(3 * j - k + 2);
+                worst = std::max(worst, std::fabs(ref - h[1280 + i * 16 + j]));
             }
         if (err) *err = worst;
         if (worst > 1e-3f) throw EngineError(MI355VITS_ERR_INTERNAL, "MFMA fragment layout differs from the one the kernels assume");

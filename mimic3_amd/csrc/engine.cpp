@@ -230,6 +230,12 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             if (pack_conv_weights_f16x2(w.data(), Cout, Cin, K, h2.data()))
                 c.packed_h2 = stage(reinterpret_cast<const float*>(h2.data()), h2.size());
         }
+        if (key.rfind("dec.rb.", 0) == 0 && epi == EPI_STD && Cin == Cout && Cin % 32 == 0 && (K == 3 || K == 5 || K == 7)) {
+            // ... and in the fragment order of k_mrf_p (16-row tiles, 32-channel k-groups)
+            std::vector<uint32_t> pp(p16_packed_words(Cout, Cin, K));
+            pack_conv_weights_p16(w.data(), Cout, Cin, K, pp.data());
+            c.packed_p = stage(reinterpret_cast<const float*>(pp.data()), pp.size());
+        }
         if (Cin % 32 == 0 && (epi == EPI_GATE ? (Cout / 2) % 32 == 0 : true)) {
             // ... and for the staged split-bf16 kernel (every dense conv with a multiple of 32 input channels)
             const int pe = epi == EPI_GATE ? EPI_GATE : EPI_STD;
@@ -357,6 +363,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         b3_min_work_ = lane0.b3_min_work_;
         wn_b3_ = lane0.wn_b3_;
         no_mrf_b3_ = lane0.no_mrf_b3_;
+        no_mrf_p_ = lane0.no_mrf_p_;
         no_fused_dds_ = lane0.no_fused_dds_;
         no_post_fusion_ = lane0.no_post_fusion_;
         enc_b3_ = lane0.enc_b3_;
@@ -389,6 +396,7 @@ void Engine::open_device(int device) {
     // pre-split LDS planes for the 32 / 64-channel MRF stages: measured slower than splitting on the fly (3.17 / 2.79 ms vs
     // 2.82 / 2.71 ms per step: four waves cannot hide the plane <-> row conversions of the epilogues), so it is opt-in
     no_mrf_b3_ = getenv("MI355VITS_MRF_PRESPLIT") == nullptr;
+    no_mrf_p_ = getenv("MI355VITS_NO_MRF_P") != nullptr;
     no_fused_dds_ = getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
     // opt-in: measured no faster (bench workload: 3.16 ms fused vs 2.96 + 0.22 ms) — the 32-channel MRF kernel runs one
     // workgroup per CU, so its tail (result to LDS, barrier, 7-tap conv, store drain) is as exposed as the plain store was
@@ -1028,8 +1036,31 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.d1[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 0];
                     m.d2[j] = c.resblock_dilations[j * MI355VITS_MAX_STAGES + 1];
                 }
+                // MATH_BF16X3: the whole stage on planes split once, weights in registers (k_mrf_p)
+                bool all_p = math_ == MATH_BF16X3 && !no_mrf_p_ && mrf_p_supported(ch, nk, m.k, m.d1, m.d2);
+                for (int j = 0; j < nk && all_p; ++j)
+                    for (int q = 0; q < 2; ++q) all_p = all_p && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_p != NO_OFF;
+                if (all_p) {
+                    double flops = 0;
+                    for (int j = 0; j < nk; ++j) {
+                        for (int q = 0; q < 2; ++q) {
+                            const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
+                            m.w[j][q] = P(w.packed_p);
+                            m.bias[j][q] = P(w.bias);
+                        }
+                        flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];
+                    }
+                    m.nrb = nk;
+                    m.math = MATH_BF16X3;
+                    m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
+                    m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
+                    m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
+                    ProfScope ps(prof_, i == 1 ? "dec.mrf_p.s1" : (i == 2 ? "dec.mrf_p.s2" : "dec.mrf_p"), flops, 8.0 * B * (double)T * ch);
+                    launch_mrf_p(m, stream_);
+                    n_fused = nk;
+                }
                 // MATH_BF16X3, 32 / 64 channels: the whole stage on pre-split planes
-                bool all_b3s = math_ == MATH_BF16X3;  // (pre-split variant: BF16X3 only)
+                bool all_b3s = math_ == MATH_BF16X3 && !n_fused;  // (pre-split variant: BF16X3 only)
                 for (int j = 0; j < nk && all_b3s; ++j)
                     for (int q = 0; q < 2; ++q) all_b3s = all_b3s && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3s != NO_OFF;
                 if (all_b3s && ((!no_mrf_b3_ && mrf_b3_supported(ch, nk, m.k, m.d1, m.d2)) || mrf_b3w_supported(ch, nk, m.k, m.d1, m.d2))) {

@@ -95,6 +95,7 @@ struct ConvW {
     size_t packed_b3s = NO_OFF; // the same for the staged split-bf16 conv kernel (layout 1, this conv's tile map)
     size_t packed_b3w = NO_OFF; // WaveNet in-layer convs: layout 1 in plain row order (fused split-bf16 layer kernel)
     size_t packed_h2 = NO_OFF;    // fused-MRF convs: two fp16 planes, weights x 2^13 (MATH_F16X2), when every |w| < 7.99
+    size_t packed_p = NO_OFF;     // fused-MRF convs (Cin = Cout, taps 3 / 5 / 7): pack_conv_weights_p16 fragments (k_mrf_p)
     size_t packed_h2s = NO_OFF;   // WaveNet layer convs: the same in plane order (layout 1), plain rows
     size_t bias = NO_OFF;
     int Cout = 0, Cin = 0, K = 1;
@@ -173,6 +174,7 @@ class Engine {
     int kmath() const { return math_ == MATH_F16X2 ? (int)MATH_BF16X3 : math_; }  // F16X2 covers the fused MRF stages only
     bool no_f16x2_convs_ = false;  // MI355VITS_F16X2_NO_CONVS=1: in MATH_F16X2 keep the staged convs / upsamplers on bf16x3
     bool enc_b3_ = true;           // the encoder's wide FFN conv on the split-bf16 staged kernel (MI355VITS_NO_ENC_B3=1: f32 kernel)
+    bool no_mrf_p_ = false;      // MI355VITS_NO_MRF_P=1: keep the on-the-fly split MRF kernel (A/B against k_mrf_p)
     bool no_mrf_b3_ = false;     // MATH_BF16X3: keep the on-the-fly split MRF kernel (A/B against the pre-split one)
     bool wn_b3_ = false;         // MATH_BF16X3: WaveNet layers as two staged split-bf16 convs instead of the fused f32 layer
     int math_ = MATH_BF16X3;     // which matrix-core path the dense convs take (include/mi355vits.h: MI355VITS_MATH_*)

@@ -14,6 +14,7 @@ typedef hipemu_f32x4 f32x4;
 #define MFMA_16x16x4_F32(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
 #define MFMA_32x32x16_BF16(a, b, c) hipemu_mfma_32x32x16_bf16((a), (b), (c))
 #define MFMA_32x32x16_F16(a, b, c) hipemu_mfma_32x32x16_f16((a), (b), (c))
+#define MFMA_16x16x32_BF16(a, b, c) hipemu_mfma_16x16x32_bf16((a), (b), (c))
 #define CVT_PK_BF16_F32(lo, hi) hipemu_cvt_pk_bf16_f32((lo), (hi))
 #define LAUNCH_KERNEL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((kernel), (grid), (block), (size_t)(shmem), __VA_ARGS__)
@@ -37,6 +38,8 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 #define MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), (c), 0, 0, 0)
+// v_mfma_f32_16x16x32_bf16: lane l = row (A) / column (B) l & 15, k-slots 8 (l >> 4) .. + 7; C/D col = l & 15, row = 4 (l >> 4) + reg
+#define MFMA_16x16x32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), (c), 0, 0, 0)
 // v_mfma_f32_32x32x16_f16: the same shape and rate with eight IEEE halves per lane
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f16x8_t as_f16x8(const uint4& v) { return __builtin_bit_cast(f16x8_t, v); }
@@ -67,8 +70,19 @@ __device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
 #define MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
 
+// lambdas that carry register arrays by reference must be inlined (an outlined one would put them in scratch memory)
+#define MI355_INLINE_LAMBDA __attribute__((always_inline))
+// timing experiments (skip a kernel's MFMA loops / staging / stores: wrong results on purpose) exist only in the lab
+// build (-DMI355_LAB, tools/): the product library carries no such switch
+#ifdef MI355_LAB
+#define LAB_ABLATE(args) ((args).ablate)
+#else
+#define LAB_ABLATE(args) 0
+#endif
+
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 

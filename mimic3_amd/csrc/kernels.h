@@ -132,6 +132,15 @@ bool mrf_b3_supported(int C, int nrb, const int* k, const int* d1, const int* d2
 bool mrf_b3w_supported(int C, int nrb, const int* k, const int* d1, const int* d2);  // 32 channels: weights in LDS too (default path)
 void launch_mrf_b3(MrfArgs a, hipStream_t s);
 
+// MATH_BF16X3 with every element split once (kernels_mrfp.cpp): bf16 planes in LDS, the running conv's weight fragments in
+// registers, v_mfma_f32_16x16x32_bf16 tiles.  w[][] = pack_conv_weights_p16 fragments.  C = 32; taps in {3, 5, 7}.
+size_t p16_packed_words(int Cout, int Cin, int K);
+void pack_conv_weights_p16(const float* w, int Cout, int Cin, int K, uint32_t* out);
+bool mrf_p_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
+void launch_mrf_p(MrfArgs a, hipStream_t s);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, current device)
+void set_max_dynamic_lds(const void* fn, int bytes);
+
 // ---------------------------------------------------------------- fused WaveNet layer of the coupling flow (K8)
 // u = tanh(in(h)[:H] + cond) * sigmoid(in(h)[H:] + cond); rs = res_skip(u); h' = (h + rs[:H]) * mask; skip += rs[H:]
 struct WnArgs {
@@ -228,6 +237,6 @@ void launch_speaker_cond(const float* emb_g, const long long* sid, const float* 
 
 // misc
 void launch_fill(float* p, float v, size_t n, hipStream_t s);
-void launch_mfma_selftest(float* out /*[32*32 + 16*16]*/, hipStream_t s);
+void launch_mfma_selftest(float* out /*[32*32 + 16*16 + 16*16]*/, hipStream_t s);
 
 }  // namespace m355

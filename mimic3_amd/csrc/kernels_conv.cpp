@@ -1847,6 +1847,24 @@ __global__ __launch_bounds__(64) void k_mfma_selftest(float* out) {
             out[1024 + row * 16 + (lane & 15)] = c[r];
         }
     }
+    // 16x16x32 bf16 (k_mrf_p): A[i][k] = i + 2k, B[k][j] = 3j - k + 2 (small integers: exact in bf16); lane = (quarter q, row /
+    // column), k-slots 8q .. 8q + 7, slot e in bits [16 (e & 1) ...] of register e >> 1
+    {
+        f32x4 c;
+        for (int r = 0; r < 4; ++r) c[r] = 0.0f;
+        const int q = lane >> 4, rc = lane & 15;
+        unsigned aw[4], bw[4];
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int k0 = 8 * q + 2 * e2, k1 = k0 + 1;
+            aw[e2] = (__float_as_uint((float)(rc + 2 * k0)) >> 16) | (__float_as_uint((float)(rc + 2 * k1)) & 0xffff0000u);
+            bw[e2] = (__float_as_uint((float)(3 * rc - k0 + 2)) >> 16) | (__float_as_uint((float)(3 * rc - k1 + 2)) & 0xffff0000u);
+        }
+        uint4 a4, b4;
+        a4.x = aw[0]; a4.y = aw[1]; a4.z = aw[2]; a4.w = aw[3];
+        b4.x = bw[0]; b4.y = bw[1]; b4.z = bw[2]; b4.w = bw[3];
+        c = MFMA_16x16x32_BF16(a4, b4, c);
+        for (int r = 0; r < 4; ++r) out[1280 + (4 * q + r) * 16 + rc] = c[r];
+    }
 }
 void launch_mfma_selftest(float* out, hipStream_t s) { LAUNCH_KERNEL(k_mfma_selftest, dim3(1), dim3(64), 0, s, out); }
 

@@ -43,6 +43,7 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 struct int4 { int x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
@@ -563,6 +564,35 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(uint4 a, uint4 b, hipemu_f
         for (int h = 0; h < 2; ++h)
             for (int e = 0; e < 8; ++e) {
                 const unsigned ua = w->mfma_a16[wave][slot][row + 32 * h][e >> 1], ub = w->mfma_b16[wave][slot][col + 32 * h][e >> 1];
+                const float fa = __uint_as_float((e & 1) ? (ua & 0xffff0000u) : (ua << 16));
+                const float fb = __uint_as_float((e & 1) ? (ub & 0xffff0000u) : (ub << 16));
+                d += (double)fa * (double)fb;
+            }
+        c[r] = (float)((double)c[r] + d);
+    }
+    return c;
+}
+
+// v_mfma_f32_16x16x32_bf16: lane l holds row (A) / column (B) l & 15 and the eight k-slots 8 (l >> 4) .. + 7 (slot j in bits
+// [16 (j & 1) ...] of register j >> 1); C/D: col = lane & 15, row = 4 (lane >> 4) + reg.  Exact products, summed in double.
+static inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(uint4 a, uint4 b, hipemu_f32x4 c) {
+    hipemu::Worker* w = hipemu::tl_worker;
+    hipemu::Fiber* f = w->cur;
+    const int wave = f->lin / 64, lane = f->lin % 64;
+    const int slot = (f->wave_ops++) & 1;
+    const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 4; ++j) {
+        w->mfma_a16[wave][slot][lane][j] = av[j];
+        w->mfma_b16[wave][slot][lane][j] = bv[j];
+    }
+    hipemu::wave_sync();
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        double d = 0.0;
+        for (int qq = 0; qq < 4; ++qq)
+            for (int e = 0; e < 8; ++e) {
+                const unsigned ua = w->mfma_a16[wave][slot][row + 16 * qq][e >> 1], ub = w->mfma_b16[wave][slot][col + 16 * qq][e >> 1];
                 const float fa = __uint_as_float((e & 1) ? (ua & 0xffff0000u) : (ua << 16));
                 const float fb = __uint_as_float((e & 1) ? (ub & 0xffff0000u) : (ub << 16));
                 d += (double)fa * (double)fb;

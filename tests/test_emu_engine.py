@@ -671,3 +671,40 @@ def test_fused_dds_layer_kernel(emu_lib, cfgname, monkeypatch):
     plain = eng.tap("logw"), eng.tap("w_ceil")
     eng.close()
     assert np.array_equal(fused[1], plain[1]) and np.abs(fused[0] - plain[0]).max() < 1e-4
+
+
+@pytest.mark.parametrize("dils", [((1, 2), (2, 6), (3, 12)), ((1, 3), (1, 3), (1, 3)), ((3, 1), (2, 1), (1, 2))])
+def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
+    """k_mrf_p (32-channel stage, MATH_BF16X3, the default path): x / x1 as bf16 planes split ONCE in LDS, the running conv's
+    weight fragments in registers, v_mfma_f32_16x16x32_bf16 tiles (320 output columns per workgroup, conv1 over the extended
+    range in 21 / 22 / 25 column tiles dealt to four column groups).  The "_low" voices' dilations, a narrow set and one with
+    r1 > r2; ragged batch over several workgroups (row 1 ends inside a workgroup); decoder stage taps and the waveform vs the
+    oracle, and vs the split-per-tap kernel (MI355VITS_NO_MRF_P=1)."""
+    import os
+
+    cfg = VitsConfig.tiny_wide()
+    cfg.resblock_dilation_sizes = dils
+    w = W.synthetic_weights(cfg, seed=78, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 24
+    forced = np.full((2, Tx), 4, np.int32)  # 96 frames -> 768 columns in the 32-channel stage: 3 workgroups per row
+    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (2, Tx))
+    lengths = np.array([Tx, Tx - 9])
+    outs = {}
+    for tag, env in (("p", None), ("fused", "MI355VITS_NO_MRF_P")):
+        if env:
+            os.environ[env] = "1"
+        try:
+            eng = Engine(blob, library=emu_lib)
+            eng.set_math("bf16x3")
+            eng.profile_enable(True)
+            outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=78, weights=w, engine=eng)
+            labels = set(eng.profile_report())
+            assert ("dec.mrf_p.s1" in labels) == (tag == "p") and ("dec.mrf_fused.s1" in labels) == (tag == "fused"), labels
+            eng.close()
+        finally:
+            if env:
+                del os.environ[env]
+    for bi in range(2):
+        L = int(outs["fused"]["lengths"][bi])
+        assert rel_rms(outs["p"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
