@@ -18,6 +18,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
 SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
+PER_FILE_FLAGS = {}
+LAB_FILE_FLAGS = {"kernels_mrfp.cpp": ["-fno-slp-vectorize", "-DMRFP_SCALAR"]}  # the lab build's side of the current A/B
 HIP_LIB = os.path.join(CSRC, "libmi355vits.so")
 EMU_LIB = os.path.join(EMU, "libmi355vits_emu.so")
 
@@ -48,19 +50,35 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def build_hip(force: bool = False, verbose_resources: bool = False) -> str:
-    if not force and not _stale(HIP_LIB, _deps()):
-        return HIP_LIB
+def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = False) -> str:
+    """One object per source (compiled in parallel, rebuilt only when the source or a header changed), then one link.
+    ``lab=True`` builds ``libmi355vits_lab.so`` with -DMI355_LAB (timing / kernel-choice experiments for tools/; never
+    loaded by the product)."""
+    target = HIP_LIB.replace(".so", "_lab.so") if lab else HIP_LIB
+    hdrs = [d for d in _deps() if d.endswith(".h")]
+    objdir = os.path.join(CSRC, "build", "lab" if lab else "hip")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = find_hipcc()
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
+            "-I", os.path.join(ROOT, "include")]
+    if lab:
+        base.append("-DMI355_LAB")
     if verbose_resources:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", HIP_LIB + ".tmp"]
-    _run(cmd)
-    os.replace(HIP_LIB + ".tmp", HIP_LIB)
-    return HIP_LIB
+        base.append("-Rpass-analysis=kernel-resource-usage")
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".cpp", ".o"))
+        if force or verbose_resources or _stale(obj, [src] + hdrs):
+            jobs.append(base + PER_FILE_FLAGS.get(s, []) + (LAB_FILE_FLAGS.get(s, []) if lab else []) + ["-c", src, "-o", obj])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(_run, jobs))
+    objs = [os.path.join(objdir, s.replace(".cpp", ".o")) for s in SOURCES]
+    if jobs or _stale(target, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"])
+        os.replace(target + ".tmp", target)
+    return target
 
 
 def build_emu(force: bool = False) -> str:
@@ -81,5 +99,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["hip", "emu"]
     if "hip" in which:
         print(build_hip(force="--force" in which, verbose_resources="--resources" in which))
+    if "lab" in which:
+        print(build_hip(force="--force" in which, lab=True))
     if "emu" in which:
         print(build_emu(force="--force" in which))

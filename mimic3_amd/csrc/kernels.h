@@ -138,6 +138,7 @@ size_t p16_packed_words(int Cout, int Cin, int K);
 void pack_conv_weights_p16(const float* w, int Cout, int Cin, int K, uint32_t* out);
 bool mrf_p_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_p(MrfArgs a, hipStream_t s);
+int current_device_cu_count();  // compute units of the current device (persistent grids), looked up once per device
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, current device)
 void set_max_dynamic_lds(const void* fn, int bytes);
 

@@ -22,6 +22,8 @@
 //     record: row 4 q + i of tile mt = channel 32 (mt >> 1) + 8 q + 4 (mt & 1) + i (the weights are packed to match,
 //     pack_conv_weights_p16).
 // HBM traffic = read x (+halo) + write y, as before.
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -30,228 +32,365 @@
 
 namespace m355 {
 
+// MRFP_SCALAR (with -fno-slp-vectorize for this file): no packed f32 VALU in the kernel
+#ifdef MRFP_SCALAR
+#define MRFP_SPLIT split3_sc
+#else
+#define MRFP_SPLIT split3_pk
+#endif
+
 namespace {
 constexpr int MRFP_KMAX = 7;  // taps whose fragments fit a wave's registers next to the accumulators
 constexpr size_t MRFP_LDS_LIMIT = 160 * 1024;
 }  // namespace
 
-// the running conv's fragments of row tile `mt`: [tap][k-group][plane] x (64 lanes x 16 B); taps >= K are not touched
-template <int G, int K>
-__device__ __forceinline__ void mrfp_load_w(uint4 (&W)[MRFP_KMAX][G][3], const uint4* __restrict__ wp) {
+// one k-group of the running conv's fragments of row tile `mt`: [tap][plane] x (64 lanes x 16 B); consecutive taps are
+// `tap_stride` uint4 apart (= C / 32 k-groups x 3 planes x 64 lanes)
+// wp is wave-uniform (one base register pair for all fragments), the lane index a 32-bit offset
+template <int K>
+__device__ __forceinline__ void mrfp_load_w(uint4 (&W)[MRFP_KMAX][3], const uint4* __restrict__ wp, int lane, int tap_stride) {
     MI355_UNROLL
     for (int k = 0; k < K; ++k)
         MI355_UNROLL
-        for (int g = 0; g < G; ++g)
-            MI355_UNROLL
-            for (int p = 0; p < 3; ++p) W[k][g][p] = wp[((k * G + g) * 3 + p) * 64];
+        for (int p = 0; p < 3; ++p) W[k][p] = wp[lane + k * tap_stride + p * 64];
 }
 
-// bf16 slot `i` (0..3) of the two registers of a half record -> f32
-__device__ __forceinline__ float bf16_slot(const uint2& v, int i) {
-    const unsigned w = (i >> 1) ? v.y : v.x;
-    return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
-}
-
-// One 16-column tile of one conv for this wave's 16 output rows: acc = init + sum over K taps x G k-groups.  xq = (plane 0,
-// k-group 0, this lane's quarter, first tap's column) in the LDS planes; PS = plane stride, LD = row pitch (uint4 units).
-// B fragments travel two steps ahead (ring of three); the six products of a step alternate between two accumulator
-// chains (small terms | large terms) so that consecutive MFMAs never wait on each other's result.
-template <int K, int G, typename Init>
-__device__ __forceinline__ f32x4 mrfp_tile(const uint4 (&W)[MRFP_KMAX][G][3], const uint4* __restrict__ xq, int PS, int LD, int dil, Init init) {
-    constexpr int S = K * G;
-    uint4 bf[3][3];
+// One 16-column tile, one k-group (32 input channels) of one conv for this wave's 16 output rows: (accb + accs) += sum over
+// K taps.  xq = (plane 0, this k-group, this lane's quarter, first tap's column) in the LDS planes; PS = plane stride (uint4).
+// B fragments travel AHEAD steps ahead (ring of AHEAD + 1); the six products of a step alternate between two accumulator
+// chains (small terms -> accs, large terms -> accb) so that consecutive MFMAs never wait on each other's result.
+// filler(s) is called inside step s: independent VALU work (the previous tile's epilogue) that the scheduler is asked to deal
+// out between this step's MFMAs — on this part VALU work overlaps matrix work only from inside the same instruction stream.
+// KN > 0 (the last tile a conv's k-group is used for): tap s of the NEXT fragments (wn, KN taps) is loaded into W[s] as soon
+// as step s has issued its MFMAs — the weight stream of the next conv travels under the rest of this tile, the epilogue and
+// the barrier instead of in front of the next conv (the L1 delivers 64 B per clock: 9 - 21 KiB per wave and conv).
+template <int K, int AHEAD, int KN, typename Filler>
+__device__ __forceinline__ void mrfp_sweep(f32x4& accb, f32x4& accs, uint4 (&W)[MRFP_KMAX][3], const uint4* __restrict__ xq, int PS, int dil,
+                                           Filler filler, const uint4* __restrict__ wn, int lane, int tap_stride) {
+    constexpr int RING = AHEAD + 1;
+    uint4 bf[RING][3];
     auto rd = [&](int s, int slot) MI355_INLINE_LAMBDA {
-        const uint4* p = xq + (s % G) * 4 * LD + (s / G) * dil;
+        const uint4* p = xq + s * dil;
         MI355_UNROLL
         for (int pl = 0; pl < 3; ++pl) bf[slot][pl] = p[pl * PS];
     };
-    rd(0, 0);
-    if (S > 1) rd(1, 1);
-    f32x4 accb = init();  // residual + bias (+ the running output): VALU beside the first fragments' LDS latency
-    f32x4 accs;
     MI355_UNROLL
-    for (int r = 0; r < 4; ++r) accs[r] = 0.0f;
+    for (int s = 0; s < AHEAD && s < K; ++s) rd(s, s);
     MI355_UNROLL
-    for (int s = 0; s < S; ++s) {
-        if (s + 2 < S) rd(s + 2, (s + 2) % 3);
+    for (int s = 0; s < K; ++s) {
+        if (s + AHEAD < K) rd(s + AHEAD, (s + AHEAD) % RING);
         SCHED_FENCE();
-        const int k = s / G, g = s % G, c = s % 3;
-        accs = MFMA_16x16x32_BF16(W[k][g][2], bf[c][0], accs);  // small terms first
-        accb = MFMA_16x16x32_BF16(W[k][g][1], bf[c][0], accb);
-        accs = MFMA_16x16x32_BF16(W[k][g][0], bf[c][2], accs);
-        accb = MFMA_16x16x32_BF16(W[k][g][0], bf[c][1], accb);
-        accs = MFMA_16x16x32_BF16(W[k][g][1], bf[c][1], accs);
-        accb = MFMA_16x16x32_BF16(W[k][g][0], bf[c][0], accb);
+        const int c = s % RING;
+        accs = MFMA_16x16x32_BF16(W[s][2], bf[c][0], accs);  // small terms first
+        accb = MFMA_16x16x32_BF16(W[s][1], bf[c][0], accb);
+        accs = MFMA_16x16x32_BF16(W[s][0], bf[c][2], accs);
+        accb = MFMA_16x16x32_BF16(W[s][0], bf[c][1], accb);
+        accs = MFMA_16x16x32_BF16(W[s][1], bf[c][1], accs);
+        accb = MFMA_16x16x32_BF16(W[s][0], bf[c][0], accb);
+        filler(s);
+        MI355_UNROLL
+        for (int u = 0; u < 6; ++u) {
+            SCHED_GROUP(0x8, 1);  // one MFMA ...
+            SCHED_GROUP(0x2, 3);  // ... then up to three VALU of the filler
+        }
         SCHED_FENCE();
+        if (KN > 0 && s < KN) {
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) W[s][p] = wn[lane + s * tap_stride + p * 64];
+        }
     }
-    MI355_UNROLL
-    for (int r = 0; r < 4; ++r) accb[r] += accs[r];
-    return accb;
+    if (KN > K) {
+        MI355_UNROLL
+        for (int s = K; s < KN; ++s)
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) W[s][p] = wn[lane + s * tap_stride + p * 64];
+    }
 }
 
-// C channels; NWM = C / 16 row tiles x NWC column groups = 8 waves; T_B = 16 NWC NT2 output columns per workgroup.
+// C channels; NWM = C / 16 row tiles x NWC column groups = 8 waves; T_B = 16 NWC NT2 output columns per work item.
+// PERSISTENT: one workgroup per CU walks the (row, column block) items — a workgroup start costs ~6 us here (160 KiB of LDS:
+// nothing overlaps it).
 // K0, K1, K2: the resblocks' tap counts (0 = no such resblock) — compile-time, so that every weight fragment has its own
-// registers and the whole stage is straight-line code between the barriers (dilations stay run-time arguments).
-template <int C, int NWM, int NWC, int NT2, int K0, int K1, int K2>
+// registers and the whole stage is straight-line code between the barriers.
+// A wave keeps ONE k-group (32 input channels) of the running conv in registers: with C = 64 a conv is two passes over the
+// wave's column tiles (the accumulators persist between the passes, statically indexed).
+// Column tiles: conv2's NT2 output tiles of a wave start at t0 + 16 (cg NT2 + i).  conv1 computes x1 over the extended range
+// [t0 - r2, t0 + T_B + r2): the INTERIOR tiles sit on conv2's grid and belong to the same wave, so conv2's residual (raw x1 at
+// its own columns) never leaves the registers; the halo is covered by ceil(r2 / 16) tiles per side that start at the range's
+// ends (they overlap the interior: the same bits are written twice), dealt round-robin to the column groups, at most NHMAX
+// per wave.  conv1's own residual (raw x) comes straight from global memory (L2 hits: the tile was staged from there).
+// SH: row pitches and dilations when known at compile time (the "_low" voices' stage shapes: every LDS access of a tile then
+// carries its offset as an immediate on one base register), or MrfPDyn = take them from the arguments.
+template <int LDX_, int LD1_, int D10, int D20, int D11, int D21, int D12, int D22>
+struct MrfPShape {
+    static constexpr int LDX = LDX_, LD1 = LD1_;
+    static constexpr int d1(int j) { return j == 0 ? D10 : (j == 1 ? D11 : D12); }
+    static constexpr int d2(int j) { return j == 0 ? D20 : (j == 1 ? D21 : D22); }
+};
+using MrfPDyn = MrfPShape<0, 0, 0, 0, 0, 0, 0, 0>;
+
+template <int C, int NWM, int NWC, int NT2, int NHMAX, int K0, int K1, int K2, typename SH>
 __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
     static_assert(NWM * NWC == 8 && NWM * 16 == C, "eight waves: C / 16 row tiles x column groups");
-    constexpr int G = C / 32, T_B = 16 * NWC * NT2;
+    constexpr int G = C / 32, T_B = 16 * NWC * NT2, TAP = G * 3 * 64, NT1 = NT2 + NHMAX;
+    constexpr int AH = G == 1 ? 2 : 1;  // B fragments ahead of their MFMAs
+    constexpr int RB = 4;               // records a thread stages per item (4 G records per column, column sets share them)
     DYN_SMEM(float, smem);
-    const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
+    const int LDX = SH::LDX ? SH::LDX : a.ldx, LD1 = SH::LD1 ? SH::LD1 : a.ld1, R = a.R;
     const int PSX = G * 4 * LDX, PS1 = G * 4 * LD1;
     uint4* Xp = reinterpret_cast<uint4*>(smem);   // [3][G][4][LDX]   lrelu(x), zero outside the row
     uint4* X1p = Xp + 3 * PSX;                    // [3][G][4][LD1]   lrelu(x1) of the current resblock, zero outside the row
     float* BS = reinterpret_cast<float*>(X1p + 3 * PS1);  // [nrb][2][C] biases
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
-    const int mt = wid % NWM, cg = wid / NWM;
-    const int q = lane >> 4, n = lane & 15;
-    const int gq = mt >> 1, hh = mt & 1;
-    const int co0 = 32 * gq + 8 * q + 4 * hh;  // this lane's four output channels co0 .. co0 + 3 = half hh of record (gq, q)
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * T_B;
-    int len = a.len ? a.len[b] : a.T;
-    if (len > a.T) len = a.T;
+    const int mt = wid % NWM;
+    // work items: item = row * ntile + column block; this workgroup takes first, first + stride, ...  (blocks of one XCD —
+    // block b runs on XCD b % 8 — walk neighbouring items: the halo columns two items share are re-read from that XCD's L2)
+    const int ntile = (a.T + T_B - 1) / T_B;
+    const int nitems = ntile * a.B;
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = (nitems + 7) >> 3, nslot = (nblk + 7 - xcd) >> 3;  // blocks on this XCD (nblk need not be a multiple of 8)
+    const int item_end = (xcd + 1) * per_xcd < nitems ? (xcd + 1) * per_xcd : nitems;
+    int item = xcd * per_xcd + slot;
 
-    uint4 W[MRFP_KMAX][G][3];
-    auto wptr = [&](int j, int c, int K) MI355_INLINE_LAMBDA { return reinterpret_cast<const uint4*>(a.w[j][c]) + (long)mt * K * (G * 3 * 64) + lane; };
-    mrfp_load_w<G, K0>(W, wptr(0, 0, K0));
+    uint4 W[MRFP_KMAX][3];
+    // fragments of (resblock j, conv c, k-group g) for this wave's row tile (wave-uniform; the lane is a 32-bit index on top)
+    auto wptr = [&](int j, int c, int K, int g) MI355_INLINE_LAMBDA {
+        return reinterpret_cast<const uint4*>(a.w[j][c]) + (long)mt * K * TAP + g * (3 * 64);
+    };
+    if (item < item_end) mrfp_load_w<K0>(W, wptr(0, 0, K0, 0), lane, TAP);
 
     for (int i = tid; i < a.nrb * 2 * C; i += 512) BS[i] = a.bias[i / (2 * C)][(i / C) & 1][i % C];
 
-    // ---- stage x[:, t0 - R : t0 - R + LDX) as planes: a thread takes one column of one (k-group, quarter) record — eight
-    // 4-byte loads (256 contiguous bytes per wave and channel), leaky-relu, split, one conflict-free 16-byte store per plane.
-    // Narrow tiles: the waves form column sets that share the records.
-    {
-        const int wpc = (LDX + 63) >> 6;          // waves per column set
-        const int nparts = 8 / wpc > 0 ? 8 / wpc : 1;
-        const int part = wid / wpc, col = tid - part * wpc * 64;
-        const float* xb = a.x + (long)b * a.x_bs;
-        const int last = len > 0 ? len - 1 : 0;
-        if (part < nparts && col < LDX && !(LAB_ABLATE(a) & 2)) {
-            const int tt = t0 - R + col;
-            const bool in = tt >= 0 && tt < len;
-            const int tc = tt < 0 ? 0 : (tt > last ? last : tt);  // every load unconditional (clamped), masked afterwards
-            constexpr int RB = 4;  // records per batch: 32 loads in flight per thread
-            for (int r0 = part * RB; r0 < 4 * G; r0 += nparts * RB) {
-                float v[RB][8];
-                MI355_UNROLL
-                for (int u = 0; u < RB; ++u)
-                    MI355_UNROLL
-                    for (int e = 0; e < 8; ++e) v[u][e] = xb[(long)(8 * (r0 + u) + e) * a.x_ld + tc];
-                SCHED_FENCE();
-                MI355_UNROLL
-                for (int u = 0; u < RB; ++u) {
-                    MI355_UNROLL
-                    for (int e = 0; e < 8; ++e) v[u][e] = in ? lrelu_f(v[u][e], 0.1f) : 0.0f;
-                    uint4 h, m, l;
-                    split3_pk(v[u][0], v[u][1], h.x, m.x, l.x);
-                    split3_pk(v[u][2], v[u][3], h.y, m.y, l.y);
-                    split3_pk(v[u][4], v[u][5], h.z, m.z, l.z);
-                    split3_pk(v[u][6], v[u][7], h.w, m.w, l.w);
-                    const int o = (r0 + u) * LDX + col;
-                    Xp[o] = h;
-                    Xp[PSX + o] = m;
-                    Xp[2 * PSX + o] = l;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    f32x4 out[NT2];
-    MI355_UNROLL
-    for (int i = 0; i < NT2; ++i)
+    // ---- staging of x[:, t0 - R : t0 - R + LDX) as planes: a thread takes one column of RB (k-group, quarter) records — eight
+    // 4-byte loads per record (256 contiguous bytes per wave and channel), all in flight together —, applies leaky-relu, splits
+    // and stores one conflict-free 16-byte record per plane.  Narrow tiles: the waves form column sets that share the records.
+    const int wpc = (LDX + 63) >> 6;  // waves per column set
+    const int nparts = 8 / wpc > 0 ? 8 / wpc : 1;
+    int spart = 0, scol = 0;
+    bool stager = false;
+    auto stage_item = [&](int bb, int tt0, int ln) MI355_INLINE_LAMBDA {
+        if (!stager || (LAB_ABLATE(a) & 2)) return;
+        const int lst = ln > 0 ? ln - 1 : 0;
+        const int tt = tt0 - R + scol;
+        const bool s_in = tt >= 0 && tt < ln;
+        const int tc = tt < 0 ? 0 : (tt > lst ? lst : tt);  // every load unconditional (clamped), masked afterwards
+        const float* xs = a.x + (long)bb * a.x_bs + tc;
+        float sv[RB][8];
         MI355_UNROLL
-        for (int r = 0; r < 4; ++r) out[i][r] = 0.0f;
-
-    // residual (x or x1 at the tile's own column, rebuilt exactly from its planes) + bias for this lane's four rows
-    auto resid_bias = [&](const uint4* P, int PS, int LD, int col, const float* bs) MI355_INLINE_LAMBDA {
-        const uint2* p2 = reinterpret_cast<const uint2*>(P + (gq * 4 + q) * LD + col) + hh;
-        const uint2 vh = p2[0], vm = p2[2 * PS], vl = p2[4 * PS];
-        const float4 bv = *reinterpret_cast<const float4*>(bs + co0);
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        f32x4 r;
-        MI355_UNROLL
-        for (int i = 0; i < 4; ++i) {
-            const float y = (bf16_slot(vh, i) + bf16_slot(vm, i)) + bf16_slot(vl, i);  // exact: the three terms of one f32
-            r[i] = (y >= 0.0f ? y : y * 10.0f) + bb[i];  // the tiles keep leaky-relu'd values; the residual is the raw one
-        }
-        return r;
-    };
-
-    auto resblock = [&](auto KC, auto KN, auto JC) MI355_INLINE_LAMBDA {
-        constexpr int K = decltype(KC)::value, KNEXT = decltype(KN)::value, j = decltype(JC)::value;
-        const int d1 = a.d1[j], d2 = a.d2[j];
-        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
-        // ---- conv1 over the extended range: column e of tile q1 <-> t = t0 - r2 + e; this wave: a contiguous run of tiles
-        const int n1 = (T_B + 2 * r2 + 15) >> 4;
-        const int base = n1 / NWC, rem = n1 % NWC;
-        const int cnt = base + (cg < rem ? 1 : 0), start = cg * base + (cg < rem ? cg : rem);
-        const float* bs1 = BS + (j * 2 + 0) * C;
-        for (int i = 0; i < cnt; ++i) {
-            const int e = (start + i) * 16 + n;
-            f32x4 acc;
-            if (!(LAB_ABLATE(a) & 1)) {
-                acc = mrfp_tile<K, G>(W, Xp + q * LDX + (R - r2 - r1) + e, PSX, LDX, d1,
-                                      [&]() MI355_INLINE_LAMBDA { return resid_bias(Xp, PSX, LDX, (R - r2) + e, bs1); });
-            } else {
-                acc = resid_bias(Xp, PSX, LDX, (R - r2) + e, bs1);
-            }
-            if (i == cnt - 1) mrfp_load_w<G, K>(W, wptr(j, 1, K));  // conv2's fragments travel under the last epilogue and the barrier
-            if (j > 0 && i == 0) __syncthreads();  // every wave is done reading the previous resblock's x1
-            const int t = t0 - r2 + e;
-            const bool live = t >= 0 && t < len;
-            float v[4];
+        for (int u = 0; u < RB; ++u)
             MI355_UNROLL
-            for (int r = 0; r < 4; ++r) v[r] = live ? fmaxf(acc[r], 0.1f * acc[r]) : 0.0f;
-            uint2 h, m, l;
-            split3_pk(v[0], v[1], h.x, m.x, l.x);
-            split3_pk(v[2], v[3], h.y, m.y, l.y);
-            uint2* p2 = reinterpret_cast<uint2*>(X1p + (gq * 4 + q) * LD1 + e) + hh;
+            for (int e = 0; e < 8; ++e) sv[u][e] = xs[(long)(8 * (spart * RB + u) + e) * a.x_ld];
+        SCHED_FENCE();  // the 8 RB loads stay in flight together
+        MI355_UNROLL
+        for (int u = 0; u < RB; ++u) {
+            float v[8];
+            MI355_UNROLL
+            for (int e = 0; e < 8; ++e) v[e] = s_in ? lrelu_f(sv[u][e], 0.1f) : 0.0f;
+            uint4 h, m, l;
+            MRFP_SPLIT(v[0], v[1], h.x, m.x, l.x);
+            MRFP_SPLIT(v[2], v[3], h.y, m.y, l.y);
+            MRFP_SPLIT(v[4], v[5], h.z, m.z, l.z);
+            MRFP_SPLIT(v[6], v[7], h.w, m.w, l.w);
+            const int o = (spart * RB + u) * LDX + scol;
+            Xp[o] = h;
+            Xp[PSX + o] = m;
+            Xp[2 * PSX + o] = l;
+        }
+    };
+    static_assert(4 * G <= 2 * RB, "one batch of RB records per thread covers a column (at most two column sets)");
+
+
+    // conv1's epilogue of one tile in three pieces (dealt out between the next tile's MFMAs): x1 (zero outside the row) ->
+    // leaky-relu -> three bf16 planes (truncation split: v = h + m + l exactly) -> one 8-byte store per plane
+    struct Pend { f32x4 x1; int e; bool live; float v[4], r[4]; uint2* base; };
+    auto epi_piece = [&](Pend& pd, int piece) MI355_INLINE_LAMBDA {
+        if (LAB_ABLATE(a) & 16) return;
+        uint2* p2 = pd.base + 2 * pd.e;
+        if (piece == 0) {
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) pd.v[r] = pd.live ? fmaxf(pd.x1[r], 0.1f * pd.x1[r]) : 0.0f;
+        } else if (piece == 1) {
+            unsigned u[4];
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) u[r] = __float_as_uint(pd.v[r]);
+            uint2 h;
+            h.x = pack_hi16(u[0], u[1]);
+            h.y = pack_hi16(u[2], u[3]);
             p2[0] = h;
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) pd.r[r] = pd.v[r] - __uint_as_float(u[r] & 0xffff0000u);
+            uint2 m;
+            m.x = pack_hi16(__float_as_uint(pd.r[0]), __float_as_uint(pd.r[1]));
+            m.y = pack_hi16(__float_as_uint(pd.r[2]), __float_as_uint(pd.r[3]));
             p2[2 * PS1] = m;
+        } else if (piece == 2) {
+            float s4[4];
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) s4[r] = pd.r[r] - __uint_as_float(__float_as_uint(pd.r[r]) & 0xffff0000u);
+            uint2 l;
+            l.x = pack_hi16(__float_as_uint(s4[0]), __float_as_uint(s4[1]));
+            l.y = pack_hi16(__float_as_uint(s4[2]), __float_as_uint(s4[3]));
             p2[4 * PS1] = l;
         }
-        if (cnt == 0) {  // (never with the supported shapes: every column group owns at least one conv1 tile)
-            mrfp_load_w<G, K>(W, wptr(j, 1, K));
-            if (j > 0) __syncthreads();
-        }
-        __syncthreads();
-        // ---- conv2 into the output registers: out += x1 + bias + conv(lrelu(x1)); this wave: tiles cg NT2 .. + NT2 - 1
-        const float* bs2 = BS + (j * 2 + 1) * C;
-        MI355_UNROLL
-        for (int i = 0; i < NT2; ++i) {
-            const int c = (cg * NT2 + i) * 16 + n;
-            auto init = [&]() MI355_INLINE_LAMBDA {
-                f32x4 r = resid_bias(X1p, PS1, LD1, c + r2, bs2);
-                MI355_UNROLL
-                for (int rr = 0; rr < 4; ++rr) r[rr] += out[i][rr];
-                return r;
-            };
-            if (!(LAB_ABLATE(a) & 1)) out[i] = mrfp_tile<K, G>(W, X1p + q * LD1 + c, PS1, LD1, d2, init);
-            else out[i] = init();
-        }
-        if constexpr (KNEXT > 0) mrfp_load_w<G, KNEXT>(W, wptr(j + 1, 0, KNEXT));  // the next resblock's first conv
     };
-
-    resblock(std::integral_constant<int, K0>{}, std::integral_constant<int, K1>{}, std::integral_constant<int, 0>{});
-    if constexpr (K1 > 0) resblock(std::integral_constant<int, K1>{}, std::integral_constant<int, K2>{}, std::integral_constant<int, 1>{});
-    if constexpr (K2 > 0) resblock(std::integral_constant<int, K2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-
+    auto no_fill = [&](int) MI355_INLINE_LAMBDA {};
     const float n_rb = (float)a.nrb;
-    auto store_all = [&](auto MEAN) MI355_INLINE_LAMBDA {  // the mean / scale choice once, outside the loops
+
+    for (; item < item_end; item += nslot) {
+        // lane / wave coordinates, re-derived per item from values the optimiser cannot see through: everything computed
+        // from them stays inside the loop body (hoisted out, the invariant addresses of ~50 unrolled tiles spill)
+        int lane_o = lane, wid_o = wid;
+        OPAQUE_V(lane_o);
+        OPAQUE_S(wid_o);
+        const int cg = wid_o / NWM;
+        const int q = lane_o >> 4, n = lane_o & 15;
+        spart = wid_o / wpc;
+        scol = wid_o * 64 + lane_o - spart * wpc * 64;
+        stager = spart < nparts && scol < LDX && spart * RB < 4 * G;
+        const int gq = mt >> 1, hh = mt & 1;
+        const int co0 = 32 * gq + 8 * q + 4 * hh;  // this lane's four output channels co0 .. co0 + 3 = half hh of record (gq, q)
+        const int b = WAVE_UNIFORM(item / ntile), t0 = WAVE_UNIFORM((item - b * ntile) * T_B);  // scalar registers, whatever the division ran on
+        int len = a.len ? a.len[b] : a.T;
+        if (len > a.T) len = a.T;
+        len = WAVE_UNIFORM(len);
+        const int last = len > 0 ? len - 1 : 0;
+        const float* xb = a.x + (long)b * a.x_bs;
+        const int item_next = item + nslot;
+        const bool more = item_next < item_end;  // wave-uniform
+
+        stage_item(b, t0, len);
+        __syncthreads();  // x is staged; every wave is done with the previous item's x1
+
+        f32x4 out[NT2];
         MI355_UNROLL
-        for (int i = 0; i < NT2; ++i) {
-            const int t = t0 + (cg * NT2 + i) * 16 + n;
-            if (t < a.T && !(LAB_ABLATE(a) & 4)) {
-                float* yp = a.y + (long)b * a.y_bs + (long)co0 * a.y_ld + t;
-                MI355_UNROLL
-                for (int r = 0; r < 4; ++r) yp[(long)r * a.y_ld] = decltype(MEAN)::value ? out[i][r] / n_rb : out[i][r] * a.out_scale;
+        for (int i = 0; i < NT2; ++i)
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) out[i][r] = 0.0f;
+
+        auto resblock = [&](auto KC, auto KN, auto JC) MI355_INLINE_LAMBDA {
+            constexpr int K = decltype(KC)::value, KNEXT = decltype(KN)::value, j = decltype(JC)::value;
+            constexpr bool last_rb = KNEXT == 0;  // after it: the next item's first conv (K0)
+            constexpr int KAFTER = last_rb ? K0 : KNEXT;
+            static_assert(K >= 3, "the epilogue pieces ride in the first three steps of the next tile");
+            const int d1 = SH::d1(j) ? SH::d1(j) : a.d1[j], d2 = SH::d2(j) ? SH::d2(j) : a.d2[j];
+            const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
+            const int nh = (r2 + 15) >> 4;  // halo tiles per side
+            // X1 column of this wave's conv1 tile `ti`: interior tiles (ti < NT2) on conv2's grid, halo tile m = ti - NT2 is
+            // number hx = cg + NWC m of the 2 nh halo tiles: left ones from column 0 up, right ones from T_B + 2 r2 down
+            auto tile_e0 = [&](int ti) MI355_INLINE_LAMBDA {
+                if (ti < NT2) return r2 + (cg * NT2 + ti) * 16;
+                const int hx = cg + NWC * (ti - NT2);
+                return hx < nh ? hx * 16 : T_B + 2 * r2 - 16 * (hx - nh + 1);
+            };
+            auto tile_on = [&](int ti) MI355_INLINE_LAMBDA { return ti < NT2 || cg + NWC * (ti - NT2) < 2 * nh; };  // wave-uniform
+            const float* bs1 = BS + (j * 2 + 0) * C;
+            const float4 bv1 = *reinterpret_cast<const float4*>(bs1 + co0);
+            const float b1[4] = {bv1.x, bv1.y, bv1.z, bv1.w};
+            // ---- conv1: raw x at every tile's own columns (global, clamped: columns outside the row are masked in the epilogue)
+            f32x4 acc1[NT1];
+            MI355_UNROLL
+            for (int ti = 0; ti < NT1; ++ti) {
+                if (tile_on(ti)) {
+                    const int t = t0 - r2 + tile_e0(ti) + n;
+                    const int tc = t < 0 ? 0 : (t > last ? last : t);
+                    MI355_UNROLL
+                    for (int r = 0; r < 4; ++r) acc1[ti][r] = (LAB_ABLATE(a) & 32) ? 0.0f : xb[(long)(co0 + r) * a.x_ld + tc];
+                }
             }
-        }
-    };
-    if (a.out_scale > 0.0f) store_all(std::false_type{});
-    else store_all(std::true_type{});
+            Pend pend;
+            pend.base = reinterpret_cast<uint2*>(X1p + (gq * 4 + q) * LD1) + hh;  // this lane's half records of x1, column 0
+            MI355_UNROLL
+            for (int g = 0; g < G; ++g) {
+                // the fragments this k-group's last tile pulls in behind its steps: the conv's next k-group, or conv2's first
+                const uint4* wn = g + 1 < G ? wptr(j, 0, K, g + 1) : wptr(j, 1, K, 0);
+                // order: interior tile 0, the halo tiles, interior tiles 1 .. NT2 - 1 (first and last are unconditional)
+                MI355_UNROLL
+                for (int oi = 0; oi < NT1; ++oi) {
+                    const int ti = oi == 0 ? 0 : (oi <= NHMAX ? NT2 + oi - 1 : oi - NHMAX);
+                    if (tile_on(ti)) {
+                        const int e = tile_e0(ti) + n;
+                        f32x4 ab = acc1[ti], as;
+                        MI355_UNROLL
+                        for (int r = 0; r < 4; ++r) {
+                            if (g == 0) ab[r] += b1[r];
+                            as[r] = 0.0f;
+                        }
+                        const uint4* xq = Xp + (g * 4 + q) * LDX + (R - r2 - r1) + e;
+                        const bool fin = g == G - 1;
+                        if (!(LAB_ABLATE(a) & 1)) {
+                            auto fl = [&](int s) MI355_INLINE_LAMBDA { if (fin && oi > 0) epi_piece(pend, s); };
+                            if (oi == NT1 - 1 && !(LAB_ABLATE(a) & 8)) mrfp_sweep<K, AH, K>(ab, as, W, xq, PSX, d1, fl, wn, lane_o, TAP);
+                            else mrfp_sweep<K, AH, 0>(ab, as, W, xq, PSX, d1, fl, wn, lane_o, TAP);
+                        } else {
+                            if (fin && oi > 0) { epi_piece(pend, 0); epi_piece(pend, 1); epi_piece(pend, 2); }
+                            if (oi == NT1 - 1 && !(LAB_ABLATE(a) & 8)) mrfp_load_w<K>(W, wn, lane_o, TAP);
+                        }
+                        MI355_UNROLL
+                        for (int r = 0; r < 4; ++r) acc1[ti][r] = ab[r] + as[r];
+                        if (fin) {
+                            if (j > 0 && oi == 0) __syncthreads();  // every wave is done reading the previous resblock's x1
+                            const int t = t0 - r2 + e;
+                            pend.x1 = acc1[ti];
+                            pend.e = e;
+                            pend.live = t >= 0 && t < len;
+                        }
+                    }
+                }
+            }
+            epi_piece(pend, 0); epi_piece(pend, 1); epi_piece(pend, 2);  // the last tile's epilogue has no MFMAs left to hide behind
+            __syncthreads();
+            // ---- conv2 into the output registers: out += x1 + bias + conv(lrelu(x1)); this wave: tiles cg NT2 .. + NT2 - 1
+            const float* bs2 = BS + (j * 2 + 1) * C;
+            const float4 bv2 = *reinterpret_cast<const float4*>(bs2 + co0);
+            const float b2[4] = {bv2.x, bv2.y, bv2.z, bv2.w};
+            MI355_UNROLL
+            for (int g = 0; g < G; ++g) {
+                const uint4* wn = g + 1 < G ? wptr(j, 1, K, g + 1) : (last_rb ? wptr(0, 0, K0, 0) : wptr(j + 1, 0, KNEXT, 0));
+                MI355_UNROLL
+                for (int i = 0; i < NT2; ++i) {
+                    f32x4 ab = out[i], as;
+                    MI355_UNROLL
+                    for (int r = 0; r < 4; ++r) {
+                        if (g == 0) ab[r] += acc1[i][r] + b2[r];  // the residual: raw x1 of the same columns, still in this wave's registers
+                        as[r] = 0.0f;
+                    }
+                    const uint4* xq = X1p + (g * 4 + q) * LD1 + (cg * NT2 + i) * 16 + n;
+                    if (!(LAB_ABLATE(a) & 1)) {
+                        if (i == NT2 - 1 && !(LAB_ABLATE(a) & 8)) {
+                            if (g + 1 < G) mrfp_sweep<K, AH, K>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
+                            else if (!last_rb || more) mrfp_sweep<K, AH, KAFTER>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
+                            else mrfp_sweep<K, AH, 0>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
+                        } else {
+                            mrfp_sweep<K, AH, 0>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
+                        }
+                    } else if (i == NT2 - 1 && !(LAB_ABLATE(a) & 8)) {
+                        if (g + 1 < G) mrfp_load_w<K>(W, wn, lane_o, TAP);
+                        else if (!last_rb || more) mrfp_load_w<KAFTER>(W, wn, lane_o, TAP);
+                    }
+                    MI355_UNROLL
+                    for (int r = 0; r < 4; ++r) out[i][r] = ab[r] + as[r];
+                }
+            }
+        };
+
+        resblock(std::integral_constant<int, K0>{}, std::integral_constant<int, K1>{}, std::integral_constant<int, 0>{});
+        if constexpr (K1 > 0) resblock(std::integral_constant<int, K1>{}, std::integral_constant<int, K2>{}, std::integral_constant<int, 1>{});
+        if constexpr (K2 > 0) resblock(std::integral_constant<int, K2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+
+        auto store_all = [&](auto MEAN) MI355_INLINE_LAMBDA {  // the mean / scale choice once, outside the loops
+            MI355_UNROLL
+            for (int i = 0; i < NT2; ++i) {
+                const int t = t0 + (cg * NT2 + i) * 16 + n;
+                if (t < a.T && !(LAB_ABLATE(a) & 4)) {
+                    float* yp = a.y + (long)b * a.y_bs + (long)co0 * a.y_ld + t;
+                    MI355_UNROLL
+                    for (int r = 0; r < 4; ++r) yp[(long)r * a.y_ld] = decltype(MEAN)::value ? out[i][r] / n_rb : out[i][r] * a.out_scale;
+                }
+            }
+        };
+        if (a.out_scale > 0.0f) store_all(std::false_type{});
+        else store_all(std::true_type{});
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -300,9 +439,10 @@ void pack_conv_weights_p16(const float* w, int Cout, int Cin, int K, uint32_t* o
 }
 
 namespace {
-struct GeoP { int T_B, NWC; };
+struct GeoP { int T_B, NWC, NHMAX; };
 inline bool geometry_p(int C, GeoP* g) {
-    if (C == 32) { *g = {320, 4}; return true; }
+    if (C == 32) { *g = {320, 4, 2}; return true; }  // 5 interior + at most 2 halo tiles of conv1 per wave
+    if (C == 64) { *g = {96, 2, 3}; return true; }   // 3 interior + at most 3 halo tiles
     return false;
 }
 // halo, row pitches (multiples of 16 columns: conflict-free 16-byte fragment reads) and LDS bytes of a stage
@@ -313,11 +453,12 @@ inline bool shape_p(int C, int nrb, const int* k, const int* d1, const int* d2, 
         const int r1 = (k[j] - 1) / 2 * d1[j], r2 = (k[j] - 1) / 2 * d2[j];
         Rm = Rm > r1 + r2 ? Rm : r1 + r2;
         r2max = r2max > r2 ? r2max : r2;
-        if ((g.T_B + 2 * r2 + 15) / 16 < g.NWC) return false;
+        const int nh = (r2 + 15) / 16;  // halo tiles per side, dealt round-robin to the column groups
+        if ((2 * nh + g.NWC - 1) / g.NWC > g.NHMAX || 16 * nh > g.T_B) return false;
     }
     *R = Rm;
-    *ldx = (g.T_B + 2 * Rm + 15 + 15) & ~15;  // + 15: conv1's last (rounded-up) tile reads inside its row
-    *ld1 = ((g.T_B + 2 * r2max + 15) / 16) * 16;
+    *ldx = (g.T_B + 2 * Rm + 15) & ~15;
+    *ld1 = (g.T_B + 2 * r2max + 15) & ~15;
     *lds = (size_t)(C / 32) * 4 * 3 * 16 * (size_t)(*ldx + *ld1) + (size_t)nrb * 2 * C * sizeof(float);
     return *lds <= MRFP_LDS_LIMIT && *ldx <= 512;  // (the staging loop: one column per thread)
 }
@@ -348,20 +489,48 @@ void set_max_dynamic_lds(const void* fn, int bytes) {
 #endif
 }
 
+int current_device_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipDeviceProp_t p;
+        n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 void launch_mrf_p(MrfArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     GeoP g;
     size_t shmem = 0;
     if (!geometry_p(a.C, &g) || a.nrb < 1 || a.nrb > MRF_MAX_RB || !shape_p(a.C, a.nrb, a.k, a.d1, a.d2, g, &a.R, &a.ldx, &a.ld1, &shmem))
         throw std::runtime_error("mrf_p: unsupported stage shape");
-    dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
+    const long nitems = (long)((a.T + g.T_B - 1) / g.T_B) * a.B;
+    const int cus = current_device_cu_count();
+    dim3 grid((unsigned)(nitems < cus ? nitems : cus));  // persistent: one workgroup per CU (160 KiB of LDS each)
+#ifdef MI355_LAB
+    {
+        const char* ab = getenv("MI355VITS_MRF_ABLATE");
+        a.ablate = ab ? (int)strtol(ab, nullptr, 0) : 0;
+    }
+#endif
     auto go = [&](auto kfn) {
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)MRFP_LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     };
     const int k1 = a.nrb > 1 ? a.k[1] : 0, k2 = a.nrb > 2 ? a.k[2] : 0;
-    if (a.k[0] == 3 && k1 == 5 && k2 == 7) go(k_mrf_p<32, 2, 4, 5, 3, 5, 7>);
-    else throw std::runtime_error("mrf_p: unsupported tap counts");
+    if (!(a.k[0] == 3 && k1 == 5 && k2 == 7)) throw std::runtime_error("mrf_p: unsupported tap counts");
+    const bool low = a.d1[0] == 1 && a.d2[0] == 2 && a.d1[1] == 2 && a.d2[1] == 6 && a.d1[2] == 3 && a.d2[2] == 12;  // the "_low" voices
+    if (a.C == 32) {
+        if (low && a.ldx == 416 && a.ld1 == 400) go(k_mrf_p<32, 2, 4, 5, 2, 3, 5, 7, MrfPShape<416, 400, 1, 2, 2, 6, 3, 12>>);
+        else go(k_mrf_p<32, 2, 4, 5, 2, 3, 5, 7, MrfPDyn>);
+    } else {
+        if (low && a.ldx == 192 && a.ld1 == 176) go(k_mrf_p<64, 4, 2, 3, 3, 3, 5, 7, MrfPShape<192, 176, 1, 2, 2, 6, 3, 12>>);
+        else go(k_mrf_p<64, 4, 2, 3, 3, 3, 5, 7, MrfPDyn>);
+    }
 }
 
 }  // namespace m355

@@ -677,7 +677,8 @@ def test_fused_dds_layer_kernel(emu_lib, cfgname, monkeypatch):
 def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
     """k_mrf_p (32-channel stage, MATH_BF16X3, the default path): x / x1 as bf16 planes split ONCE in LDS, the running conv's
     weight fragments in registers, v_mfma_f32_16x16x32_bf16 tiles (320 output columns per workgroup, conv1 over the extended
-    range in 21 / 22 / 25 column tiles dealt to four column groups).  The "_low" voices' dilations, a narrow set and one with
+    range in 21 / 22 / 25 column tiles dealt to four column groups); the 64-channel stage before it runs the same kernel with two
+    k-group passes per conv (96 output columns per workgroup, 4 row tiles x 2 column groups).  The "_low" voices' dilations, a narrow set and one with
     r1 > r2; ragged batch over several workgroups (row 1 ends inside a workgroup); decoder stage taps and the waveform vs the
     oracle, and vs the split-per-tap kernel (MI355VITS_NO_MRF_P=1)."""
     import os
@@ -687,9 +688,10 @@ def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
     w = W.synthetic_weights(cfg, seed=78, frames_per_id=2.0)
     blob = W.pack(cfg, w)
     Tx = 24
-    forced = np.full((2, Tx), 4, np.int32)  # 96 frames -> 768 columns in the 32-channel stage: 3 workgroups per row
-    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (2, Tx))
-    lengths = np.array([Tx, Tx - 9])
+    forced = np.full((3, Tx), 4, np.int32)  # 96 frames -> 768 columns in the 32-channel stage: 3 items per row, 9 items on the
+    # CPU model's 8 "CUs": the persistent loop runs more than once in both stages
+    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (3, Tx))
+    lengths = np.array([Tx, Tx - 9, Tx - 1])
     outs = {}
     for tag, env in (("p", None), ("fused", "MI355VITS_NO_MRF_P")):
         if env:
@@ -701,10 +703,11 @@ def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
             outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=78, weights=w, engine=eng)
             labels = set(eng.profile_report())
             assert ("dec.mrf_p.s1" in labels) == (tag == "p") and ("dec.mrf_fused.s1" in labels) == (tag == "fused"), labels
+            assert ("dec.mrf_p" in labels) == (tag == "p"), labels  # the 64-channel stage: two k-group passes per conv
             eng.close()
         finally:
             if env:
                 del os.environ[env]
-    for bi in range(2):
+    for bi in range(3):
         L = int(outs["fused"]["lengths"][bi])
         assert rel_rms(outs["p"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
