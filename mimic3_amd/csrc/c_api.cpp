@@ -98,6 +98,7 @@ int mi355vits_create_from_buffer(const void* blob, size_t blob_bytes, int device
 int mi355vits_clone(mi355vits_handle src, mi355vits_handle* out) {
     if (out) *out = nullptr;
     if (!src) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(src->eng->mu);  // the clone reads the source's math mode / flags: not while a run or set_math is under way
     return guarded(src, [&] {
         if (!out) throw EngineError(MI355VITS_ERR_INVALID, "out must not be null");
         std::unique_ptr<mi355vits_engine> h(new mi355vits_engine());

@@ -362,10 +362,8 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         math_ = lane0.math_;
         b3_min_work_ = lane0.b3_min_work_;
         wn_b3_ = lane0.wn_b3_;
-        no_mrf_b3_ = lane0.no_mrf_b3_;
         no_mrf_p_ = lane0.no_mrf_p_;
         no_fused_dds_ = lane0.no_fused_dds_;
-        no_post_fusion_ = lane0.no_post_fusion_;
         enc_b3_ = lane0.enc_b3_;
         no_f16x2_convs_ = lane0.no_f16x2_convs_;
     } catch (...) {
@@ -384,25 +382,19 @@ void Engine::open_device(int device) {
     HIP_CHECK(hipEventCreate(&ev_start_));
     HIP_CHECK(hipEventCreate(&ev_end_));
     prof_.stream = stream_;
-    const char* fg = getenv("MI355VITS_FORCE_GENERIC");
+    const char* fg = lab_getenv("MI355VITS_FORCE_GENERIC");
     force_generic_ = fg && fg[0] == '1';
-    const char* nw = getenv("MI355VITS_NO_FUSED_WN");
+    const char* nw = lab_getenv("MI355VITS_NO_FUSED_WN");
     no_fused_wn_ = nw && nw[0] == '1';
-    const char* nf = getenv("MI355VITS_NO_FUSED_MRF");
+    const char* nf = lab_getenv("MI355VITS_NO_FUSED_MRF");
     no_fused_mrf_ = nf && nf[0] == '1';
-    const char* bw = getenv("MI355VITS_B3_MIN_WORK");
+    const char* bw = lab_getenv("MI355VITS_B3_MIN_WORK");
     b3_min_work_ = bw ? atoi(bw) : 256;
-    wn_b3_ = getenv("MI355VITS_WN_B3") != nullptr;
-    // pre-split LDS planes for the 32 / 64-channel MRF stages: measured slower than splitting on the fly (3.17 / 2.79 ms vs
-    // 2.82 / 2.71 ms per step: four waves cannot hide the plane <-> row conversions of the epilogues), so it is opt-in
-    no_mrf_b3_ = getenv("MI355VITS_MRF_PRESPLIT") == nullptr;
-    no_mrf_p_ = getenv("MI355VITS_NO_MRF_P") != nullptr;
-    no_fused_dds_ = getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
-    // opt-in: measured no faster (bench workload: 3.16 ms fused vs 2.96 + 0.22 ms) — the 32-channel MRF kernel runs one
-    // workgroup per CU, so its tail (result to LDS, barrier, 7-tap conv, store drain) is as exposed as the plain store was
-    no_post_fusion_ = getenv("MI355VITS_POST_FUSION") == nullptr;
-    enc_b3_ = getenv("MI355VITS_NO_ENC_B3") == nullptr;
-    no_f16x2_convs_ = getenv("MI355VITS_F16X2_NO_CONVS") != nullptr;
+    wn_b3_ = lab_getenv("MI355VITS_WN_B3") != nullptr;
+    no_mrf_p_ = lab_getenv("MI355VITS_NO_MRF_P") != nullptr;
+    no_fused_dds_ = lab_getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
+    enc_b3_ = lab_getenv("MI355VITS_NO_ENC_B3") == nullptr;
+    no_f16x2_convs_ = lab_getenv("MI355VITS_F16X2_NO_CONVS") != nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
     const char* mm = getenv("MI355VITS_MATH");
     if (mm && mm[0]) {
@@ -993,7 +985,6 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
     int ch = C0;
     long T = Ty;
     const int nk = c.n_resblock_kernels;
-    bool post_fused = false;  // conv_post + tanh + peak done inside the last stage's MRF kernel
     HIP_CHECK(hipMemsetAsync(d_peaks_, 0, sizeof(unsigned) * B, stream_));
     for (int i = 0; i < c.n_upsamples; ++i) {
         const int r = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
@@ -1059,29 +1050,6 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     launch_mrf_p(m, stream_);
                     n_fused = nk;
                 }
-                // MATH_BF16X3, 32 / 64 channels: the whole stage on pre-split planes
-                bool all_b3s = math_ == MATH_BF16X3 && !n_fused;  // (pre-split variant: BF16X3 only)
-                for (int j = 0; j < nk && all_b3s; ++j)
-                    for (int q = 0; q < 2; ++q) all_b3s = all_b3s && cw(S("dec.rb.%d.c.%d", i * nk + j, q)).packed_b3s != NO_OFF;
-                if (all_b3s && ((!no_mrf_b3_ && mrf_b3_supported(ch, nk, m.k, m.d1, m.d2)) || mrf_b3w_supported(ch, nk, m.k, m.d1, m.d2))) {
-                    double flops = 0;
-                    for (int j = 0; j < nk; ++j) {
-                        for (int q = 0; q < 2; ++q) {
-                            const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
-                            m.w[j][q] = P(w.packed_b3s);
-                            m.bias[j][q] = P(w.bias);
-                        }
-                        flops += 2.0 * 2.0 * B * (double)T * ch * ch * m.k[j];
-                    }
-                    m.nrb = nk;
-                    m.math = MATH_BF16X3;
-                    m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
-                    m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
-                    m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
-                    ProfScope ps(prof_, i == 1 ? "dec.mrf_b3.s1" : (i == 2 ? "dec.mrf_b3.s2" : "dec.mrf_b3"), flops, 8.0 * B * (double)T * ch);
-                    launch_mrf_b3(m, stream_);
-                    n_fused = nk;
-                }
                 // the longest prefix of resblocks whose tiles fit LDS together (128 channels: only the narrow ones)
                 int p = n_fused ? 0 : nk;
                 while (p > 0 && !(mrf_fused_supported(ch, p, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF)) --p;
@@ -1108,18 +1076,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
                     m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
-                    // last stage, whole MRF in the kernel: conv_post + tanh + peak ride along (the stage output is never
-                    // written; with debug taps on it is, through the separate kernel)
-                    double bytes = 8.0 * B * (double)T * ch;
-                    if (i == c.n_upsamples - 1 && p == nk && !taps_on_ && !no_post_fusion_ && m.math != MATH_F16X2 && mrf_fused_post_supported(ch, p, m.k, m.d1, m.d2)) {
-                        m.post_w = vec("dec.conv_post.weight");
-                        m.audio = d_audio_; m.audio_bs = T;
-                        m.audio_len = d_alen_;
-                        m.peak_bits = d_peaks_;
-                        post_fused = true;
-                        flops += 2.0 * B * (double)T * ch * MRF_POST_K;
-                        bytes = 4.0 * B * (double)T * (ch + 1);
-                    }
+                    const double bytes = 8.0 * B * (double)T * ch;
                     ProfScope ps(prof_, i == 1 ? "dec.mrf_fused.s1" : (i == 2 ? "dec.mrf_fused.s2" : (i == 0 ? "dec.mrf_fused.s0" : "dec.mrf_fused")), flops,
                                  bytes);
                     launch_mrf_fused(m, stream_);
@@ -1173,7 +1130,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         }
         tap(S("dec.mrf.%d", i).c_str(), d_bufC_, {B, ch, T});
     }
-    if (!post_fused) {
+    {
         ProfScope ps(prof_, "dec.conv_post_tanh", 2.0 * B * (double)T * ch * 7, 4.0 * B * (double)T * (ch + 1));
         launch_conv_post_tanh(d_bufC_, (long)ch * T, (int)T, vec("dec.conv_post.weight"), ch, 7, B, (int)T, d_alen_, d_audio_,
                               T, d_peaks_, stream_);

@@ -89,6 +89,14 @@ __device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
 #else
 #define LAB_ABLATE(args) 0
 #endif
+// kernel-choice / A-B switches are read from the environment only in the lab build and in the CPU model the tests run
+// on; the product library ignores them (its one knob, MI355VITS_MATH, is read when a handle is created)
+#include <cstdlib>
+#if defined(MI355_LAB) || defined(MI355_EMU)
+static inline const char* lab_getenv(const char* name) { return getenv(name); }
+#else
+static inline const char* lab_getenv(const char*) { return nullptr; }
+#endif
 
 #include <cstdint>
 #include <cstdio>

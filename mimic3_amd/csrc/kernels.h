@@ -112,26 +112,12 @@ struct MrfArgs {
     const int* len = nullptr;  // [B] rows end at their own length
     int B = 1, C = 0, T = 0;
     int R = 0, ldx = 0, ld1 = 0, vec = 0;  // filled by the launcher (R = staging halo, rounded up to 4)
-    int tb = 0, kp = 0;                    // launch_mrf_b3 (32 channels): output columns per workgroup, taps per weight segment
     float out_scale = 0.0f;  // 0: y = mean of the nrb resblocks; > 0: y = out_scale * sum (a stage fused only in part:
                              // the remaining resblocks are accumulated onto y by the conv-by-conv path)
     int ablate = 0;  // profiling only (MI355VITS_MRF_ABLATE): 1 = skip MFMA loops, 2 = skip staging, 4 = skip output
-    // last stage, 32 channels: conv_post (C -> 1, 7 taps, no bias) + tanh + per-row peak fused behind the resblocks'
-    // mean; the stage output is never written.  post_w = [C][7]; y is unused when set.
-    const float* post_w = nullptr;
-    float* audio = nullptr; long audio_bs = 0;
-    const int* audio_len = nullptr;  // [B] valid samples (peak and input mask), or null = T
-    unsigned* peak_bits = nullptr;   // [B], atomicMax of |audio| as float bits (zeroed by the caller)
 };
-constexpr int MRF_POST_K = 7;
-bool mrf_fused_post_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);
-// MATH_BF16X3 with pre-split LDS planes (C = 32 or 64); w[][] = pack_conv_weights_bf16x3_mode(..., EPI_STD, layout 1)
-bool mrf_b3_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
-bool mrf_b3w_supported(int C, int nrb, const int* k, const int* d1, const int* d2);  // 32 channels: weights in LDS too (default path)
-void launch_mrf_b3(MrfArgs a, hipStream_t s);
-
 // MATH_BF16X3 with every element split once (kernels_mrfp.cpp): bf16 planes in LDS, the running conv's weight fragments in
 // registers, v_mfma_f32_16x16x32_bf16 tiles.  w[][] = pack_conv_weights_p16 fragments.  C = 32; taps in {3, 5, 7}.
 size_t p16_packed_words(int Cout, int Cin, int K);

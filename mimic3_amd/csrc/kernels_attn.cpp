@@ -313,7 +313,7 @@ void launch_rel_attention_mfma(const float* qkv, const float* emb_rel_k, const f
                                int T, int H, int n_heads, int window, float* out, hipStream_t s) {
     if (!rel_attention_mfma_supported(T, H, n_heads, window)) throw std::runtime_error("rel_attention_mfma: unsupported shape");
     dim3 grid((T + 31) / 32, n_heads, B);
-    static const bool one_wave = getenv("MI355VITS_ATTN_ONE_WAVE") != nullptr;  // the older single-wave kernel
+    static const bool one_wave = lab_getenv("MI355VITS_ATTN_ONE_WAVE") != nullptr;  // the older single-wave kernel
     if (!one_wave) {
         const size_t sh4 = (32 * 32 + 2 * 4 * 32 + 4 * 16 * 64) * sizeof(float);
         if (T <= 128) {

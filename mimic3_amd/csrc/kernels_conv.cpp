@@ -733,7 +733,7 @@ template <int MT, int NT, int WM, int WN, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], float* xs, int b, int t0, int tile0, int n_tiles,
                                               int wm, int wn, int brow, int bcol, int tid, int out_len) {
     constexpr int T_B = 32 * NT * WN;
-    if ((a.ablate & 4) && acc[0][0][0] != 1.2345f) return;
+    if ((LAB_ABLATE(a) & 4) && acc[0][0][0] != 1.2345f) return;
     if (EPI == EPI_STD && a.ovec) {
         // Through LDS (free after the last chunk) so that global memory sees whole rows: the C/D fragment gives a lane
         // one column of 16 rows, i.e. 128-byte pieces per store instruction; re-read row-major, every lane moves 16
@@ -898,9 +898,9 @@ __global__ __launch_bounds__(256) MIN_WAVES_PER_SIMD(MT * NT >= 4 ? 3 : 4) void 
     const int brow = lane >> 5, bcol = lane & 31;
     for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
         // ---- stage x[c0:c0+CI_C, ts : ts+LD) with mask + leaky-relu fused
-        if (!(a.ablate & 2)) stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
+        if (!(LAB_ABLATE(a) & 2)) stage_tile_256(xb + (long)c0 * a.x_ld, a.x_ld, CI_C, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, xs, a.vec);
         __syncthreads();
-        if (!(a.ablate & 1)) {
+        if (!(LAB_ABLATE(a) & 1)) {
             const float* wp[MT];
             MI355_UNROLL
             for (int i = 0; i < MT; ++i) {
@@ -969,9 +969,9 @@ __global__ __launch_bounds__(256) void k_conv1d_b3(ConvArgs a) {
 
     const int brow = lane >> 5, bcol = lane & 31;
     for (int c0 = 0; c0 < a.Cin; c0 += CI_C) {
-        if (!(a.ablate & 2)) stage_planes<NG, 4, H2>(xb + (long)c0 * a.x_ld, a.x_ld, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, planes, PS, tid, 256);
+        if (!(LAB_ABLATE(a) & 2)) stage_planes<NG, 4, H2>(xb + (long)c0 * a.x_ld, a.x_ld, LD, ts, Tin < in_len ? Tin : in_len, a.in_slope, planes, PS, tid, 256);
         __syncthreads();
-        if (!(a.ablate & 1)) {
+        if (!(LAB_ABLATE(a) & 1)) {
             const uint4* wp[MT];
             MI355_UNROLL
             for (int i = 0; i < MT; ++i) {
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
     // of one column tile — consecutive tile numbers, read the same input tile at the same time — share an L2 instead of
     // fetching it once per XCD (the 256 -> 128 layer has 8 row blocks per input tile).  Placement only: any mapping is correct.
     const unsigned G = gridDim.x;
-    const unsigned vid = (G % 8 == 0 && !(a.ablate & 16)) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    const unsigned vid = (G % 8 == 0 && !(LAB_ABLATE(a) & 16)) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
     const long n_mine = vid < total ? (total - vid + G - 1) / G : 0;
     const long steps = n_mine * nchunks;
     uint4* planes = reinterpret_cast<uint4*>(xs);
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
     // (in one loop with a role branch inside they would be live through the producer branch as well)
     if (producer) {
         for (long s = 0; s < steps; ++s) {
-            if (s + 1 < steps && !(a.ablate & 2)) stage(s + 1, tid - 256, 256);
+            if (s + 1 < steps && !(LAB_ABLATE(a) & 2)) stage(s + 1, tid - 256, 256);
             __syncthreads();
         }
         return;
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
             if (t >= n_tiles) t = n_tiles - 1;
             wp[ii] = reinterpret_cast<const uint4*>(a.wb3) + ((long)t * a.K * gpt + (chunk * CI_C >> 4)) * GW + lane;
         }
-        if (!(a.ablate & 1)) {
+        if (!(LAB_ABLATE(a) & 1)) {
             if constexpr (H2) h2_chunk_lean<MT, NT, NG>(acc, wp, planes + (s & 1) * 3 * PS + brow * LD + bcol + wn * NT * 32, PS, LD, a.K, gpt, a.dil);
             else b3_chunk_lean<MT, NT, NG, W1>(acc, wp, planes + (s & 1) * 3 * PS + brow * LD + bcol + wn * NT * 32, PS, LD, a.K, gpt, a.dil);
         }
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(512) void k_conv1d_b3_pc(ConvArgs a) {
                         for (int r = 0; r < 16; ++r) acc[ii][jj][r] *= 1.0f / F16X2_ACC_SCALE;
             }
         }
-        if (chunk == nchunks - 1 && (!(a.ablate & 4) || acc[0][0][0] == 1.2345f)) {
+        if (chunk == nchunks - 1 && (!(LAB_ABLATE(a) & 4) || acc[0][0][0] == 1.2345f)) {
             const long q = tile / row_blocks;
             const int ct = (int)(q % col_tiles), b = (int)(q / col_tiles);
             epi_polyphase_regs<MT, NT>(a, acc, b, ct * T_B + wn * NT * 32 + bcol, tile0, brow);
@@ -1281,10 +1281,10 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     // C_in chunk: fixed by C_in alone (largest even divisor <= 64) so that the summation order — and with it
     // every output bit — does not depend on the tile shape chosen for a batch size; only a receptive field too
     // large for LDS shrinks it further.
-    static const size_t lds_cap = [] { const char* e = getenv("MI355VITS_CONV_LDS_KB"); return (size_t)(e ? atoi(e) : 60) * 1024; }();
+    static const size_t lds_cap = [] { const char* e = lab_getenv("MI355VITS_CONV_LDS_KB"); return (size_t)(e ? atoi(e) : 60) * 1024; }();
     auto fits = [&](int c) { return (size_t)c * LD * sizeof(float) <= lds_cap; };
     int ci_c = 0;
-    static const int chunk_max = [] { const char* e = getenv("MI355VITS_CONV_CHUNK"); return e ? atoi(e) : 64; }();
+    static const int chunk_max = [] { const char* e = lab_getenv("MI355VITS_CONV_CHUNK"); return e ? atoi(e) : 64; }();
     for (int c = chunk_max; c >= 2; c -= 2)
         if (a.Cin % c == 0 && fits(c)) { ci_c = c; break; }
     if (ci_c == 0) throw std::runtime_error("conv1d_mfma: receptive field too large for LDS staging");
@@ -1295,10 +1295,10 @@ void launch_cfg(const ConvArgs& a, int n_tiles, hipStream_t s) {
     av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
     // row-major epilogue through LDS (EPI_STD): needs 16-byte aligned output / residual rows; for the polyphase
     // scatter also a phase count that divides the 32-row tile and keeps a lane's 4 rows inside one channel
-    static const bool no_ovec = getenv("MI355VITS_CONV_NO_OVEC") != nullptr;
+    static const bool no_ovec = lab_getenv("MI355VITS_CONV_NO_OVEC") != nullptr;
     // the polyphase scatter straight from registers already writes 1 KiB contiguous per store instruction (a lane owns
     // 4 consecutive samples); routing it through LDS measured slower (upsample 1.91 -> 2.34 ms/step), so it is opt-in
-    static const bool polyphase_via_lds = getenv("MI355VITS_CONV_POLY_LDS") != nullptr;
+    static const bool polyphase_via_lds = lab_getenv("MI355VITS_CONV_POLY_LDS") != nullptr;
     av.ovec = EPI == EPI_STD && !no_ovec && av.yvec &&
               (!a.res || ((a.res_ld % 4 == 0) && (a.res_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.res) % 16 == 0))) &&
               (!a.shuf_s || (polyphase_via_lds && 32 % a.shuf_s == 0 && a.shuf_s % 4 == 0 && a.Cout % 4 == 0));
@@ -1347,7 +1347,7 @@ void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
     ConvArgs av = a;
     av.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     av.yvec = (a.y_ld % 4 == 0) && (a.y_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.y) % 16 == 0);
-    static const bool no_ovec = getenv("MI355VITS_CONV_NO_OVEC") != nullptr;
+    static const bool no_ovec = lab_getenv("MI355VITS_CONV_NO_OVEC") != nullptr;
     av.ovec = EPI == EPI_STD && !no_ovec && av.yvec && !a.shuf_s &&
               (!a.res || ((a.res_ld % 4 == 0) && (a.res_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.res) % 16 == 0)));
     if (av.ovec) {
@@ -1357,14 +1357,13 @@ void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
     auto go = [&](auto kfn) {
 #ifndef MI355_EMU
         if (shmem > 64 * 1024) {
-            static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)once;
+            set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
         }
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, av);
     };
     if constexpr (EPI == EPI_STD) {
-        static const bool no_pc = getenv("MI355VITS_NO_B3_PC") != nullptr;
+        static const bool no_pc = lab_getenv("MI355VITS_NO_B3_PC") != nullptr;
         if (wide && a.shuf_s && (a.shuf_s & 3) == 0 && !no_pc && 2 * shmem <= 160 * 1024) {
             // persistent producer / consumer form: two staging buffers, one workgroup per CU
             const long total = (long)grid.x * grid.y * grid.z;
@@ -1373,8 +1372,7 @@ void launch_b3(const ConvArgs& a, int n_tiles, hipStream_t s) {
             grid = dim3((unsigned)(total < cus ? total : cus), 1, 1);
             auto gop = [&](auto kfn) {
 #ifndef MI355_EMU
-                static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)once;
+                set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
 #endif
                 LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, av);
             };
@@ -1419,7 +1417,7 @@ bool conv1d_b3_supported(int Cin, int Cout, int K, int dil, int T_hint) {
 
 void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     if (a_in.T <= 0 || a_in.B <= 0) return;
-    static const int ablate = getenv("MI355VITS_CONV_ABLATE") ? atoi(getenv("MI355VITS_CONV_ABLATE")) : 0;
+    static const int ablate = lab_getenv("MI355VITS_CONV_ABLATE") ? atoi(lab_getenv("MI355VITS_CONV_ABLATE")) : 0;
     ConvArgs a = a_in;
     a.ablate = ablate;
     if (!conv1d_mfma_supported(a.Cin, a.Cout, a.K, a.dil)) throw std::runtime_error("conv1d_mfma: unsupported shape");
@@ -1456,7 +1454,7 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     struct Cand { int MT, NT, WM, WN; };
     static const Cand forced = [] {
         Cand f{0, 0, 0, 0};
-        const char* e = getenv("MI355VITS_CONV_CFG");
+        const char* e = lab_getenv("MI355VITS_CONV_CFG");
         if (e) sscanf(e, "%d,%d,%d,%d", &f.MT, &f.NT, &f.WM, &f.WN);
         return f;
     }();
@@ -1475,7 +1473,7 @@ void launch_conv1d_mfma(const ConvArgs& a_in, hipStream_t s) {
     };
     // LDS-free streaming kernel: pointwise convs, and short sequences (encoder FFN) where the grid is too small to
     // hide the stage/barrier cycle of the staged kernel
-    static const int poly_direct_cin = getenv("MI355VITS_POLY_DIRECT_CIN") ? atoi(getenv("MI355VITS_POLY_DIRECT_CIN")) : 64;
+    static const int poly_direct_cin = lab_getenv("MI355VITS_POLY_DIRECT_CIN") ? atoi(lab_getenv("MI355VITS_POLY_DIRECT_CIN")) : 64;
     const bool direct = a.epi != EPI_GATE && ((a.K * (a.Cin >> 1)) % 8) == 0 &&
                         (a.shuf_s ? (a.K <= 2 && a.Cin <= poly_direct_cin && (a.shuf_s & 3) == 0)
                                   : (a.K == 1 || (a.K <= 3 && a.T <= 512 && !a.fixed_rule)));
@@ -1769,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh_vec(const float* __restr
 void launch_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, int Cin, int K, int B, int L,
                            const int* valid_len, float* audio, long audio_bs, unsigned* peak_bits, hipStream_t s) {
     if (L <= 0 || B <= 0) return;
-    static const bool no_vec = getenv("MI355VITS_CONV_POST_STAGED") != nullptr;
+    static const bool no_vec = lab_getenv("MI355VITS_CONV_POST_STAGED") != nullptr;
     const bool aligned = (x_ld % 4 == 0) && (x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                          (audio_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(audio) % 16 == 0);
     if (aligned && K <= 9 && (K & 1) && !no_vec) {

@@ -253,15 +253,9 @@ __device__ __forceinline__ void mrf_conv2(f32x16 (&out)[NA], const float* __rest
 // ds_read of an unrolled k-step group then carries its offset as an immediate; 0 = take them from the arguments.
 // MATH: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f32 operands split 3 x bf16, six products on the bf16 MFMA,
 // 2 = the same with the weights' leading bf16 term only (three products; "bf16 weights").
-// POST (32 channels, the last stage): the workgroup's 512 columns of mean(resblocks) go to LDS (the x tile's space)
-// instead of global memory, and 504 of them — the tile minus conv_post's halo of 3 (4, to keep the staging aligned) per
-// side — become audio samples: leaky-relu(0.01), 7-tap 32 -> 1 conv in the order of k_conv_post_tanh_vec (same bits),
-// tanh, per-row peak.  Saves the stage output's write, its re-read and a launch.
-template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0, int MATH = 0, bool POST = false>
+template <int WM, int WT, int N2, int NT1MAX, int NT2MAX, int LDXC = 0, int LD1C = 0, int MATH = 0>
 __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     static_assert(WM * WT == 8, "8 waves per workgroup");
-    static_assert(!POST || WM == 1, "conv_post is fused behind the 32-channel stage only");
-    static_assert(!POST || MATH != 3, "MATH_F16X2 keeps its output accumulators scaled: no conv_post fusion");
     constexpr float XS = MATH == 3 ? F16X2_X_SCALE : 1.0f;          // scale of the values kept in the LDS tiles
     constexpr float OUT_UNSCALE = MATH == 3 ? 1.0f / F16X2_ACC_SCALE : 1.0f;
     static_assert(NT1MAX == 3 && NT2MAX == 2, "static dispatch below");
@@ -279,7 +273,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
     const int wt = (WM == 1) ? wid : (WM == 2 ? ((wid >> 2) * 2 + (wid & 1)) : ((wid & 1) ^ (wid >> 2)));
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.y;
-    const int t0 = POST ? blockIdx.x * (T_B - 8) - 4 : blockIdx.x * T_B;
+    const int t0 = blockIdx.x * T_B;
     int len = a.len ? a.len[b] : a.T;
     if (len > a.T) len = a.T;
 
@@ -287,12 +281,7 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         const int j = i / (2 * C), q = (i / C) & 1, c = i % C;
         BS[i] = a.bias[j][q][c];
     }
-    // POST: conv_post's weights as [C][8] (7 taps + a zero; 32-byte rows, 16-byte aligned: two broadcast ds_read_b128 per channel)
-    float* PW = BS + ((a.nrb * 2 * C + 3) & ~3);
-    if constexpr (POST) {
-        if (tid < C * 8) PW[tid] = (tid & 7) < MRF_POST_K ? a.post_w[(tid >> 3) * MRF_POST_K + (tid & 7)] : 0.0f;
-    }
-    if (!(a.ablate & 2)) stage_tile_pk<512>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec, XS);
+    if (!(LAB_ABLATE(a) & 2)) stage_tile_pk<512>(a.x + (long)b * a.x_bs, a.x_ld, C, LDX, t0 - R, len, 0.1f, X, a.vec, XS);
     __syncthreads();
 
     f32x16 out[NT2MAX];
@@ -311,9 +300,9 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         nt1 = n1 > wt ? (n1 - wt + WT - 1) / WT : 0;
         const float* wp = a.w[j][0];
         const float* bs = BS + (j * 2 + 0) * C;
-        if (nt1 >= 3) mrf_conv1_compute<MATH, 3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
-        else if (nt1 == 2) mrf_conv1_compute<MATH, 2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
-        else if (nt1 == 1) mrf_conv1_compute<MATH, 1, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, a.ablate);
+        if (nt1 >= 3) mrf_conv1_compute<MATH, 3, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, LAB_ABLATE(a));
+        else if (nt1 == 2) mrf_conv1_compute<MATH, 2, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, LAB_ABLATE(a));
+        else if (nt1 == 1) mrf_conv1_compute<MATH, 1, NT1MAX, CP, WT>(acc1, wp, bs, X, LDX, R, r1, r2, K, d1, wm, wt, brow, bcol, LAB_ABLATE(a));
     };
 
     conv1_compute(0);
@@ -340,85 +329,18 @@ __global__ __launch_bounds__(512) void k_mrf_fused(MrfArgs a) {
         {
             const float* wp = a.w[j][1];
             const float* bs = BS + (j * 2 + 1) * C;
-            if (nt2 >= 2) mrf_conv2<MATH, 2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
-            else if (nt2 == 1) mrf_conv2<MATH, 1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, a.ablate);
+            if (nt2 >= 2) mrf_conv2<MATH, 2, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, LAB_ABLATE(a));
+            else if (nt2 == 1) mrf_conv2<MATH, 1, NT2MAX, CP, WT>(out, wp, bs, X1, LD1, r2, K, d2, wm, wt, brow, bcol, LAB_ABLATE(a));
         }
         if (j + 1 < a.nrb) conv1_compute(j + 1);
     }
 
     const float n = (float)a.nrb;
-    if constexpr (POST) {
-        // X is free: its last readers (conv1 of the last resblock) passed the barrier in front of the last conv2
-        constexpr int YLD = T_B + 8;  // +8: the two half-waves (rows 4 apart) land on different banks
-        float* Y = X;
-        int vl = a.audio_len ? a.audio_len[b] : a.T;
-        if (vl > a.T) vl = a.T;
-        auto put = [&](auto MEAN) {  // the mean / scale choice once, outside the loops
-            MI355_UNROLL
-            for (int i = 0; i < NT2MAX; ++i) {
-                if (i < nt2) {
-                    const int c0 = (wt + WT * i) * 32 + bcol;
-                    const int t = t0 + c0;
-                    const bool live = t >= 0 && t < vl;
-                    MI355_UNROLL
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = (r & 3) + 8 * (r >> 2) + 4 * brow;
-                        const float v = decltype(MEAN)::value ? out[i][r] / n : out[i][r] * a.out_scale;
-                        Y[co * YLD + c0 + 1] = live ? (v >= 0.0f ? v : v * 0.01f) : 0.0f;
-                    }
-                }
-            }
-        };
-        if (a.out_scale > 0.0f) put(std::false_type{});
-        else put(std::true_type{});
-        __syncthreads();
-        // two consecutive output samples per thread, t = t0 + 4 + q and the next (q even, q < T_B - 8): their eight input
-        // columns q + 1 .. q + 8 are four 8-byte LDS reads per channel (Y is stored one column to the right: 8-byte aligned)
-        const int q = 2 * tid;
-        const int t = t0 + 4 + q;
-        float pk = 0.0f;
-        if (q < T_B - 8 && t < a.T && !(a.ablate & 4)) {
-            float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll 4
-            for (int c = 0; c < C; ++c) {
-                const float2* yr = reinterpret_cast<const float2*>(Y + c * YLD + q + 2);
-                const float2 p0 = yr[0], p1 = yr[1], p2 = yr[2], p3 = yr[3];
-                const float yv[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
-                const float4 w0 = reinterpret_cast<const float4*>(PW)[2 * c], w1 = reinterpret_cast<const float4*>(PW)[2 * c + 1];
-                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                MI355_UNROLL
-                for (int k = 0; k < MRF_POST_K; ++k) {
-                    acc0 = fmaf(wv[k], yv[k], acc0);
-                    acc1 = fmaf(wv[k], yv[k + 1], acc1);
-                }
-            }
-            const float y0 = tanhf(acc0), y1 = tanhf(acc1);
-            if (t < vl) pk = fabsf(y0);
-            if (t + 1 < vl) pk = fmaxf(pk, fabsf(y1));
-            float* ap = a.audio + (long)b * a.audio_bs + t;
-            if (t + 1 < a.T && (a.audio_bs & 1) == 0) {
-                *reinterpret_cast<float2*>(ap) = make_float2(y0, y1);
-            } else {
-                ap[0] = y0;
-                if (t + 1 < a.T) ap[1] = y1;
-            }
-        }
-        pk = wave_reduce_max(pk);
-        if (lane == 0) BS[wid] = pk;  // the biases are no longer needed
-        __syncthreads();
-        if (tid == 0) {
-            float m = BS[0];
-            MI355_UNROLL
-            for (int w8 = 1; w8 < 8; ++w8) m = fmaxf(m, BS[w8]);
-            atomicMax(a.peak_bits + b, __float_as_uint(m));
-        }
-        return;
-    }
     auto store_all = [&](auto MEAN) {  // the mean / scale choice once, outside the loops
         MI355_UNROLL
         for (int i = 0; i < NT2MAX; ++i) {
             const int t = t0 + (wt + WT * i) * 32 + bcol;
-            if (i < nt2 && t < a.T && !(a.ablate & 4)) {
+            if (i < nt2 && t < a.T && !(LAB_ABLATE(a) & 4)) {
                 float* yp = a.y + (long)b * a.y_bs + (long)(wm * 32 + 4 * brow) * a.y_ld + t;
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r) {
@@ -463,10 +385,6 @@ bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int*
     return ((size_t)C * (ldx + ld1) + (size_t)nrb * 2 * C) * sizeof(float) <= LDS_LIMIT;
 }
 
-bool mrf_fused_post_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
-    return C == 32 && mrf_fused_supported(C, nrb, k, d1, d2);
-}
-
 void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     Geo g;
@@ -483,33 +401,15 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
     a.ld1 = ((g.T_B + 2 * r2max + 31) / 32) * 32;
     a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
     {
-        const char* ab = getenv("MI355VITS_MRF_ABLATE");
+        const char* ab = lab_getenv("MI355VITS_MRF_ABLATE");
         a.ablate = ab ? atoi(ab) : 0;
     }
-    const bool post = a.post_w != nullptr;
-    const size_t shmem = ((size_t)a.C * (a.ldx + a.ld1) + (size_t)a.nrb * 2 * a.C + (post ? a.C * 8 + 4 : 0)) * sizeof(float);
-    if (post && !(a.C == 32 && a.audio && a.peak_bits && (size_t)a.C * (g.T_B + 8) <= (size_t)a.C * a.ldx && shmem <= LDS_LIMIT))
-        throw std::runtime_error("mrf_fused: conv_post fusion needs the 32-channel stage");
-    dim3 grid(post ? (a.T + g.T_B - 9) / (g.T_B - 8) : (a.T + g.T_B - 1) / g.T_B, a.B);
+    const size_t shmem = ((size_t)a.C * (a.ldx + a.ld1) + (size_t)a.nrb * 2 * a.C) * sizeof(float);
+    dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
     auto go = [&](auto kfn) {
-#ifndef MI355_EMU
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-        (void)once;
-#endif
+        set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     };
-    if (post) {  // generic row pitches except for the default math on the "_low" shapes
-        if (a.math == MATH_BF16X3) {
-            if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1, true>);
-            else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 1, true>);
-        } else if (a.math == MATH_BF16W) {
-            go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 2, true>);
-        } else {
-            if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 0, true>);
-            else go(k_mrf_fused<1, 8, 16, 3, 2, 0, 0, 0, true>);
-        }
-        return;
-    }
     if (a.math == MATH_F16X2) {
         if (a.C == 32) {
             if (a.ldx == 640 && a.ld1 == 608) go(k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 3>);
@@ -552,462 +452,6 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s) {
         if (a.ldx == 320 && a.ld1 == 288) go(k_mrf_fused<2, 4, 6, 3, 2, 320, 288>);
         else go(k_mrf_fused<2, 4, 6, 3, 2>);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The fused stage in MATH_BF16X3 with the split done once per element: both LDS tiles hold three bf16 PLANES
-// ([plane][16-channel group][half][column] x 16 B, b3.h) instead of f32 values, so the matrix-core loops carry no VALU
-// work at all (on the fly the split costs as much issue time as the MFMAs it feeds: tools/bf16x3_probe, V3 vs V5).
-//   * x (+halo) is split while it is staged (stage_planes), x1 in conv1's epilogue — a lane's 16 rows of a 32 x 32 tile
-//     are exactly two 16-byte plane records (eight channels each), so the epilogue writes 6 ds_write_b128 per tile and
-//     the residual / accumulator preload reads 6 ds_read_b128 (x = h + m + l exactly);
-//   * four waves, one per SIMD with the whole register file: a wave owns a contiguous run of up to NT1MAX column tiles
-//     of one 32-row tile, every weight fragment feeds all of them (b3_chunk);
-//   * 6 B per element instead of 4: T_B = 256 columns for 32 channels, 128 for 64 (halo 45 + 36 per side).
-// ------------------------------------------------------------------------------------------------
-// a lane's rows r = 0..7 (a = 0, 1) of row tile wm are the eight k-slots of record [group 2 wm][half brow], rows 8..15 of
-// [group 2 wm + 1][half brow]: value of row r = plane sums of slot (r & 3) + 4 ((r >> 2) & 1)
-__device__ __forceinline__ void planes_to_rows(const uint4* __restrict__ P, int PS, int LD, int wm, int brow, int col, float (&v)[16]) {
-    MI355_UNROLL
-    for (int hg = 0; hg < 2; ++hg) {
-        const int o = ((2 * wm + hg) * 2 + brow) * LD + col;
-        const uint4 h = P[o], m = P[PS + o], l = P[2 * PS + o];
-        const unsigned hh[4] = {h.x, h.y, h.z, h.w}, mm[4] = {m.x, m.y, m.z, m.w}, ll[4] = {l.x, l.y, l.z, l.w};
-        MI355_UNROLL
-        for (int q = 0; q < 4; ++q) {  // slots 2q, 2q + 1
-            v[8 * hg + 2 * q] = (__uint_as_float(hh[q] << 16) + __uint_as_float(mm[q] << 16)) + __uint_as_float(ll[q] << 16);
-            v[8 * hg + 2 * q + 1] = (__uint_as_float(hh[q] & 0xffff0000u) + __uint_as_float(mm[q] & 0xffff0000u)) + __uint_as_float(ll[q] & 0xffff0000u);
-        }
-    }
-}
-__device__ __forceinline__ void rows_to_planes(uint4* __restrict__ P, int PS, int LD, int wm, int brow, int col, const float (&v)[16]) {
-    MI355_UNROLL
-    for (int hg = 0; hg < 2; ++hg) {
-        uint4 h, m, l;
-        split3_pk(v[8 * hg + 0], v[8 * hg + 1], h.x, m.x, l.x);
-        split3_pk(v[8 * hg + 2], v[8 * hg + 3], h.y, m.y, l.y);
-        split3_pk(v[8 * hg + 4], v[8 * hg + 5], h.z, m.z, l.z);
-        split3_pk(v[8 * hg + 6], v[8 * hg + 7], h.w, m.w, l.w);
-        const int o = ((2 * wm + hg) * 2 + brow) * LD + col;
-        P[o] = h;
-        P[PS + o] = m;
-        P[2 * PS + o] = l;
-    }
-}
-// accumulator register r of a lane <-> slot order of the two records: r = 4 a + m  ->  record a >> 1, slot 4 (a & 1) + m
-__device__ __forceinline__ int rec_index(int r) { return 8 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3); }
-
-template <int C, int WM, int WT, int N2, int NT1MAX>
-__global__ __launch_bounds__(256) void k_mrf_b3(MrfArgs a) {
-    static_assert(WM * WT == 4 && C == 32 * WM, "4 waves: WM row tiles x WT column runs");
-    static_assert(N2 % WT == 0, "output column tiles divide evenly");
-    constexpr int NG = C / 16, T_B = 32 * N2, NT2 = N2 / WT;
-    DYN_SMEM(float, smem);
-    const int LDX = a.ldx, LD1 = a.ld1, R = a.R;
-    const int PSX = NG * 2 * LDX, PS1 = NG * 2 * LD1;
-    uint4* Xp = reinterpret_cast<uint4*>(smem);
-    uint4* X1p = Xp + 3 * PSX;
-    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
-    const int wm = wid / WT, wt = wid % WT;
-    const int brow = lane >> 5, bcol = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * T_B;
-    int len = a.len ? a.len[b] : a.T;
-    if (len > a.T) len = a.T;
-
-    if (!(a.ablate & 2)) stage_planes<NG>(a.x + (long)b * a.x_bs, a.x_ld, LDX, t0 - R, len, 0.1f, Xp, PSX, tid, 256);
-    __syncthreads();
-
-    f32x16 out[1][NT2];
-    MI355_UNROLL
-    for (int i = 0; i < NT2; ++i)
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) out[0][i][r] = 0.0f;
-    // biases travel one conv ahead of their use (16 loads in flight under the previous conv's matrix-core loop): a wave
-    // alone on its SIMD has nothing else to hide an L2 round trip per conv behind
-    float bias_n[16];
-    MI355_UNROLL
-    for (int r = 0; r < 16; ++r) bias_n[r] = a.bias[0][0][32 * wm + (r & 3) + 8 * (r >> 2) + 4 * brow];
-
-    for (int j = 0; j < a.nrb; ++j) {
-        const int K = a.k[j], d1 = a.d1[j], d2 = a.d2[j];
-        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
-        // ---- conv1 over the extended range e in [0, T_B + 2 r2): column tile q <-> t = t0 - r2 + 32 q + bcol; this wave: a
-        // contiguous run of cnt tiles from `start`
-        const int n1 = (T_B + 2 * r2 + 31) / 32;
-        const int base = n1 / WT, rem = n1 % WT;
-        const int cnt = base + (wt < rem ? 1 : 0), start = wt * base + (wt < rem ? wt : rem);
-        f32x16 acc1[1][NT1MAX];
-        float bias[16];
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) bias_n[r] = a.bias[j][1][32 * wm + (r & 3) + 8 * (r >> 2) + 4 * brow];  // conv2's, for later
-        MI355_UNROLL
-        for (int i = 0; i < NT1MAX; ++i) {
-            if (i < cnt) {
-                float v[16];
-                planes_to_rows(Xp, PSX, LDX, wm, brow, (R - r2) + (start + i) * 32 + bcol, v);
-                MI355_UNROLL
-                for (int r = 0; r < 16; ++r) acc1[0][i][r] = unlrelu(v[rec_index(r)]) + bias[r];
-            }
-        }
-        {
-            const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.w[j][0]) + (long)wm * K * NG * 192 + lane};
-            const uint4* xq = Xp + brow * LDX + bcol + (R - r2 - r1) + start * 32;
-            if (!(a.ablate & 1)) {
-                if (cnt >= 4 && NT1MAX >= 4) b3_chunk<1, (NT1MAX >= 4 ? 4 : NT1MAX), NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
-                else if (cnt == 3 && NT1MAX >= 3) b3_chunk<1, (NT1MAX >= 3 ? 3 : NT1MAX), NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
-                else if (cnt == 2) b3_chunk<1, 2, NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
-                else if (cnt == 1) b3_chunk<1, 1, NG, NT1MAX>(acc1, wp, xq, PSX, LDX, K, NG, d1);
-            }
-        }
-        if (j > 0) __syncthreads();  // every wave is done reading the previous resblock's x1
-        // ---- conv1 epilogue: x1 (zero outside the row), leaky-relu, split -> planes
-        MI355_UNROLL
-        for (int i = 0; i < NT1MAX; ++i) {
-            if (i < cnt) {
-                const int e = (start + i) * 32 + bcol;
-                const int t = t0 - r2 + e;
-                const bool live = t >= 0 && t < len;
-                float v[16];
-                MI355_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const float x1 = acc1[0][i][r];
-                    v[rec_index(r)] = live ? fmaxf(x1, 0.1f * x1) : 0.0f;
-                }
-                if (e < LD1) rows_to_planes(X1p, PS1, LD1, wm, brow, e, v);
-            }
-        }
-        __syncthreads();
-        // ---- conv2 into the output registers: out += x1 + bias + conv(lrelu(x1)); this wave: tiles wt * NT2 ..
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
-        {
-            const int jn = j + 1 < a.nrb ? j + 1 : j;  // next resblock's conv1 bias (the last one re-reads its own)
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) bias_n[r] = a.bias[jn][0][32 * wm + (r & 3) + 8 * (r >> 2) + 4 * brow];
-        }
-        MI355_UNROLL
-        for (int i = 0; i < NT2; ++i) {
-            float v[16];
-            planes_to_rows(X1p, PS1, LD1, wm, brow, r2 + (wt * NT2 + i) * 32 + bcol, v);
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) out[0][i][r] += unlrelu(v[rec_index(r)]) + bias[r];
-        }
-        {
-            const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.w[j][1]) + (long)wm * K * NG * 192 + lane};
-            if (!(a.ablate & 1)) b3_chunk<1, NT2, NG>(out, wp, X1p + brow * LD1 + bcol + wt * NT2 * 32, PS1, LD1, K, NG, d2);
-        }
-    }
-
-    const float n = (float)a.nrb;
-    MI355_UNROLL
-    for (int i = 0; i < NT2; ++i) {
-        const int t = t0 + (wt * NT2 + i) * 32 + bcol;
-        if (t < a.T && !(a.ablate & 4)) {
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = a.out_scale > 0.0f ? out[0][i][r] * a.out_scale : out[0][i][r] / n;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 32 channels (the last stage: one 32-row tile, so a weight fragment feeds only the column tiles of its own wave, and
-// eight waves fetching every fragment from L2 for every workgroup is more traffic than the CU's vector-memory path
-// carries next to the matrix cores).  Here the weights of the running conv sit in LDS as well:
-//   * LDS: x planes + x1 planes (pre-split, as k_mrf_b3) + a segment (<= kp taps) of the running conv's bf16x3 fragments
-//     (2 groups x 3 KiB per tap); both MFMA operands are ds_read_b128, the loops carry no VALU and no global loads at
-//     all, so a wave alone on its SIMD (whole register file) runs them back to back with one group of look-ahead;
-//   * the next segment and the next bias travel into registers under the running loop (nothing in the loop waits on
-//     the vector-memory counter) and are written to LDS between the barriers that separate two segments;
-//   * four waves; conv2 computes 8 column tiles (2 per wave), conv1 the extended range tb + 2 r2 in 8..12 tiles dealt in
-//     contiguous runs of 2 or 3; tb <= 256 is chosen so that the widest conv1 is a whole number of tiles
-//     (the "_low" voices, r2 = 2 / 12 / 36: tb = 248, conv1 tiles 8 / 9 / 10).
-// ------------------------------------------------------------------------------------------------
-constexpr int MW_KMAX = 11, MW_N1MAX = 10, MW_WREGS = 8;  // taps per conv; conv1 column tiles; uint4 per thread and segment (kp <= 5)
-
-__global__ __launch_bounds__(256) void k_mrf_b3w(MrfArgs a) {
-    constexpr int NG = 2, NT2 = 2, NT1 = 3;
-    DYN_SMEM(float, smem);
-    const int LDX = a.ldx, LD1 = a.ld1, R = a.R, T_B = a.tb, KP = a.kp;
-    const int PSX = NG * 2 * LDX, PS1 = NG * 2 * LD1;
-    uint4* Xp = reinterpret_cast<uint4*>(smem);
-    uint4* X1p = Xp + 3 * PSX;
-    uint4* Wl = X1p + 3 * PS1;  // [taps of the segment][NG][3 planes][64 lanes]
-    const int tid = threadIdx.x, lane = tid & 63, wt = WAVE_UNIFORM(tid >> 6);
-    const int brow = lane >> 5, bcol = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * T_B;
-    int len = a.len ? a.len[b] : a.T;
-    if (len > a.T) len = a.T;
-
-    // a conv of K taps runs in ceil(K / KP) segments of (nearly) equal length
-    auto seg_taps = [&](int K) { const int np = (K + KP - 1) / KP; return (K + np - 1) / np; };
-    uint4 wr[MW_WREGS];
-    auto w_fetch = [&](const float* wsrc, int k0, int taps) {  // clamped: every load unconditional
-        const uint4* src = reinterpret_cast<const uint4*>(wsrc) + (long)k0 * NG * 192;
-        const int n = taps * NG * 192;
-        MI355_UNROLL
-        for (int i = 0; i < MW_WREGS; ++i) {
-            const int idx = tid + 256 * i;
-            wr[i] = src[idx < n ? idx : n - 1];
-        }
-    };
-    auto w_store = [&](int taps) {
-        const int n = taps * NG * 192;
-        MI355_UNROLL
-        for (int i = 0; i < MW_WREGS; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < n) Wl[idx] = wr[i];
-        }
-    };
-    auto bias_load = [&](const float* bp, float (&bv)[16]) {
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2) + 4 * brow];
-    };
-    // fetch the segment that follows (j, q, k0 .. k0 + taps): the same conv's next taps, the other conv, the next resblock
-    auto fetch_next = [&](int j, int q, int k0, int taps) {
-        const int K = a.k[j];
-        if (k0 + taps < K) {
-            const int st = seg_taps(K);
-            w_fetch(a.w[j][q], k0 + taps, K - (k0 + taps) < st ? K - (k0 + taps) : st);
-        } else if (q == 0) {
-            w_fetch(a.w[j][1], 0, seg_taps(K));
-        } else {
-            const int jn = j + 1 < a.nrb ? j + 1 : j;  // after the last conv: a harmless re-read
-            w_fetch(a.w[jn][0], 0, seg_taps(a.k[jn]));
-        }
-    };
-    auto next_taps = [&](int j, int q, int k0, int taps) {
-        const int K = a.k[j];
-        if (k0 + taps < K) { const int st = seg_taps(K); return K - (k0 + taps) < st ? K - (k0 + taps) : st; }
-        if (q == 0) return seg_taps(K);
-        return seg_taps(a.k[j + 1 < a.nrb ? j + 1 : j]);
-    };
-
-    w_fetch(a.w[0][0], 0, seg_taps(a.k[0]));
-    if (!(a.ablate & 2)) stage_planes<NG>(a.x + (long)b * a.x_bs, a.x_ld, LDX, t0 - R, len, 0.1f, Xp, PSX, tid, 256);
-    w_store(seg_taps(a.k[0]));
-    float bias_n[16];
-    bias_load(a.bias[0][0], bias_n);
-    __syncthreads();
-
-    f32x16 out[1][NT2];
-    MI355_UNROLL
-    for (int i = 0; i < NT2; ++i)
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) out[0][i][r] = 0.0f;
-    const uint4* wl[1] = {Wl + lane};
-
-    for (int j = 0; j < a.nrb; ++j) {
-        const int K = a.k[j], d1 = a.d1[j], d2 = a.d2[j];
-        const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
-        const int st = seg_taps(K);
-        // ---- conv1 over the extended range e in [0, tb + 2 r2): column tile q <-> t = t0 - r2 + 32 q + bcol; this wave: a
-        // contiguous run of cnt (2 or 3) tiles from `start`
-        const int n1 = (T_B + 2 * r2 + 31) / 32;
-        const int base = n1 >> 2, rem = n1 & 3;
-        const int cnt = base + (wt < rem ? 1 : 0), start = wt * base + (wt < rem ? wt : rem);
-        float bias[16];
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
-        bias_load(a.bias[j][1], bias_n);
-        f32x16 acc1[1][NT1];
-        MI355_UNROLL
-        for (int i = 0; i < NT1; ++i) {
-            if (i < cnt) {
-                float v[16];
-                planes_to_rows(Xp, PSX, LDX, 0, brow, (R - r2) + (start + i) * 32 + bcol, v);
-                MI355_UNROLL
-                for (int r = 0; r < 16; ++r) acc1[0][i][r] = unlrelu(v[rec_index(r)]) + bias[r];
-            }
-        }
-        for (int k0 = 0; k0 < K; k0 += st) {
-            const int taps = K - k0 < st ? K - k0 : st;
-            fetch_next(j, 0, k0, taps);
-            const uint4* xq = Xp + brow * LDX + bcol + (R - r2 - r1) + start * 32 + k0 * d1;
-            if (!(a.ablate & 1)) {
-                if (cnt >= 3) b3_chunk<1, 3, NG, NT1>(acc1, wl, xq, PSX, LDX, taps, NG, d1);
-                else if (cnt == 2) b3_chunk<1, 2, NG, NT1>(acc1, wl, xq, PSX, LDX, taps, NG, d1);
-                else if (cnt == 1) b3_chunk<1, 1, NG, NT1>(acc1, wl, xq, PSX, LDX, taps, NG, d1);
-            }
-            __syncthreads();  // every wave is done with this segment (last one: and with the previous resblock's x1)
-            if (k0 + taps >= K) {
-                // conv1 epilogue: x1 (zero outside the row), leaky-relu, split -> planes
-                MI355_UNROLL
-                for (int i = 0; i < NT1; ++i) {
-                    if (i < cnt) {
-                        const int e = (start + i) * 32 + bcol;
-                        const int t = t0 - r2 + e;
-                        const bool live = t >= 0 && t < len;
-                        float v[16];
-                        MI355_UNROLL
-                        for (int r = 0; r < 16; ++r) {
-                            const float x1 = acc1[0][i][r];
-                            v[rec_index(r)] = live ? fmaxf(x1, 0.1f * x1) : 0.0f;
-                        }
-                        if (e < LD1) rows_to_planes(X1p, PS1, LD1, 0, brow, e, v);
-                    }
-                }
-            }
-            w_store(next_taps(j, 0, k0, taps));
-            __syncthreads();
-        }
-        // ---- conv2 into the output registers: out += x1 + bias + conv(lrelu(x1)); this wave: output tiles 2 wt, 2 wt + 1
-        MI355_UNROLL
-        for (int r = 0; r < 16; ++r) bias[r] = bias_n[r];
-        bias_load(a.bias[j + 1 < a.nrb ? j + 1 : j][0], bias_n);
-        MI355_UNROLL
-        for (int i = 0; i < NT2; ++i) {
-            float v[16];
-            planes_to_rows(X1p, PS1, LD1, 0, brow, r2 + (wt * NT2 + i) * 32 + bcol, v);
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) out[0][i][r] += unlrelu(v[rec_index(r)]) + bias[r];
-        }
-        for (int k0 = 0; k0 < K; k0 += st) {
-            const int taps = K - k0 < st ? K - k0 : st;
-            const bool last_seg = j + 1 == a.nrb && k0 + taps >= K;
-            if (!last_seg) fetch_next(j, 1, k0, taps);
-            if (!(a.ablate & 1)) b3_chunk<1, NT2, NG>(out, wl, X1p + brow * LD1 + bcol + wt * NT2 * 32 + k0 * d2, PS1, LD1, taps, NG, d2);
-            if (!last_seg) {
-                __syncthreads();
-                w_store(next_taps(j, 1, k0, taps));
-                __syncthreads();
-            }
-        }
-    }
-
-    const bool mean = !(a.out_scale > 0.0f);
-    const float n = (float)a.nrb;
-    MI355_UNROLL
-    for (int i = 0; i < NT2; ++i) {
-        const int c0 = (wt * NT2 + i) * 32 + bcol;
-        const int t = t0 + c0;
-        if (c0 < T_B && t < a.T && !(a.ablate & 4)) {
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int co = (r & 3) + 8 * (r >> 2) + 4 * brow;
-                a.y[(long)b * a.y_bs + (long)co * a.y_ld + t] = mean ? out[0][i][r] / n : out[0][i][r] * a.out_scale;
-            }
-        }
-    }
-}
-
-namespace {
-struct GeoB3 { int C, T_B, WT, NT1MAX; };
-inline bool geometry_b3(int C, GeoB3* g) {
-    if (C == 32) { *g = {32, 256, 4, 3}; return true; }
-    if (C == 64) { *g = {64, 128, 2, 4}; return true; }
-    return false;
-}
-inline void shape_b3(const GeoB3& g, int nrb, const int* k, const int* d1, const int* d2, int* R, int* ldx, int* ld1, bool* ok) {
-    int Rm = 0, r2max = 0;
-    *ok = true;
-    for (int j = 0; j < nrb; ++j) {
-        if (k[j] < 1 || (k[j] % 2) == 0 || d1[j] < 1 || d2[j] < 1) { *ok = false; return; }
-        const int r1 = (k[j] - 1) / 2 * d1[j], r2 = (k[j] - 1) / 2 * d2[j];
-        Rm = Rm > r1 + r2 ? Rm : r1 + r2;
-        r2max = r2max > r2 ? r2max : r2;
-        const int n1 = (g.T_B + 2 * r2 + 31) / 32;
-        if ((n1 + g.WT - 1) / g.WT > g.NT1MAX) *ok = false;
-    }
-    *R = (Rm + 3) & ~3;  // the staged window starts on a 16-byte boundary
-    *ldx = (g.T_B + *R + Rm + 3) & ~3;
-    *ld1 = (g.T_B + 2 * r2max + 3) & ~3;
-}
-}  // namespace
-
-namespace {
-// geometry of k_mrf_b3w: halo R, row pitches, output columns per workgroup, LDS bytes
-inline bool shape_b3w(int nrb, const int* k, const int* d1, const int* d2, int* R, int* ldx, int* ld1, int* tb, int* kp, size_t* lds) {
-    int Rm = 0, r2max = 0, over = 0, kmax = 1;
-    for (int j = 0; j < nrb; ++j) {
-        if (k[j] < 1 || (k[j] % 2) == 0 || k[j] > MW_KMAX || d1[j] < 1 || d2[j] < 1) return false;
-        const int r1 = (k[j] - 1) / 2 * d1[j], r2 = (k[j] - 1) / 2 * d2[j];
-        Rm = Rm > r1 + r2 ? Rm : r1 + r2;
-        r2max = r2max > r2 ? r2max : r2;
-        over = over > r1 - r2 ? over : r1 - r2;
-        kmax = kmax > k[j] ? kmax : k[j];
-    }
-    // output columns: at most 8 tiles (2 per wave), and the widest conv1 (tb + 2 max r2) a whole number of tiles <= 10
-    int t = 32 * MW_N1MAX - 2 * r2max;
-    if (t > 256) t = 256;
-    if (t < 128) return false;
-    const int n1max = (t + 2 * r2max + 31) / 32;
-    *R = Rm;
-    *tb = t;
-    *ldx = (Rm + 32 * n1max + over + 3) & ~3;
-    *ld1 = (32 * ((t + 31) / 32) + 2 * r2max + 3) & ~3;
-    const size_t planes = (size_t)192 * (*ldx + *ld1);
-    if (planes + 2 * 6144 > LDS_LIMIT) return false;
-    int p = (int)((LDS_LIMIT - planes) / 6144);  // taps of weight fragments that fit next to the planes
-    if (p > 5) p = 5;                            // MW_WREGS uint4 per thread = 5 taps
-    if (p > kmax) p = kmax;
-    *kp = p;
-    *lds = planes + (size_t)p * 6144;
-    return true;
-}
-// opt-in (MI355VITS_MRF_B3W=1): measured 5.4 ms against the on-the-fly kernel's 2.9 ms on the bench workload — with one
-// 32-row tile every MFMA needs 0.67 KiB of LDS operands (the loops run at the LDS port's pace, not the matrix cores'),
-// the 248-column tile makes ten short weight segments whose L2 fetches are exposed, and the halo costs 11 % more tiles
-inline bool no_b3w() { return getenv("MI355VITS_MRF_B3W") == nullptr; }  // read per call: tests flip it inside one process
-}  // namespace
-
-bool mrf_b3w_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
-    int R, ldx, ld1, tb, kp;
-    size_t lds;
-    return C == 32 && nrb >= 1 && nrb <= MRF_MAX_RB && !no_b3w() && shape_b3w(nrb, k, d1, d2, &R, &ldx, &ld1, &tb, &kp, &lds);
-}
-
-bool mrf_b3_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
-    if (mrf_b3w_supported(C, nrb, k, d1, d2)) return true;
-    GeoB3 g;
-    if (!geometry_b3(C, &g) || nrb < 1 || nrb > MRF_MAX_RB) return false;
-    int R, ldx, ld1;
-    bool ok;
-    shape_b3(g, nrb, k, d1, d2, &R, &ldx, &ld1, &ok);
-    return ok && (size_t)96 * (C / 16) * (ldx + ld1) <= LDS_LIMIT;
-}
-
-void launch_mrf_b3(MrfArgs a, hipStream_t s) {
-    if (a.T <= 0 || a.B <= 0) return;
-    if (mrf_b3w_supported(a.C, a.nrb, a.k, a.d1, a.d2)) {
-        size_t shmem;
-        shape_b3w(a.nrb, a.k, a.d1, a.d2, &a.R, &a.ldx, &a.ld1, &a.tb, &a.kp, &shmem);
-        const char* ab = getenv("MI355VITS_MRF_ABLATE");
-        a.ablate = ab ? atoi(ab) : 0;
-        dim3 grid((a.T + a.tb - 1) / a.tb, a.B);
-#ifndef MI355_EMU
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mrf_b3w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-        (void)once;
-#endif
-        LAUNCH_KERNEL(k_mrf_b3w, grid, dim3(256), shmem, s, a);
-        return;
-    }
-    GeoB3 g;
-    if (!geometry_b3(a.C, &g) || !mrf_b3_supported(a.C, a.nrb, a.k, a.d1, a.d2)) throw std::runtime_error("mrf_b3: unsupported stage shape");
-    bool ok;
-    shape_b3(g, a.nrb, a.k, a.d1, a.d2, &a.R, &a.ldx, &a.ld1, &ok);
-    a.vec = (a.x_ld % 4 == 0) && (a.x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0);
-    {
-        const char* ab = getenv("MI355VITS_MRF_ABLATE");
-        a.ablate = ab ? atoi(ab) : 0;
-    }
-    const size_t shmem = (size_t)96 * (a.C / 16) * (a.ldx + a.ld1);
-    dim3 grid((a.T + g.T_B - 1) / g.T_B, a.B);
-    auto go = [&](auto kfn) {
-#ifndef MI355_EMU
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-        (void)once;
-#endif
-        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
-    };
-    if (a.C == 32) go(k_mrf_b3<32, 1, 4, 8, 3>);
-    else go(k_mrf_b3<64, 2, 2, 4, 4>);
 }
 
 }  // namespace m355

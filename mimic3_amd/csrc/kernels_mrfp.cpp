@@ -513,7 +513,7 @@ void launch_mrf_p(MrfArgs a, hipStream_t s) {
     dim3 grid((unsigned)(nitems < cus ? nitems : cus));  // persistent: one workgroup per CU (160 KiB of LDS each)
 #ifdef MI355_LAB
     {
-        const char* ab = getenv("MI355VITS_MRF_ABLATE");
+        const char* ab = lab_getenv("MI355VITS_MRF_ABLATE");
         a.ablate = ab ? (int)strtol(ab, nullptr, 0) : 0;
     }
 #endif

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_
     const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
     const int toff = tlo - ts;
 
-    if (!(a.ablate & 2)) {   // stage h[b, :, ts : ts + LDX)
+    if (!(LAB_ABLATE(a) & 2)) {   // stage h[b, :, ts : ts + LDX)
         const float* hb = a.h_in + (long)b * a.h_bs;
         if (a.vec) {
             const int ld4 = LDX >> 2;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_
         }
         const float* wp0 = a.w_in + (long)(2 * p) * a.K * CP * 64 + lane;
         const float* wp1 = wp0 + (long)a.K * CP * 64;
-        if (!(a.ablate & 1)) wn_mfma2<CP>(acc0, acc1, wp0, wp1, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
+        if (!(LAB_ABLATE(a) & 1)) wn_mfma2<CP>(acc0, acc1, wp0, wp1, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
             const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(acc0[r], -15.0f), 15.0f));
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_
         }
         const float* wp0 = a.w_rs + (long)p * CP * 64 + lane;
         const float* wp1 = two ? a.w_rs + (long)(NP + p) * CP * 64 + lane : wp0;
-        if (!(a.ablate & 1)) wn_mfma2<CP>(acc0, acc1, wp0, wp1, U + brow * 32 + bcol, 32, 1, 0);
-        if (t < a.T && !((a.ablate & 4) && acc0[0] != 1.2345f)) {
+        if (!(LAB_ABLATE(a) & 1)) wn_mfma2<CP>(acc0, acc1, wp0, wp1, U + brow * 32 + bcol, 32, 1, 0);
+        if (t < a.T && !((LAB_ABLATE(a) & 4) && acc0[0] != 1.2345f)) {
             const bool live = t < len;
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     const float* hb = a.h_in + (long)b * a.h_bs;
     // LDS index of element (channel c, column col) of a tile with `ld` columns: see wn_mfma_b4
     auto pk = [](int c, int col, int ld) { return ((((c >> 3) * 2 + (c & 1)) * ld + col) << 2) + ((c >> 1) & 3); };
-    if (!(a.ablate & 2)) {
+    if (!(LAB_ABLATE(a) & 2)) {
         // one float4 of LDS = four channels (8g + 2q + brow, q = 0..3) at one column.  A thread moves a 4 x 4 block: four
         // 16-byte loads along time (one per channel), transposed in registers, four 16-byte LDS stores (one per column)
         const int ld4 = LDX >> 2;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             }
             wp[m] = a.w_in + (long)q * a.K * CP * 64 + lane;
         }
-        if (!(a.ablate & 1))
+        if (!(LAB_ABLATE(a) & 1))
             wn_mfma_b4<MT, CP>(acc, wp, reinterpret_cast<const float4*>(X) + brow * LDX + toff + bcol, LDX, a.K, a.dil);
         if (two && MT * w < NTILE / 2) {  // the residual input of this wave's h' tiles, while the h tile is still there
             MI355_UNROLL
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     const float4* U = reinterpret_cast<const float4*>(X) + brow * 32 + bcol;
     const bool live = t < len;
     auto finish = [&](const f32x16& acc, int q, const f32x16& hr) {
-        if (t >= a.T || ((a.ablate & 4) && acc[0] != 1.2345f)) return;
+        if (t >= a.T || ((LAB_ABLATE(a) & 4) && acc[0] != 1.2345f)) return;
         if (two && 32 * q < H) {  // wave-uniform: a tile lies entirely in the h' half or in the skip half
             MI355_UNROLL
             for (int r = 0; r < 16; ++r)
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             for (int r = 0; r < 16; ++r) acc[m][r] = a.b_rs[32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow];
             wp[m] = a.w_rs + (long)q * CP * 64 + lane;
         }
-        if (!(a.ablate & 1)) wn_mfma_b4<MT, CP>(acc, wp, U, 32, 1, 0);
+        if (!(LAB_ABLATE(a) & 1)) wn_mfma_b4<MT, CP>(acc, wp, U, 32, 1, 0);
         MI355_UNROLL
         for (int m = 0; m < MT; ++m) finish(acc[m], MT * w + m, hres[m]);
     } else if (NW == 12) {  // 6 tiles, one per wave
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             const float* w1[1] = {a.w_rs + (long)w * CP * 64 + lane};
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) a1[0][r] = a.b_rs[32 * w + (r & 3) + 8 * (r >> 2) + 4 * brow];
-            if (!(a.ablate & 1)) wn_mfma_b4<1, CP>(a1, w1, U, 32, 1, 0);
+            if (!(LAB_ABLATE(a) & 1)) wn_mfma_b4<1, CP>(a1, w1, U, 32, 1, 0);
             finish(a1[0], w, hres[0]);
         }
     } else {  // 6 tiles: waves 0, 1 take two, waves 2, 3 one
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
             for (int r = 0; r < 16; ++r) acc[m][r] = a.b_rs[32 * qq + (r & 3) + 8 * (r >> 2) + 4 * brow];
             wp[m] = a.w_rs + (long)qq * CP * 64 + lane;
         }
-        if (!(a.ablate & 1)) {
+        if (!(LAB_ABLATE(a) & 1)) {
             if (nq == 2) {
                 wn_mfma_b4<2, CP>(acc, wp, U, 32, 1, 0);
             } else {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     const int PS = NG * 2 * LD;    // uint4 per plane
     const bool two = a.Crs == 2 * H;
 
-    if (!(a.ablate & 2)) stage_planes<NG, NG, H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, 256);  // 2 column sets x 12 rows: one round trip
+    if (!(LAB_ABLATE(a) & 2)) stage_planes<NG, NG, H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, 256);  // 2 column sets x 12 rows: one round trip
     __syncthreads();
 
     // ---- in-layer conv: wave w owns row tiles w, w + 4, w + 8 (rows 32 q .. 32 q + 31 of the 2H), all 3 column tiles
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             }
             wp[i] = reinterpret_cast<const uint4*>(a.w_in) + (long)q * a.K * NG * GW + lane;
         }
-        if (!(a.ablate & 1)) {
+        if (!(LAB_ABLATE(a) & 1)) {
             if constexpr (H2) h2_chunk<3, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
             else b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         }
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             }
             wp[i] = reinterpret_cast<const uint4*>(a.w_rs) + (long)q * NG * GW + lane;
         }
-        if (!(a.ablate & 1)) {
+        if (!(LAB_ABLATE(a) & 1)) {
             if (two) {
                 if constexpr (H2) h2_chunk<3, NT, NG, NT>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] *= UNACC;
         }
     }
-    if ((a.ablate & 4) && acc[0][0][0] != 1.2345f) return;
+    if ((LAB_ABLATE(a) & 4) && acc[0][0][0] != 1.2345f) return;
     // ---- epilogue: rows < H (two-output layers): h' = (h + rs) * mask; the others: skip (+)= rs.  The 16 old values a
     // lane needs per 32 x 32 tile are loaded unconditionally (clamped column) and one tile ahead of the stores: the
     // memory counter retires in order, so a load issued after a store cannot be waited for without waiting for that
@@ -662,11 +662,11 @@ bool wn_layer_b3_supported(int H, int K, int dil) {
 void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!wn_layer_b3_supported(a.H, a.K, a.dil)) throw std::runtime_error("wn_layer_b3: unsupported shape");
-    static const int ablate = getenv("MI355VITS_WN_ABLATE") ? atoi(getenv("MI355VITS_WN_ABLATE")) : 0;
+    static const int ablate = lab_getenv("MI355VITS_WN_ABLATE") ? atoi(lab_getenv("MI355VITS_WN_ABLATE")) : 0;
     a.ablate = ablate;
     a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
     // 96-column tiles when they fill the chip, 32-column tiles for small grids (same bits, see k_wn_layer_b3)
-    const char* nt_s = getenv("MI355VITS_WN_B3_NT");  // read per launch: tests flip it inside one process
+    const char* nt_s = lab_getenv("MI355VITS_WN_B3_NT");  // read per launch: tests flip it inside one process
     const long nwg3 = (long)((a.T + 95) / 96) * a.B;
     const int nt = nt_s ? atoi(nt_s) : (nwg3 < 128 ? 1 : 3);
     const int tb = nt == 1 ? 32 : 96;
@@ -677,8 +677,7 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     dim3 grid((a.T + tb - 1) / tb, a.B);
     auto go = [&](auto kfn) {
 #ifndef MI355_EMU
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)once;
+        set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
     };
@@ -701,7 +700,7 @@ void launch_wn_layer(WnArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!wn_layer_fused_supported(a.H, a.K, a.dil)) throw std::runtime_error("wn_layer: unsupported shape");
     a.ldx = (32 + (a.K - 1) * a.dil + 3 + 3) & ~3;
-    static const int ablate = getenv("MI355VITS_WN_ABLATE") ? atoi(getenv("MI355VITS_WN_ABLATE")) : 0;
+    static const int ablate = lab_getenv("MI355VITS_WN_ABLATE") ? atoi(lab_getenv("MI355VITS_WN_ABLATE")) : 0;
     a.ablate = ablate;
     a.vec = (a.h_ld % 4 == 0) && (a.h_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(a.h_in) % 16 == 0);
     const size_t shmem = (size_t)a.H * a.ldx * sizeof(float);  // ldx >= 32: U fits in the h tile
@@ -709,7 +708,7 @@ void launch_wn_layer(WnArgs a, hipStream_t s) {
     // Three geometries with identical arithmetic (same bits): 4 waves x 3 tiles keeps the SIMDs evenly loaded when the
     // grid fills the chip; 6 x 2 and 12 x 1 have ever shorter dependent MFMA chains per wave, which is what matters when
     // only a few dozen workgroups exist (one utterance: 31 workgroups per layer).
-    const char* six_s = getenv("MI355VITS_WN_SIX_WAVES");  // read per launch: tests flip it inside one process
+    const char* six_s = lab_getenv("MI355VITS_WN_SIX_WAVES");  // read per launch: tests flip it inside one process
     const int six_env = six_s ? atoi(six_s) : -1;
     const long nwg = (long)grid.x * grid.y;
     const int geom = six_env >= 0 ? six_env : (nwg < 128 ? 2 : (nwg < 512 ? 1 : 0));  // 0: 4x3, 1: 6x2, 2: 12x1

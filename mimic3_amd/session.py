@@ -363,14 +363,15 @@ class _MicroBatcher:
                     g[5].set_exception(e)
 
     def close(self):
-        self._q.put(None)
-        if self._thread is not threading.current_thread():
-            self._thread.join(timeout=5.0)
-        if self._pool is not None:
-            self._pool.shutdown(wait=False)
-        # requests still queued get an error instead of hanging
         import queue
 
+        self._q.put(None)
+        on_dispatcher = self._thread is threading.current_thread()
+        if not on_dispatcher:
+            self._thread.join(timeout=5.0)
+        if self._pool is not None:
+            self._pool.shutdown(wait=not on_dispatcher)  # batches already handed to a lane finish first
+        # requests still queued get an error instead of hanging
         while True:
             try:
                 it = self._q.get_nowait()
@@ -378,6 +379,9 @@ class _MicroBatcher:
                 break
             if it is not None and not it[5].done():
                 it[5].set_exception(RuntimeError("session closed"))
+        if not on_dispatcher and self._thread.is_alive():
+            self._q.put(None)  # the drain above may have swallowed the sentinel of a dispatcher that was still busy
+            self._thread.join(timeout=5.0)
 
 
 class InferenceSession:
@@ -402,15 +406,18 @@ class InferenceSession:
         # one weight upload per device; further lanes of a device share it (mi355vits_clone).  Lane-major order:
         # consecutive handles sit on different devices.
         firsts = []
+        self._engines = []
         try:
             for d in devices:
                 firsts.append(_native.Engine(weights, device=d, library=library))
-            self._engines = list(firsts)
+                self._engines.append(firsts[-1])
             for _ in range(lanes - 1):
-                self._engines.extend(f.clone() for f in firsts)
+                for f in firsts:
+                    self._engines.append(f.clone())
         except BaseException:
-            for e in firsts:
+            for e in reversed(self._engines):  # clones before the handles whose weights they share
                 e.close()
+            self._engines = []
             raise
         self.devices = list(devices)
         self._closed = False
@@ -526,7 +533,11 @@ class InferenceSession:
         self._closed = True
         if self._batcher is not None:
             self._batcher.close()
-        for e in self._engines:
+        # wait for every call in flight: a handle is destroyed only once its lane has come back (a worker still inside
+        # mi355vits_run must not find its engine freed under it)
+        for _ in range(self._free_lanes.size):
+            self._free_lanes.acquire()
+        for e in reversed(self._engines):  # clones before the handles whose weights they share
             e.close()
 
     def __del__(self):

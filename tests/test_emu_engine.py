@@ -419,78 +419,6 @@ def test_bf16x3_engine_path_long_utterance_uses_the_staged_split_kernels(emu_lib
     eng.close()
 
 
-@pytest.mark.parametrize("dils", [((1, 2), (2, 6), (3, 12)), ((1, 3), (1, 3), (1, 3)), ((3, 1), (2, 1), (1, 2))])
-def test_bf16x3_last_stage_mrf_with_weights_in_lds(emu_lib, dils):
-    """k_mrf_b3w (32-channel stage, MATH_BF16X3; opt-in, MI355VITS_MRF_B3W=1): x / x1 as pre-split planes and the running conv's weight fragments in
-    LDS in segments of a few taps.  The "_low" voices' dilations (248 output columns per workgroup, conv1 in 8 / 9 / 10 column
-    tiles, the 7-tap convs in two segments), a narrow set (256 columns) and one with r1 > r2; ragged batch over several
-    workgroups; decoder stage taps and the waveform vs the oracle, and vs the on-the-fly kernel."""
-    import os
-
-    cfg = VitsConfig.tiny_wide()
-    cfg.resblock_dilation_sizes = dils
-    w = W.synthetic_weights(cfg, seed=77, frames_per_id=2.0)
-    blob = W.pack(cfg, w)
-    Tx = 24
-    forced = np.full((2, Tx), 3, np.int32)  # 72 frames -> 576 columns in the 32-channel stage: 3 workgroups per row
-    ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (2, Tx))
-    lengths = np.array([Tx, Tx - 7])
-    outs = {}
-    for tag, env in (("b3w", "MI355VITS_MRF_B3W"), ("fused", None)):
-        if env:
-            os.environ[env] = "1"
-        try:
-            eng = Engine(blob, library=emu_lib)
-            eng.set_math("bf16x3")
-            eng.profile_enable(True)
-            outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=77, weights=w, engine=eng)
-            labels = set(eng.profile_report())
-            assert ("dec.mrf_b3.s1" in labels) == (tag == "b3w") and ("dec.mrf_fused.s1" in labels) == (tag == "fused"), labels
-            eng.close()
-        finally:
-            if env:
-                del os.environ[env]
-    # same products, same order, f32 accumulate in both: the split-once kernel reproduces the split-per-use kernel's bits
-    for bi in range(2):
-        L = int(outs["fused"]["lengths"][bi])
-        assert rel_rms(outs["b3w"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
-
-
-@pytest.mark.parametrize("math", ["bf16x3", "f32"])
-def test_conv_post_fused_behind_the_last_mrf_stage(emu_lib, math):
-    """Opt-in MI355VITS_POST_FUSION=1.  Last stage (32 channels): conv_post + tanh + peak inside the fused MRF kernel (504 samples per 512-column tile, no stage
-    output in global memory) must give the bits of the separate kernel (same summation order) — waveform, int16 and
-    lengths; ragged batch, more than one tile per row; and the separate kernel is what runs when debug taps are on."""
-    import os
-
-    cfg = VitsConfig.tiny_wide()
-    w = W.synthetic_weights(cfg, seed=78, frames_per_id=2.0)
-    os.environ["MI355VITS_POST_FUSION"] = "1"  # opt-in (read when a handle is created)
-    try:
-        eng = Engine(W.pack(cfg, w), library=emu_lib)
-    finally:
-        del os.environ["MI355VITS_POST_FUSION"]
-    eng.set_math(math)
-    eng.profile_enable(True)
-    Tx = 40
-    forced = np.full((3, Tx), 4, np.int32)  # 160 frames -> 1280 samples: three tiles per full row
-    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (3, Tx))
-    lengths = np.array([Tx, Tx - 13, 3])
-    scales = (0.667, 1.0, 0.8)
-    fused = eng.run(ids, lengths, scales, forced_durations=forced, seed=5, want_pcm16=True)
-    assert "dec.conv_post_tanh" not in eng.profile_report()
-    eng.profile_reset()
-    plain = eng.run(ids, lengths, scales, forced_durations=forced, seed=5, want_pcm16=True, debug_taps=True)
-    assert "dec.conv_post_tanh" in eng.profile_report()
-    assert np.array_equal(fused["lengths"], plain["lengths"]) and np.array_equal(fused["peaks"], plain["peaks"])
-    for b in range(3):
-        L = int(fused["lengths"][b])
-        assert np.array_equal(fused["audio"][b, :L], plain["audio"][b, :L])
-        assert np.array_equal(fused["pcm"][b], plain["pcm"][b])
-    eng.close()
-    check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=78, weights=w)
-
-
 def test_wide_encoder_ffn_conv_on_the_split_kernel(emu_lib):
     """The text encoder's 192 -> 768, k = 3 FFN conv (K Cin >= 512, >= 4 row blocks) runs on the split-bf16 staged kernel in
     MATH_BF16X3 — a rule of the layer alone, so a row's bits do not depend on what it is batched with even though the

@@ -1,0 +1,267 @@
+"""Serving-shaped paths on the real device (pytest -m gpu): caller-side micro-batching and lanes (SURVEY.md §8f N2 — the
+reference's shape is N worker threads on one shared session, mimic3_http/synthesis.py:88-136, mimic3_tts/voice.py:277-292),
+ordered streaming (N4), the metric's batch-256 configuration on ONE GPU (BASELINE.json `metric`), and the split kernels on data
+with a wide dynamic range."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mimic3_amd import weights as W
+from mimic3_amd._native import Engine
+from mimic3_amd.config import VitsConfig
+from mimic3_amd.session import InferenceSession, InvalidArgument, SessionOptions
+from mimic3_amd.streaming import stream_sentences
+from oracle.vits_oracle import VitsOracle, audio_float_to_int16
+from tests.util import REL_RMS_TOL, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+DET = np.array([0.0, 1.0, 0.0], np.float32)  # deterministic scales: a request's bits do not depend on its utterance index
+
+
+def _feed(ids):
+    a = np.asarray(ids, np.int64).reshape(1, -1)
+    return {"input": a, "input_lengths": np.array([a.shape[1]], np.int64), "scales": DET}
+
+
+@pytest.fixture(scope="module")
+def voice():
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=21, frames_per_id=2.0)
+    return cfg, w, W.pack(cfg, w)
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_micro_batching_on_the_device_is_bitwise_equal_to_separate_calls(voice, lanes):
+    """32 client threads, one single-utterance run_pcm16 each, 2 ms collection window: the dispatcher groups them by
+    (scales, phoneme-length class) and runs batched calls — on `lanes` handles of the device.  Lengths straddle the 128 / 256 /
+    512 classes (the text encoder's kernels follow the padded length).  Every result must be the bytes a plain session gives
+    for the same request alone, and (three of them) within tolerance of the oracle."""
+    cfg, w, blob = voice
+    lengths = [40, 100, 127, 128, 129, 200, 255, 256, 257, 300, 400, 511, 512, 513, 520, 64] * 2
+    rng = np.random.default_rng(5)
+    sents = [rng.integers(1, cfg.num_symbols, n).astype(np.int64) for n in lengths]
+    plain = InferenceSession(blob)
+    expect = [plain.run_pcm16(_feed(s))[0][0].copy() for s in sents]
+    so = SessionOptions()
+    so.micro_batch_window_ms = 2.0
+    so.micro_batch_max = 16
+    so.lanes = lanes
+    mb = InferenceSession(blob, sess_options=so)
+    got = [None] * len(sents)
+    errs = []
+
+    def work(i):
+        try:
+            got[i] = mb.run_pcm16(_feed(sents[i]))[0][0].copy()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((i, e))
+
+    for _ in range(2):  # twice: the second round meets warm handles and different batch compositions
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(sents))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        for i, (e, g) in enumerate(zip(expect, got)):
+            assert g is not None and g.shape == e.shape and np.array_equal(e, g), (i, lengths[i])
+    b = mb._batcher
+    assert b.requests == 2 * len(sents) and b.batches < b.requests, (b.batches, b.requests)  # it did batch
+    ora = VitsOracle(cfg, w)
+    for i in (0, 4, 8):  # 40, 129, 257 ids
+        r = ora.infer(sents[i][None, :], np.array([lengths[i]]), DET)
+        ref16 = audio_float_to_int16(r["audio"][0, 0, : int(r["audio_lengths"][0])])
+        assert got[i].shape == ref16.shape
+        d = np.abs(got[i].astype(np.int32) - ref16.astype(np.int32))
+        assert (d > 0).mean() <= 0.10 and d.max() <= 16, ((d > 0).mean(), d.max())
+    mb.close()
+    plain.close()
+
+
+def test_streaming_on_the_device_keeps_order_and_bytes_and_stops_at_a_failing_sentence(voice):
+    """stream_sentences over a session with micro-batching and two lanes: chunks arrive in sentence order and are the bytes
+    of per-sentence calls; a sentence that fails (an id outside the symbol table) raises when its turn comes, after its
+    predecessors were delivered and without delivering anything behind it."""
+    cfg, w, blob = voice
+    rng = np.random.default_rng(8)
+    sents = [rng.integers(1, cfg.num_symbols, int(n)).astype(np.int64) for n in rng.integers(30, 161, 20)]
+    plain = InferenceSession(blob)
+    expect = [plain.run_pcm16(_feed(s))[0][0].copy() for s in sents]
+    so = SessionOptions()
+    so.micro_batch_window_ms = 1.0
+    so.lanes = 2
+    sess = InferenceSession(blob, sess_options=so)
+    chunks = list(stream_sentences(sess, sents, scales=DET, look_ahead=8))
+    assert len(chunks) == len(sents)
+    for e, g in zip(expect, chunks):
+        assert np.array_equal(e, g)
+    bad = list(sents)
+    bad[7] = np.array([3, 4, cfg.num_symbols + 5, 6], np.int64)
+    seen = []
+    with pytest.raises((InvalidArgument, RuntimeError)):
+        for c in stream_sentences(sess, bad, scales=DET, look_ahead=8):
+            seen.append(c)
+    assert len(seen) == 7 and all(np.array_equal(e, g) for e, g in zip(expect[:7], seen))
+    # the session is still usable afterwards
+    assert np.array_equal(sess.run_pcm16(_feed(sents[0]))[0][0], expect[0])
+    sess.close()
+    plain.close()
+
+
+def test_batch_256_on_one_gpu_lengths_batch_invariance_and_oracle_parity():
+    """BASELINE.json's metric is quoted at batch 1 and batch 256; 256 x 128 ids x 6 frames on ONE device (about 27 GB of
+    workspace): every row has the forced length, three sampled rows are bitwise what they are alone (same global utterance
+    index, same Philox stream) and match the oracle."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234, frames_per_id=6.0)
+    eng = Engine(W.pack(cfg, w))
+    B, Tx = 256, 128
+    rng = np.random.default_rng(256)
+    ids = rng.integers(1, cfg.num_symbols, (B, Tx)).astype(np.int64)
+    lens = np.full(B, Tx, np.int64)
+    lens[5], lens[77], lens[200] = 97, 128, 64
+    forced = np.full((B, Tx), 6, np.int32)
+    nw = rng.standard_normal((B, 2, Tx)).astype(np.float32)
+    nz = rng.standard_normal((B, cfg.inter_channels, Tx * 6)).astype(np.float32)
+    sc = [0.667, 1.0, 0.8]
+    full = eng.run(ids, lens, sc, forced_durations=forced, noise_w=nw, noise_z=nz, want_pcm16=True)
+    assert np.array_equal(full["lengths"], lens * 6 * cfg.hop_length)
+    ora = VitsOracle(cfg, w)
+    for b in (5, 77, 200):
+        n = int(lens[b])
+        one = eng.run(ids[b:b + 1, :n], [n], sc, forced_durations=forced[b:b + 1, :n], noise_w=nw[b:b + 1, :, :n],
+                      noise_z=nz[b:b + 1, :, : n * 6], want_pcm16=True)
+        L = int(one["lengths"][0])
+        assert L == int(full["lengths"][b])
+        assert np.array_equal(full["audio"][b, :L], one["audio"][0, :L]), b
+        assert np.array_equal(full["pcm"][b, :L], one["pcm"][0, :L]), b
+        r = ora.infer(ids[b:b + 1, :n], np.array([n]), sc, forced_durations=forced[b:b + 1, :n], noise_w=nw[b:b + 1, :, :n],
+                      noise_z=nz[b:b + 1, :, : n * 6])
+        assert rel_rms(full["audio"][b, :L], r["audio"][0, 0, :L]) < REL_RMS_TOL, b
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ dynamic range
+def _conv_ref(x, w, bias, dil):
+    K = w.shape[2]
+    return F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil,
+                    padding=(K * dil - dil) // 2).numpy()
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_staged_conv_kernels_on_wide_dynamic_range(gpu_lib, impl):
+    """impl 2 (f32 operands split into three bf16 terms, six products on the bf16 matrix cores) and impl 1 (f32 MFMA) against
+    an fp64 conv on inputs far from N(0, 1): all inputs x 2^+100, x 2^-100 (every split term still a normal bf16), per-channel
+    scales from 2^-20 to 2^+20 inside one reduction, and x 2^-120 — there the second and third terms of the split
+    (2^-128, 2^-136 relative to 1) are subnormal: the result may fall back to the leading term's 8 bits but must not be
+    garbage.  Then +inf / NaN in one input element: only the outputs whose receptive field holds it are non-finite."""
+    B, Cin, Cout, T, K, dil = 2, 128, 64, 700, 5, 2
+    rng = np.random.default_rng(11)
+    x0 = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    zero_b = np.zeros(Cout, np.float32)
+
+    def rel_err(x):
+        y = gpu_lib.test_conv1d(x, w, zero_b, None, dilation=dil, impl=impl).astype(np.float64)
+        ref = _conv_ref(x, w, zero_b, dil)
+        return float(np.sqrt(np.mean((y - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+
+    base = rel_err(x0)
+    assert base < 5e-7, base
+    for e in (100, -100):
+        r = rel_err(np.ldexp(x0, e).astype(np.float32))
+        assert r < 2.0 * base + 1e-7, (e, r, base)  # scaling by a power of two changes nothing while every term stays normal
+    ch = np.ldexp(1.0, (np.arange(Cin) % 41) - 20).astype(np.float32)
+    r_mixed = rel_err(x0 * ch[None, :, None])
+    assert r_mixed < 5e-7, r_mixed
+    r_tiny = rel_err(np.ldexp(x0, -120).astype(np.float32))
+    print(f"\nimpl {impl}: rel rms vs fp64  N(0,1) {base:.2e}  mixed channel scales {r_mixed:.2e}  x 2^-120 {r_tiny:.2e}")
+    assert r_tiny < (2.0 ** -6 if impl == 2 else 1e-5), r_tiny
+    # non-finite inputs stay local
+    for bad in (np.inf, np.nan):
+        xb = x0.copy()
+        xb[1, 17, 300] = bad
+        y = gpu_lib.test_conv1d(xb, w, zero_b, None, dilation=dil, impl=impl)
+        reach = (K - 1) // 2 * dil
+        hit = np.zeros((B, T), bool)
+        hit[1, 300 - reach: 300 + reach + 1: dil] = True
+        assert np.all(~np.isfinite(y[1][:, hit[1]])), bad
+        clean = np.ones((B, Cout, T), bool)
+        clean[1][:, hit[1]] = False
+        y0 = gpu_lib.test_conv1d(x0, w, zero_b, None, dilation=dil, impl=impl)
+        assert np.all(np.isfinite(y[clean])) and np.array_equal(y[clean], y0[clean]), bad
+
+
+def _scaled_decoder(w, s):
+    """The HiFi-GAN decoder is positively homogeneous when its biases scale along: conv_pre's weight and every decoder bias
+    x s  ->  every stage's activations x s (leaky-relu and the convs commute with a positive scale)."""
+    out = dict(w)
+    out["dec.conv_pre.weight"] = (w["dec.conv_pre.weight"].astype(np.float64) * s).astype(np.float32)
+    for k in w:
+        if k.startswith("dec.") and k.endswith(".bias"):
+            out[k] = (w[k].astype(np.float64) * s).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32", "f16x2"])
+@pytest.mark.parametrize("log2s", [0, 40, -40, -100])
+def test_fused_mrf_stages_on_scaled_activations_vs_fp64(math, log2s):
+    """The fused MRF kernels (k_mrf_p / k_mrf_fused, every math mode) on activations x 2^log2s: stage taps against the oracle
+    in fp64 with the same (scaled) weights.  bf16x3 and f32 are scale-free (power-of-two scaling moves exponents only, every
+    split term stays normal down to 2^-100); f16x2 is a FIXED-scale mode — activations x 2^4 must fit fp16: beyond about
+    |x| = 4094 they saturate and below 2^-7 the second term goes subnormal — so away from log2s = 0 it only has to stay
+    finite (include/mi355vits.h documents the range; the mode is opt-in)."""
+    cfg = VitsConfig.apope_low()
+    w = _scaled_decoder(W.synthetic_weights(cfg, seed=77, frames_per_id=3.0), 2.0 ** log2s)
+    eng = Engine(W.pack(cfg, w))
+    eng.set_math(math)
+    rng = np.random.default_rng(3)
+    ids = rng.integers(1, cfg.num_symbols, (2, 40)).astype(np.int64)
+    lens = np.array([40, 27])
+    forced = np.full((2, 40), 3, np.int32)
+    eng.run(ids, lens, DET, forced_durations=forced, debug_taps=True)
+    ref = VitsOracle(cfg, w, dtype=torch.float64).infer(ids, lens, DET, forced_durations=forced)
+    worst = 0.0
+    for i in range(len(cfg.upsample_rates)):
+        got = eng.tap(f"dec.mrf.{i}")
+        f = got.shape[2] // int(ref["z"].shape[2])
+        for b in range(2):
+            n = int(ref["y_lengths"][b]) * f
+            r = np.asarray(ref[f"dec.mrf.{i}"][b], np.float64)[:, :n]
+            g = got[b, :, :n].astype(np.float64)
+            assert np.all(np.isfinite(g)), (math, log2s, i)
+            worst = max(worst, rel_rms(g, r))
+    print(f"\n{math} x 2^{log2s}: worst MRF stage rel rms vs fp64 {worst:.2e}")
+    if math != "f16x2" or log2s == 0:
+        assert worst < 5e-6, (math, log2s, worst)
+    eng.close()
+
+
+def test_f16x2_weight_range_fallback_and_activation_clip():
+    """MATH_F16X2's two documented edges: a stage whose weights reach |w| >= 7.99 is packed without fp16 planes and runs as
+    bf16x3 (results stay f32-grade); activations beyond |x| = 4094 saturate in the LDS tiles (finite, not f32-grade)."""
+    cfg = VitsConfig.apope_low()
+    w0 = W.synthetic_weights(cfg, seed=78, frames_per_id=3.0)
+    ids = np.random.default_rng(4).integers(1, cfg.num_symbols, (1, 36)).astype(np.int64)
+    forced = np.full((1, 36), 3, np.int32)
+    # (1) one resblock weight of the last stage made large: the whole voice must still match the fp64 oracle
+    w = dict(w0)
+    k = [n for n in w if n.startswith("dec.resblocks.") and n.endswith(".weight")][-1]
+    big = w[k].copy()
+    big.flat[0] = 9.5
+    w[k] = big
+    eng = Engine(W.pack(cfg, w))
+    eng.set_math("f16x2")
+    out = eng.run(ids, [36], DET, forced_durations=forced)
+    ref = VitsOracle(cfg, w, dtype=torch.float64).infer(ids, np.array([36]), DET, forced_durations=forced)
+    L = int(out["lengths"][0])
+    assert rel_rms(out["audio"][0, :L], ref["audio"][0, 0, :L]) < REL_RMS_TOL
+    eng.close()
+    # (2) decoder activations x 2^14 (|x| far beyond 4094): saturating conversion keeps everything finite
+    eng = Engine(W.pack(cfg, _scaled_decoder(w0, 2.0 ** 14)))
+    eng.set_math("f16x2")
+    out = eng.run(ids, [36], DET, forced_durations=forced)
+    assert np.all(np.isfinite(out["audio"]))
+    eng.close()
