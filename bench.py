@@ -144,16 +144,17 @@ def kernel_table(eng, step, nsteps):
     return rep, table, tot_ms
 
 
-def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32"):
+def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32", traffic=None):
+    """`traffic`: measure_traffic_in_run's result for the dominant kernel, or None (then "traffic" is null: nothing is quoted
+    from a stored table)."""
     dom = table[0]
     drec = rep[dom["kernel"]]
     dsec = drec["ms"] * 1e-3
-    # the committed counter passes are per math mode: "<label>" = bf16x3 (the default), "f32:<label>", "f16x2:<label>"
-    traffic = _pmc_traffic(("" if math == "bf16x3" else math + ":") + dom["kernel"], workload_key, voice)
     # the roof of the dominant kernel: kernels named *_b3 / running in MATH_BF16X3 execute six bf16 MFMA products per
     # algorithmic f32 multiply-add, so their matrix-core roof is 2500 / 6 TFLOP/s of ALGORITHMIC f32 work
     on_bf16 = math in ("bf16x3", "f16x2") and any(t in dom["kernel"] for t in ("mrf", "wn_layer_b3", "dec.rb", "upsample.s0", "upsample.s1", "conv_pre"))
     on_f16x2 = math == "f16x2" and "mrf_fused" in dom["kernel"]  # three f16 MFMA products per multiply-add (same MFMA rate)
+    mfma = "v_mfma_f32_16x16x32_bf16" if "mrf_p" in dom["kernel"] else "v_mfma_f32_32x32x16_bf16"
     peak = PEAK_BF16_TFLOPS / 3.0 if on_f16x2 else (PEAK_BF16X3_TFLOPS if on_bf16 else PEAK_FP32_TFLOPS)
     return {
         "kernel": dom["kernel"],
@@ -164,7 +165,7 @@ def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32"):
         "frac": drec["flops"] / dsec / 1e12 / peak,
         "matrix_core_path": ("v_mfma_f32_32x32x16_f16 x 3 partial products per multiply-add (operands as 2 x fp16 terms): peak = 2500 / 3 TFLOP/s"
                              if on_f16x2 else
-                             ("v_mfma_f32_32x32x16_bf16 x 6 partial products per f32 multiply-add (operands split 3 x bf16, f32 "
+                             (mfma + " x 6 partial products per f32 multiply-add (operands split 3 x bf16, f32 "
                               "accumulate): peak = 2500 TFLOP/s dense bf16 / 6") if on_bf16 else "v_mfma_f32_32x32x2_f32: peak = 157.3 TFLOP/s"),
         "frac_of_f32_mfma_peak": drec["flops"] / dsec / 1e12 / PEAK_FP32_TFLOPS,
         "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
@@ -178,8 +179,8 @@ def roofline_of(rep, table, tot_ms, nsteps, workload_key, voice, math="f32"):
         "note": "achieved = ALGORITHMIC f32 FLOPs (2 x Cout x Cin x K per output sample, halo recompute not counted) / launch "
                 "time by HIP events on the engine stream; the dense Conv1d stacks are matrix-core-bound on MI355X (AI >= 24 "
                 "FLOP/B vs ridge 19.7 at f32); hbm_* give the same launches against the 8 TB/s HBM roof as BASELINE asks; "
-                "traffic = rocprofv3 PMC passes of this workload committed under profiles/ (counters cannot be read "
-                "in-process)",
+                "traffic = HBM bytes per launch measured in this run by rocprofv3 counter passes in a subprocess (null when "
+                "not measured: extra legs, rocprofv3 missing)",
         "whole_step": {
             "tflops": sum(v["flops"] for v in rep.values()) / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
             "hbm_algorithmic_gbs": sum(v["bytes"] for v in rep.values()) / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0,
@@ -217,6 +218,7 @@ def main():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg (profiling runs: keeps per-kernel "
                     "averages pure batch-32)")
     ap.add_argument("--no-extra", action="store_true", help="skip the device-only and vctk_low legs")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes that measure roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -323,6 +325,21 @@ def main():
 
     if rank == 0:
         print(f"headline: {value:.4g} samples/s, {ms_per_step:.3f} ms/step over {elapsed:.2f} s (host-to-host)", file=sys.stderr)
+        # where a step's wall time goes on ONE handle driven sequentially: the call as the caller sees it (Python marshalling +
+        # H2D of the ids + launches + the sync on the frame counts + D2H of the int16 into a pooled pinned buffer) against the
+        # device time between the call's first and last HIP event; with `streams` handles in flight the headline hides most
+        # of the difference behind another handle's kernels
+        walls, devs = [], []
+        for i in range(12):
+            t1 = time.perf_counter()
+            wl.step(i, eng)
+            walls.append(time.perf_counter() - t1)
+            devs.append(eng.last_run_ms())
+        w_ms, d_ms = float(np.median(walls[2:])) * 1e3, float(np.median(devs[2:]))
+        result["host_ms_per_step"] = {"one_handle_call_ms": w_ms, "device_ms": d_ms, "host_side_ms": max(0.0, w_ms - d_ms),
+                                      "handles_in_flight": max(1, args.streams),
+                                      "note": "median of 10 sequential calls on one handle; host_side = call wall - device time "
+                                              "between the call's first and last event"}
 
     if not args.no_extra:
         # same loop, int16 result left in HBM: the compute-side number (round 1's headline definition)
@@ -375,7 +392,11 @@ def main():
     if rank == 0 and not args.no_roofline:
         nsteps = 3
         rep, table, tot_ms = kernel_table(eng, lambda i: wl.step(i, device_only=True), nsteps)
-        result["roofline"] = roofline_of(rep, table, tot_ms, nsteps, [B, Tx, fpi], args.voice, math)
+        traffic = None
+        if n_gpus == 1 and not args.no_traffic:
+            tail = ["--batch", str(B), "--tx", str(Tx), "--frames-per-id", str(fpi), "--voice", args.voice] + (["--math", math] if args.math else [])
+            traffic = measure_traffic_in_run(table[0]["kernel"], tail)
+        result["roofline"] = roofline_of(rep, table, tot_ms, nsteps, [B, Tx, fpi], args.voice, math, traffic)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w") as f:
             json.dump(table, f, indent=1)
@@ -387,8 +408,8 @@ def main():
         vw = Workload(vcfg, W.synthetic_weights(vcfg, seed=1234), devices, args.streams, 32, 128, fpi, 0, 1,
                       multispeaker_sid=True, math=args.math)
         vw.size_workspaces()
-        vsteps = max(20, args.steps // 3)
-        el_v, out_v = timed(vw, vsteps, 5)
+        vsteps = max(60, args.steps // 3)  # >= 60 steps after 10 warm-up: a 20-step leg measures clock ramp and first-touch costs
+        el_v, out_v = timed(vw, vsteps, 10)
         sps = int(out_v["lengths"].sum())
         extra = {
             "workload": f"en_US/vctk_low (109 speakers, gin 512), 32 utterances x 128 phoneme ids, sid = b mod 109, forced "
@@ -404,13 +425,29 @@ def main():
             print_table("vctk_low b32, per-kernel (HIP events):", tablev[:12])
         result["extra"] = {"vctk_low_b32": extra}
         vw.close()
+        # ---- BASELINE.json `metric`: "... batch=1 and batch=256": the whole batch-256 configuration on ONE device (configs[3]
+        # shards it 8 x 32; it also fits one MI355X: about 27 GB of workspace per handle)
+        bigw = Workload(cfg, weights, devices, min(2, max(1, args.streams)), 256, Tx, fpi, 0, 1, multispeaker_sid=cfg.is_multispeaker,
+                        math=args.math)
+        bigw.size_workspaces()
+        bsteps = max(8, args.steps // 16)
+        el_g, out_g = timed(bigw, bsteps, 2)
+        spb = int(out_g["lengths"].sum())
+        big = {"workload": f"en_UK/apope_low, 256 utterances x {Tx} phoneme ids on ONE GPU, forced {fpi} frames/id; host-to-host",
+               "value": spb * bsteps / el_g, "unit": "samples/s", "steps": bsteps, "ms_per_step": el_g / bsteps * 1e3,
+               "x_realtime": (spb / SAMPLE_RATE) / (el_g / bsteps), "math": math, "global_batch": 256}
+        if not args.no_roofline:
+            repg, tableg, totg = kernel_table(bigw.engines[0], lambda i: bigw.step(i, device_only=True), 2)
+            big["roofline"] = roofline_of(repg, tableg, totg, 2, [256, Tx, fpi], args.voice, math)
+        result["extra"]["apope_low_b256_1gpu"] = big
+        bigw.close()
         if math != "f32":
             # ---- the same headline workload on the pure f32-MFMA path (v_mfma_f32_32x32x2_f32 everywhere), for reference
             fw = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
                           math="f32")
             fw.size_workspaces()
-            fsteps = max(20, args.steps // 4)
-            el_f, out_f = timed(fw, fsteps, 5)
+            fsteps = max(60, args.steps // 4)
+            el_f, out_f = timed(fw, fsteps, 10)
             f32_leg = {"math": "f32", "value": int(out_f["lengths"].sum()) * fsteps / el_f, "unit": "samples/s", "steps": fsteps,
                        "ms_per_step": el_f / fsteps * 1e3,
                        "note": "same workload, every dense conv on v_mfma_f32_32x32x2_f32 (MI355VITS_MATH=f32)"}
@@ -426,7 +463,7 @@ def main():
             bw = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
                           math="bf16w")
             bw.size_workspaces()
-            el_b, out_b = timed(bw, fsteps, 5)
+            el_b, out_b = timed(bw, fsteps, 10)
             bw_leg = {"math": "bf16w", "dtype": "bf16-weights (bf16 x exact-f32 activations, f32 accumulate)",
                       "value": int(out_b["lengths"].sum()) * fsteps / el_b, "unit": "samples/s", "steps": fsteps,
                       "ms_per_step": el_b / fsteps * 1e3,
@@ -445,7 +482,7 @@ def main():
             hw = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
                           math="f16x2")
             hw.size_workspaces()
-            el_h, out_h = timed(hw, fsteps, 5)
+            el_h, out_h = timed(hw, fsteps, 10)
             h2_leg = {"math": "f16x2", "dtype": "f32 in / out / accumulate; dense-conv operands as 2 x fp16 (22 bits), 3 MFMA products",
                       "value": int(out_h["lengths"].sum()) * fsteps / el_h, "unit": "samples/s", "steps": fsteps,
                       "ms_per_step": el_h / fsteps * 1e3,
@@ -536,6 +573,65 @@ def cpu_baseline(cfg, weights, wl, budget_s):
         "engine_vs_oracle": best["engine_vs_oracle"],
         "legs": legs, "host_cpus": ncpu, "cpu": _cpu_model(), "torch": torch.__version__,
     }
+
+
+# profiler label -> substring of the kernel name as rocprofv3 prints it (the label's launches are that kernel's)
+_KERNEL_NEEDLES = {
+    "dec.mrf_p.s2": "k_mrf_p<32", "dec.mrf_p.s1": "k_mrf_p<64", "dec.mrf_p": "k_mrf_p<",
+    "dec.mrf_fused.s0": "k_mrf_fused<4", "dec.mrf_fused.s1": "k_mrf_fused<2", "dec.mrf_fused.s2": "k_mrf_fused<1",
+    "flow.wn_layer_b3": "k_wn_layer_b3", "flow.wn_layer": "k_wn_layer_h192",
+}
+
+
+def measure_traffic_in_run(label, argv_tail, timeout_s=240):
+    """HBM bytes per launch of the kernel behind profiler label `label`, MEASURED NOW: two counters-only rocprofv3 passes
+    (FETCH_SIZE, WRITE_SIZE — they do not fit one pass; MI355X_MICROARCH.md "rocprofv3 PMC slots") of a short run of this
+    same script on this same box.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: on gfx950 FETCH_SIZE tallies 64 B per
+    128-B read request (same guide, "HBM").  None when rocprofv3 is missing or a pass fails — never a stored constant."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3")
+    needle = _KERNEL_NEEDLES.get(label)
+    if not prof or not needle:
+        return None
+    means, launches, kname_seen = {}, 0, None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mi355vits_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
+                   "--streams", "1", "--no-cpu-baseline", "--no-extra", "--no-b1", "--no-roofline", "--no-traffic"] + argv_tail
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
+            if not dbs:
+                return None
+            per, names = {}, {}
+            con = sqlite3.connect(dbs[0])
+            for disp, kname, val in con.execute("select dispatch_id, kernel_name, value from counters_collection where counter_name = ?",
+                                                (counter,)):
+                if needle in kname:
+                    per[disp] = per.get(disp, 0.0) + val
+                    names[disp] = kname
+            con.close()
+            if not per:
+                return None
+            means[counter] = sum(per.values()) / len(per)
+            launches = len(per)
+            kname_seen = next(iter(names.values()))
+        except (subprocess.SubprocessError, OSError, sqlite3.Error):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"hbm_bytes_per_launch": int((2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024), "fetch_size_kib": means["FETCH_SIZE"],
+            "write_size_kib": means["WRITE_SIZE"], "launches": launches, "kernel": kname_seen,
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two counters-only passes of a 3-step run of "
+                      "this script on this box), 2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE tallies 64 B per 128-B request)"}
 
 
 def _pmc_traffic(kernel, workload_key, voice="apope_low"):
