@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+for rep in 1 2 3; do
+  timeout 300 python bench.py --steps 40 --no-extra --no-cpu-baseline --no-traffic --no-b1 > $O/r03_ab_q.json 2> $O/r03_ab_q.err
+  echo "product q rep $rep: $(grep -o '"ms_per_step": [0-9.]*' $O/r03_ab_q.json)"; grep "dec.mrf_p" $O/r03_ab_q.err
+  timeout 300 python tools/lab_bench.py --steps 40 --no-extra --no-cpu-baseline --no-traffic --no-b1 > $O/r03_ab_p.json 2> $O/r03_ab_p.err
+  echo "product p rep $rep: $(grep -o '"ms_per_step": [0-9.]*' $O/r03_ab_p.json)"; grep "dec.mrf_p" $O/r03_ab_p.err
+done
