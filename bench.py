@@ -209,7 +209,7 @@ def main():
     ap.add_argument("--math", choices=["bf16x3", "f32", "f16x2"], default=None,
                     help="matrix-core path of the dense convs (default: the engine's, MI355VITS_MATH or bf16x3 = f32 operands "
                          "split exactly into 3 bf16 terms, six MFMA products, f32 accumulate; f32 = v_mfma_f32 only)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI355VITS_BENCH_STREAMS", "3")),
                     help="engine handles (HIP streams) kept in flight per GPU; steps are dealt to them in turn")
     ap.add_argument("--single-process", action="store_true",
                     help="drive all --gpus devices from this one process (threads), no torch.distributed")
@@ -402,6 +402,13 @@ def main():
             json.dump(table, f, indent=1)
         print_table("per-kernel (HIP events):", table)
 
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, weights, wl, args.cpu_seconds)
+
+    # the extra legs open their own handles: the headline's go first.  HIP maps a process's streams onto a few hardware
+    # queues; with the headline's idle handles still open two ACTIVE handles of a leg can land on one queue and serialise —
+    # measured (tools/floor_diag2.py): 7.87 ms per step alone, 9.45 ms with two idle handles open, 7.88 ms after closing them
+    wl.close()
     if rank == 0 and n_gpus == 1 and not args.no_extra and args.voice == "apope_low":
         # ---- BASELINE.json configs[2]: en_US/vctk_low multi-speaker, batch 32 x 128 phonemes, one MI355X
         vcfg = VitsConfig.vctk_low()
@@ -493,12 +500,9 @@ def main():
             result["extra"]["f16x2"] = h2_leg
             hw.close()
 
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, weights, wl, args.cpu_seconds)
 
     if rank == 0:
         print(json.dumps(result))
-    wl.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,165 @@
+"""``/api/tts/stream`` next to the reference's ``/api/tts`` (BASELINE.json configs[4]: "long-form SSML
+(~10k chars chunked) streamed through mimic3_http").
+
+The unchanged server answers a request only after its LAST sentence: ``do_synthesis`` joins every ``AudioResult`` of
+``SSMLSpeaker.speak`` / ``end_utterance`` into one WAV (``mimic3_http/synthesis.py:36-85``, ``app.py:157-227``), and the sentences
+of a request run one after the other on one worker thread (``tts.py:470-515``).  With the engine behind ``onnx_model.run`` a
+sentence takes a few milliseconds; what a listener waits for is the join.
+
+This module streams the same bytes sentence by sentence, with ``look_ahead`` sentences in flight on the shared session, using
+ONLY the reference's own objects:
+
+1. *plan*: the request goes through the reference's unmodified front end (``SSMLSpeaker`` or ``speak_text`` →
+   ``end_utterance``) with ``Mimic3TextToSpeechSystem._speak_sentence_phonemes`` (``tts.py:519-551``, the per-sentence unit: ids,
+   ``ids_to_audio``, volume) in *recording* mode for this thread only: every sentence yields an empty placeholder and its
+   ``(phonemes, settings)`` are noted; breaks (``add_break``, zero bytes made on the host by the reference itself,
+   ``tts.py:452-465``) and marks pass through.  Text processing only: microseconds per sentence.
+2. *stream*: the recorded sentences are handed to the ORIGINAL ``_speak_sentence_phonemes`` on a small thread pool — the same
+   calls the server's own workers make, so the session's lanes / micro-batcher / device round-robin batch them — and the
+   results are emitted in order: RIFF header for a stream of unknown length first, then PCM per sentence (and the breaks where
+   the reference put them).
+
+The concatenated PCM equals what ``/api/tts`` returns for the same request (tested in tests/test_reference_http.py on the CPU
+model of the kernels).  Nothing here touches the GPU; it is scheduling above ``InferenceSession``.
+"""
+from __future__ import annotations
+
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from copy import deepcopy
+from typing import Any, Iterator, List, Optional, Tuple
+
+from .streaming import wav_stream_header
+
+_recording = threading.local()
+_patch_lock = threading.Lock()
+
+
+def _install_recorder(tts_cls) -> None:
+    """Wrap ``tts_cls._speak_sentence_phonemes`` once: transparent unless the calling thread is planning a stream."""
+    with _patch_lock:
+        if getattr(tts_cls, "_mi355_stream_recorder", False):
+            return
+        original = tts_cls._speak_sentence_phonemes
+
+        def _speak_sentence_phonemes(self, sent_phonemes, settings=None):
+            plan = getattr(_recording, "plan", None)
+            if plan is None:
+                return original(self, sent_phonemes, settings=settings)
+            settings = settings or self.settings
+            plan.append((list(sent_phonemes), deepcopy(settings)))  # the caller clears its list right after the call
+            from opentts_abc import AudioResult
+
+            return AudioResult(sample_rate_hz=self.settings.sample_rate, audio_bytes=b"", sample_width_bytes=2, num_channels=1)
+
+        tts_cls._speak_sentence_phonemes = _speak_sentence_phonemes
+        tts_cls._mi355_speak_sentence_original = original
+        tts_cls._mi355_stream_recorder = True
+
+
+def plan_request(tts, text: str, ssml: bool = False, text_language: Optional[str] = None) -> List[Tuple[str, Any]]:
+    """The request as the reference's front end splits it: ``[("speak", (phonemes, settings)) | ("bytes", pcm_bytes), ...]``."""
+    _install_recorder(type(tts))
+    from opentts_abc import AudioResult
+
+    sentences: list = []
+    _recording.plan = sentences
+    try:
+        if ssml:
+            from opentts_abc.ssml import SSMLSpeaker
+
+            results = list(SSMLSpeaker(tts).speak(text))
+        else:
+            tts.begin_utterance()
+            tts.speak_text(text, text_language=text_language)
+            results = list(tts.end_utterance())
+    finally:
+        _recording.plan = None
+    plan: List[Tuple[str, Any]] = []
+    it = iter(sentences)
+    for r in results:
+        if isinstance(r, AudioResult):
+            if r.audio_bytes:
+                plan.append(("bytes", r.audio_bytes))  # a break: zero samples from add_break
+            else:
+                plan.append(("speak", next(it)))
+    return plan
+
+
+def stream_request(tts, text: str, ssml: bool = False, text_language: Optional[str] = None, look_ahead: int = 16,
+                   sample_rate: Optional[int] = None) -> Iterator[bytes]:
+    """WAV stream of one request: header, then one chunk per sentence / break, in order, ``look_ahead`` sentences in flight."""
+    if look_ahead < 1:
+        raise ValueError("look_ahead must be >= 1")
+    plan = plan_request(tts, text, ssml=ssml, text_language=text_language)
+    original = type(tts)._mi355_speak_sentence_original
+    yield wav_stream_header(sample_rate or tts.settings.sample_rate)
+    pool = ThreadPoolExecutor(max_workers=look_ahead, thread_name_prefix="mi355vits-http-stream")
+    pending: list = []
+    todo = iter(plan)
+
+    def submit_next() -> bool:
+        try:
+            kind, payload = next(todo)
+        except StopIteration:
+            return False
+        if kind == "bytes":
+            pending.append(payload)
+        else:
+            phonemes, settings = payload
+            pending.append(pool.submit(lambda p=phonemes, s=settings: original(tts, p, settings=s).audio_bytes))
+        return True
+
+    try:
+        while len(pending) < look_ahead and submit_next():
+            pass
+        while pending:
+            head = pending.pop(0)
+            chunk = head if isinstance(head, (bytes, bytearray)) else head.result()  # raises here if this sentence failed
+            submit_next()
+            if chunk:
+                yield chunk
+    finally:
+        for f in pending:
+            if not isinstance(f, (bytes, bytearray)):
+                f.cancel()
+        pool.shutdown(wait=True)
+
+
+def add_stream_route(app, tts, quart_module, args=None, look_ahead: int = 16, rule: str = "/api/tts/stream"):
+    """Register ``rule`` on the Quart app ``mimic3_http.app.get_app`` returned.  ``tts``: a ``Mimic3TextToSpeechSystem`` of the
+    server process (its voices share the sessions of the synthesis workers through ``Mimic3Voice._SHARED_MODELS``,
+    ``voice.py:277-292``); ``quart_module``: the imported ``quart``.  Query parameters as ``/api/tts`` (``app.py:157-219``):
+    ``voice``, ``noiseScale``, ``noiseW``, ``lengthScale``, ``ssml``, ``textLanguage``; text in the POST body or ``?text=``."""
+    request, Response = quart_module.request, quart_module.Response
+    lock = threading.Lock()  # one request at a time plans on this tts object (its settings are per-request state)
+
+    @app.route(rule, methods=["GET", "POST"])
+    async def app_tts_stream():
+        a = request.args
+        if request.method == "POST":
+            text = (await request.data).decode()
+        else:
+            text = a.get("text", "")
+        assert text, "No text provided"
+        if args is not None and getattr(args, "max_text_length", None) is not None:
+            text = text[: args.max_text_length]
+        ssml_str = a.get("ssml")
+        ssml = (ssml_str.strip().lower() in {"true", "1", "yes", "on"}) if ssml_str else request.content_type == "application/ssml+xml"
+        voice = a.get("voice") or (getattr(args, "voice", None) if args is not None else None)
+
+        def chunks():
+            with lock:
+                tts.speaker = None
+                if voice:
+                    tts.voice = str(voice)
+                for key, name in (("noiseScale", "noise_scale"), ("noiseW", "noise_w"), ("lengthScale", "length_scale")):
+                    v = a.get(key)
+                    base = getattr(args, name, None) if args is not None else None
+                    if v or base is not None:
+                        setattr(tts.settings, name, float(v) if v else base)
+                yield from stream_request(tts, text, ssml=ssml, text_language=a.get("textLanguage"), look_ahead=look_ahead)
+
+        return Response(chunks(), mimetype="audio/wav")
+
+    return app_tts_stream
