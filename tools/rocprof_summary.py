@@ -63,15 +63,19 @@ def _labels(B, Tx, fpi):
     # the needles name the MATH_BF16X3 variants (math template argument 1 / k_wn_layer_b3): the default path bench.py times;
     # MI355VITS_MATH=f32 runs match the ", 0>" / k_wn_layer_h192 entries
     return {
-        "dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 1, false>", 2 * 4 * B * 64 * Ty * 64),      # read x + write y, [64, 64 Ty]
-        "dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1, false>", 2 * 4 * B * 32 * Ty * 256),    # [32, 256 Ty]
+        # round 3: the MRF stages of 64 / 32 channels on k_mrf_p (planes split once, weights in registers)
+        "dec.mrf_p.s1": ("k_mrf_p<64,", 2 * 4 * B * 64 * Ty * 64),      # read x + write y, [64, 64 Ty]
+        "dec.mrf_p.s2": ("k_mrf_p<32,", 2 * 4 * B * 32 * Ty * 256),     # [32, 256 Ty]
+        "dec.mrf_fused.s0": ("k_mrf_fused<4, 2, 3, 3, 2, 160, 128, 1>", 2 * 4 * B * 128 * Ty * 8),
+        "dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 1>", 2 * 4 * B * 64 * Ty * 64),
+        "dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 1>", 2 * 4 * B * 32 * Ty * 256),
         "flow.wn_layer_b3": ("k_wn_layer_b3<false, 3>", 4 * 4 * B * 192 * Ty + 6 * (384 * 192 * 5 + 384 * 192)),  # h r+w, skip r+w, bf16x3 weights
         # MATH_F16X2 (bench --math f16x2)
-        "f16x2:dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 3, false>", 2 * 4 * B * 64 * Ty * 64),
-        "f16x2:dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 3, false>", 2 * 4 * B * 32 * Ty * 256),
+        "f16x2:dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 3>", 2 * 4 * B * 64 * Ty * 64),
+        "f16x2:dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 3>", 2 * 4 * B * 32 * Ty * 256),
         "f16x2:flow.wn_layer_b3": ("k_wn_layer_b3<false, 3, true>", 4 * 4 * B * 192 * Ty + 4 * (384 * 192 * 5 + 384 * 192)),
-        "f32:dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 0, false>", 2 * 4 * B * 64 * Ty * 64),
-        "f32:dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 0, false>", 2 * 4 * B * 32 * Ty * 256),
+        "f32:dec.mrf_fused.s1": ("k_mrf_fused<2, 4, 6, 3, 2, 320, 288, 0>", 2 * 4 * B * 64 * Ty * 64),
+        "f32:dec.mrf_fused.s2": ("k_mrf_fused<1, 8, 16, 3, 2, 640, 608, 0>", 2 * 4 * B * 32 * Ty * 256),
         "f32:flow.wn_layer": ("k_wn_layer_h192<4>", 4 * 4 * B * 192 * Ty + 4 * (384 * 192 * 5 + 384 * 192)),
     }
 
