@@ -21,9 +21,15 @@ in HBM (compute-side number).  Batch-1 latency / RTF on the reference's golden-u
 
 The JSON line also carries
   "roofline"     — dominant kernel group, algorithmic FLOPs / launch time measured with HIP events on the
-                   engine's stream (mi355vits_profile_*), against the fp32 matrix-core peak, plus HBM numbers
+                   engine's stream (mi355vits_profile_*), against the matrix-core peak of its path, plus HBM numbers;
+                   "traffic" = HBM bytes per launch MEASURED IN THIS RUN by two counters-only rocprofv3 passes of a
+                   3-step subprocess (or null: --no-traffic, rocprofv3 missing, extra legs) — never a stored table
+  "host_ms_per_step" — one handle driven sequentially: call wall time vs device time
   "cpu_baseline" — the PyTorch-CPU oracle (onnxruntime is not installed here) timed on this host's cores on
-                   a bounded sample of the same workload (rank 0, N = 1 only).
+                   a bounded sample of the same workload (rank 0, N = 1 only), with the engine checked against it
+  "extra"        — vctk_low b32 (configs[2]), the whole batch-256 configuration on ONE GPU, the f32-MFMA / bf16-weights /
+                   f16x2 math modes; they run after the headline's handles are closed (open idle handles alias HIP
+                   streams onto shared hardware queues: tools/floor_diag2.py).
 """
 from __future__ import annotations
 
@@ -636,21 +642,6 @@ def measure_traffic_in_run(label, argv_tail, timeout_s=240):
             "write_size_kib": means["WRITE_SIZE"], "launches": launches, "kernel": kname_seen,
             "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two counters-only passes of a 3-step run of "
                       "this script on this box), 2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE tallies 64 B per 128-B request)"}
-
-
-def _pmc_traffic(kernel, workload_key, voice="apope_low"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), valid for
-    the workload they were collected on; None otherwise (counters cannot be read from inside this process)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        e = t.get(kernel)
-        if e and e["workload"] == list(workload_key) and e.get("voice", "apope_low") == voice:
-            return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
-                    "source": e["source"]}
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
 
 
 def _cpu_model():
