@@ -134,7 +134,7 @@ void mi355vits_destroy(mi355vits_handle h);
  * (default: environment MI355VITS_MATH = "f32" | "bf16x3", else BF16X3):
  *   MI355VITS_MATH_F32     v_mfma_f32_32x32x2_f32 — f32 operands, bit-exact f32 FMA chains;
  *   MI355VITS_MATH_BF16X3  the f32 operands split EXACTLY into three bf16 terms each (x = h + m + l) and the six leading
- *                          partial products on v_mfma_f32_32x32x16_bf16 with f32 accumulation: every retained product is
+ *                          partial products on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16 / _16x16x32_bf16) with f32 accumulation: every retained product is
  *                          exact, the three dropped ones are below 2^-24 of the product — the f32 rounding level.  Same
  *                          parity tolerances; measured against fp64 it is slightly MORE accurate than the f32 MFMA kernels
  *                          (tests/test_gpu_parity.py::test_split_bf16_staged_conv_kernel_vs_fp64), at 6/16 of their
@@ -148,10 +148,16 @@ void mi355vits_destroy(mi355vits_handle h);
  * bf16, the activations stay exact f32 (three terms), f32 accumulate: three MFMA products per multiply-add.  A REDUCED
  * precision variant: separate tolerance (rel. RMS <= 2e-2 vs the f32 oracle), never the default, reported separately. */
 #define MI355VITS_MATH_BF16W 2
-/* experimental: every kernel of the three-term bf16 split (MRF stages, WaveNet layers, staged convs, upsamplers) with both
- * operands split into TWO fp16 terms (11 + 11 significant bits,
- * power-of-two pre-scaling, three products per multiply-add on v_mfma_f32_32x32x16_f16); every other kernel as BF16X3.
- * A 22-bit-operand mode: between BF16W and the f32-grade default, with its own tests; never the default. */
+/* experimental, opt-in: every kernel of the three-term bf16 split (fused MRF stages, fused WaveNet layers, staged convs,
+ * polyphase upsamplers) with both operands split into TWO fp16 terms (11 + 11 significant bits, three products per multiply-add
+ * on v_mfma_f32_32x32x16_f16); every other kernel (text encoder, duration predictor) as in BF16X3.  A FIXED-SCALE mode:
+ * weights are packed x 2^13 (a stage holding a weight |w| >= 7.99 silently runs as BF16X3 instead), activations are written to
+ * the LDS tiles x 2^4 with a saturating round-toward-zero conversion — |x| > 4094 CLIPS (no runtime detection), and below
+ * |x| = 2^-7 the second term goes subnormal (absolute instead of relative precision).  Measured on the MI355X
+ * (tests/test_gpu_serving.py::test_fused_mrf_stages_on_scaled_activations_vs_fp64): at the activations' natural scale the stage
+ * error against fp64 is 1.2e-6 (like the other modes); with the decoder's activations scaled by 2^+-40 the result is finite but
+ * meaningless (rel. error ~1).  A 22-bit-operand mode between BF16W and the f32-grade default, with its own tests; never the
+ * default.  (The 64- / 32-channel MRF stages run the round-2 kernel k_mrf_fused in this mode, not k_mrf_p.) */
 #define MI355VITS_MATH_F16X2 3
 int mi355vits_set_math(mi355vits_handle h, int mode);
 int mi355vits_get_math(mi355vits_handle h);

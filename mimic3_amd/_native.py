@@ -345,8 +345,9 @@ class Engine:
     def set_math(self, mode) -> None:
         """``"f32"`` (f32 MFMA), ``"bf16x3"`` (f32 operands split 3 x bf16, six bf16-MFMA products, f32 accumulate; the
         default), ``"bf16w"`` (bf16-rounded weights x exact activations: reduced precision, BASELINE configs[4]) or ``"f16x2"``
-        (experimental: the fused MRF stages with operands as two fp16 terms = 22 significant bits, three products; everything
-        else as bf16x3)."""
+        (experimental, fixed-scale: every kernel of the bf16x3 split — fused MRF stages, WaveNet layers, staged convs, upsamplers —
+        with operands as two fp16 terms = 22 significant bits, three products; activations beyond |x| = 4094 clip, a stage with a
+        weight |w| >= 7.99 runs as bf16x3; the text encoder / duration predictor as in bf16x3.  See include/mi355vits.h)."""
         self._check(self.native.lib.mi355vits_set_math(self._h, self.MATH_MODES.get(mode, mode)))
 
     @property

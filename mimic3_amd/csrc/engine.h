@@ -170,7 +170,9 @@ class Engine {
     bool force_generic_ = false;
     int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
     bool no_fused_dds_ = false;  // MI355VITS_NO_FUSED_DDS=1: DDS layers as three launches (A/B + fallback)
-    int kmath() const { return math_ == MATH_F16X2 ? (int)MATH_BF16X3 : math_; }  // F16X2 covers the fused MRF stages only
+    // the math mode of the kernels that have no fp16 form of their own: in F16X2 they run as BF16X3 (the kernels that do —
+    // fused MRF stages, fused WaveNet layers, staged convs, upsamplers — are switched where they are launched)
+    int kmath() const { return math_ == MATH_F16X2 ? (int)MATH_BF16X3 : math_; }
     bool no_f16x2_convs_ = false;  // MI355VITS_F16X2_NO_CONVS=1: in MATH_F16X2 keep the staged convs / upsamplers on bf16x3
     bool enc_b3_ = true;           // the encoder's wide FFN conv on the split-bf16 staged kernel (MI355VITS_NO_ENC_B3=1: f32 kernel)
     bool no_mrf_p_ = false;      // MI355VITS_NO_MRF_P=1: keep the on-the-fly split MRF kernel (A/B against k_mrf_p)
