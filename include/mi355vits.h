@@ -197,7 +197,9 @@ long mi355vits_list_taps(mi355vits_handle h, char* buf, size_t cap);
 
 /* Kernel unit-test hook: one Conv1d through a chosen implementation on host buffers.
  * impl: 0 = generic VALU kernel, 1 = fp32-MFMA kernel, 2 = split-bf16 staged kernel (MI355VITS_MATH_BF16X3; needs
- * Cin % 32 == 0 and T > 512).  See tests/test_gpu_parity.py, tests/test_emu_engine.py. */
+ * Cin % 32 == 0 and T > 512), 3 = the text encoder's slice kernel (MI355VITS_MATH_BF16X3; Cin % 192 == 0, K in {1, 3}, dilation
+ * 1; Cin > 192: the raw sums of the 192-channel slices added up, no bias / residual).  See tests/test_gpu_parity.py,
+ * tests/test_emu_engine.py. */
 typedef struct mi355vits_conv_test {
     int32_t impl, B, Cin, Cout, T, K, dilation;
     const float* x;       /* [B,Cin,T] */

@@ -244,7 +244,34 @@ int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t) {
         }
         if (t->in_len) { HIP_CHECK(hipMemcpy(dil.p, t->in_len, t->B * 4, hipMemcpyHostToDevice)); a.in_len = dil.as<int>(); }
         if (t->out_len) { HIP_CHECK(hipMemcpy(dol.p, t->out_len, t->B * 4, hipMemcpyHostToDevice)); a.out_len = dol.as<int>(); }
-        if (t->impl == 1 || t->impl == 2) {
+        if (t->impl == 3) {  // the encoder's slice kernel (k_enc_b3); split convs: the raw slice sums added up here, no epilogue
+            if (!enc_conv_b3_supported(t->Cin, t->Cout, t->K, t->dilation)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the encoder slice kernel");
+            std::vector<uint32_t> b3(bf16x3_packed_words_mode(t->Cout, t->Cin, t->K, EPI_STD));
+            pack_conv_weights_bf16x3_mode(t->w, t->Cout, t->Cin, t->K, EPI_STD, 1, b3.data());
+            DevBuf db3(b3.size() * 4);
+            HIP_CHECK(hipMemcpy(db3.p, b3.data(), b3.size() * 4, hipMemcpyHostToDevice));
+            a.wb3 = db3.as<float>();
+            a.math = MATH_BF16X3;
+            a.ksplit = t->Cin / 192;
+            DevBuf dpart(ny * 4 * (size_t)a.ksplit);
+            if (a.ksplit > 1) {
+                if (t->bias || t->res || t->relu || t->accumulate) throw EngineError(MI355VITS_ERR_INVALID, "split conv: raw sums only");
+                a.part = dpart.as<float>();
+            }
+            launch_enc_conv_b3(a, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipGetLastError());
+            if (a.ksplit > 1) {
+                std::vector<float> parts(ny * (size_t)a.ksplit);
+                HIP_CHECK(hipMemcpy(parts.data(), dpart.p, parts.size() * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < ny; ++i) {
+                    float v = parts[i];
+                    for (int sl = 1; sl < a.ksplit; ++sl) v += parts[(size_t)sl * ny + i];
+                    t->y[i] = v;
+                }
+                return;
+            }
+        } else if (t->impl == 1 || t->impl == 2) {
             if (!conv1d_mfma_supported(t->Cin, t->Cout, t->K, t->dilation)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the MFMA kernel");
             packed.resize(mfma_packed_floats(t->Cout, t->Cin, t->K));
             pack_conv_weights_mfma(t->w, t->Cout, t->Cin, t->K, packed.data());

@@ -364,6 +364,8 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         wn_b3_ = lane0.wn_b3_;
         no_mrf_p_ = lane0.no_mrf_p_;
         no_fused_dds_ = lane0.no_fused_dds_;
+        no_dds_stack_ = lane0.no_dds_stack_;
+        no_enc_gemm_ = lane0.no_enc_gemm_;
         enc_b3_ = lane0.enc_b3_;
         no_f16x2_convs_ = lane0.no_f16x2_convs_;
     } catch (...) {
@@ -393,6 +395,8 @@ void Engine::open_device(int device) {
     wn_b3_ = lab_getenv("MI355VITS_WN_B3") != nullptr;
     no_mrf_p_ = lab_getenv("MI355VITS_NO_MRF_P") != nullptr;
     no_fused_dds_ = lab_getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
+    no_dds_stack_ = lab_getenv("MI355VITS_NO_DDS_STACK") != nullptr;
+    no_enc_gemm_ = lab_getenv("MI355VITS_NO_ENC_GEMM") != nullptr;
     enc_b3_ = lab_getenv("MI355VITS_NO_ENC_B3") == nullptr;
     no_f16x2_convs_ = lab_getenv("MI355VITS_F16X2_NO_CONVS") != nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
@@ -594,6 +598,11 @@ Engine::~Engine() { release(); }
 // =================================================================================================
 // launch helpers
 // =================================================================================================
+bool Engine::enc_gemm(const ConvW& w, const ConvArgs& a) const {
+    return !force_generic_ && !no_enc_gemm_ && !phase_b_ && math_on_bf16(kmath()) && w.packed_b3s != NO_OFF && a.epi == EPI_STD &&
+           w.epi == EPI_STD && !a.shuf_s && a.Tin < 0 && !a.accumulate && enc_conv_b3_supported(w.Cin, w.Cout, w.K, a.dil);
+}
+
 void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     // frames-sized tensors: the kernel is a function of the layer, not of the batch's padding.  Phoneme-sized ones (the text
     // encoder) stay on the f32 kernels except the wide FFN conv (192 -> 768, k3: K Cin >= 512 and >= 4 row blocks), whose
@@ -613,6 +622,13 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     if (a.epi == EPI_RESSKIP) ch_io += w.Cout;  // h and skip are read-modify-write
     const double bytes = 4.0 * a.B * (double)a.T * ch_io + 4.0 * (double)w.Cout * w.Cin * w.K;
     ProfScope ps(prof_, label, flops, bytes);
+    if (enc_gemm(w, a)) {  // phoneme-sized dense convs: one 192-channel slice per workgroup, staged once (k_enc_b3)
+        a.wb3 = P(w.packed_b3s);
+        a.math = kmath();
+        if (a.ksplit != w.Cin / 192) throw EngineError(MI355VITS_ERR_INTERNAL, "split encoder conv: the caller owns the partial sums");
+        launch_enc_conv_b3(a, stream_);
+        return;
+    }
     if (!force_generic_ && w.packed != NO_OFF) {
         a.w = P(w.packed);
         // split-bf16 staged kernel where it pays: convs with little work per staged chunk (1x1 convs, the last
@@ -733,10 +749,23 @@ void Engine::text_encoder(int B, int Tx) {
         f2.in_len = d_len_; f2.out_len = d_len_; f2.mask_before_res = 1;
         f2.res = d_x_; f2.res_bs = xbs; f2.res_ld = Tx;
         f2.B = B; f2.T = Tx;
-        conv("enc.ffn2", cw(S("enc.%d.ffn2", i)), f2);
+        const ConvW& w2 = cw(S("enc.%d.ffn2", i));
+        const bool split2 = enc_gemm(w2, f2) && w2.Cin / 192 > 1 && d_part_ != nullptr;  // raw slice sums; the LayerNorm adds them up
+        if (split2) {
+            f2.ksplit = w2.Cin / 192;
+            f2.part = d_part_;
+        } else if (enc_gemm(w2, f2) && w2.Cin / 192 > 1) {
+            throw EngineError(MI355VITS_ERR_INTERNAL, "split encoder conv without its buffer");
+        }
+        conv("enc.ffn2", w2, f2);
         {
             LNArgs ln;
             ln.x = d_x2_; ln.y = d_x_; ln.B = B; ln.C = H; ln.T = Tx;
+            if (split2) {
+                ln.x = d_part_; ln.nparts = f2.ksplit; ln.part_stride = (long)B * xbs;
+                ln.bias = P(w2.bias); ln.premask_len = d_len_;
+                ln.res = d_x_;
+            }
             ln.gamma = vec(S("enc_p.encoder.norm_layers_2.%d.gamma", i));
             ln.beta = vec(S("enc_p.encoder.norm_layers_2.%d.beta", i));
             if (i == c.n_layers - 1) ln.out_len = d_len_;  // x = x * x_mask after the last layer
@@ -809,20 +838,62 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
     const int H = c.hidden_channels;
     const long bs = (long)H * Tx;
     const int nth = 3 * c.dp_num_bins - 1;
+    // the whole stack in one launch each (k_dds_stack): pre + DDS layers + proj, and for a ConvFlow the spline too
+    const bool stack = !force_generic_ && !no_fused_dds_ && !no_dds_stack_ &&
+                       dds_stack_supported(H, c.dp_kernel_size, c.dp_dds_layers, H) && nth <= H && c.dp_num_bins <= 16 &&
+                       cw("dp.pre").packed != NO_OFF && cw("dp.proj").packed != NO_OFF;
+    auto stack_layers = [&](DdsStackArgs& a, const std::string& key) {
+        a.n_layers = c.dp_dds_layers;
+        a.K = c.dp_kernel_size;
+        for (int i = 0; i < c.dp_dds_layers; ++i) {
+            const ConvW& w = cw(key + S(".convs_1x1.%d", i));
+            if (w.packed == NO_OFF) throw EngineError(MI355VITS_ERR_INTERNAL, "dds stack: 1x1 conv without packed weights");
+            a.dw_w[i] = vec(key + S(".convs_sep.%d.weight", i));
+            a.dw_b[i] = vec(key + S(".convs_sep.%d.bias", i));
+            a.g1[i] = vec(key + S(".norms_1.%d.gamma", i));
+            a.b1[i] = vec(key + S(".norms_1.%d.beta", i));
+            a.w1x1[i] = P(w.packed);
+            a.bias1x1[i] = P(w.bias);
+            a.g2[i] = vec(key + S(".norms_2.%d.gamma", i));
+            a.b2[i] = vec(key + S(".norms_2.%d.beta", i));
+        }
+        a.len = d_len_;
+        a.B = B;
+        a.T = Tx;
+    };
+    const double stack_flops = 2.0 * B * (double)Tx * H * H;
+    if (stack) {
+        DdsStackArgs a;
+        a.src = d_x_;
+        a.pre_mode = DDS_PRE_CONV;
+        a.pre_w = P(cw("dp.pre").packed);
+        a.pre_b = P(cw("dp.pre").bias);
+        a.cond = d_cond_dp_;
+        a.cond_bs = H;
+        stack_layers(a, "dp.convs");
+        a.proj_w = P(cw("dp.proj").packed);
+        a.proj_b = P(cw("dp.proj").bias);
+        a.proj_cout = H;
+        a.out = d_h_;
+        ProfScope ps(prof_, "dp.stack", stack_flops * (c.dp_dds_layers + 2), 8.0 * B * H * Tx);
+        launch_dds_stack(a, H, stream_);
+    }
     // h = proj(DDS(pre(x) [+ cond(g)])) * mask
     ConvArgs pre;
     pre.x = d_x_; pre.x_bs = bs; pre.x_ld = Tx;
     pre.y = d_d0_; pre.y_bs = bs; pre.y_ld = Tx;
     pre.cond = d_cond_dp_; pre.cond_bs = H;
     pre.B = B; pre.T = Tx;
-    conv("dp.pre", cw("dp.pre"), pre);
-    dds("dp.convs", d_d0_, d_d1_, d_d2_, B, Tx);
+    if (!stack) {
+        conv("dp.pre", cw("dp.pre"), pre);
+        dds("dp.convs", d_d0_, d_d1_, d_d2_, B, Tx);
+    }
     ConvArgs pr;
     pr.x = d_d0_; pr.x_bs = bs; pr.x_ld = Tx;
     pr.y = d_h_; pr.y_bs = bs; pr.y_ld = Tx;
     pr.in_len = d_len_; pr.out_len = d_len_;
     pr.B = B; pr.T = Tx;
-    conv("dp.proj", cw("dp.proj"), pr);
+    if (!stack) conv("dp.proj", cw("dp.proj"), pr);
     tap("dp.h", d_h_, {B, H, Tx});
 
     {
@@ -833,6 +904,26 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
     for (int j = c.dp_n_flows - 1; j >= 1; --j) {
         ch0 ^= 1;  // Flip
         const std::string p = S("dp.flows.%d", 1 + 2 * j);
+        if (stack && cw(p + ".proj").packed != NO_OFF) {
+            DdsStackArgs a;
+            a.src = d_h_;
+            a.pre_mode = DDS_PRE_AFFINE;
+            a.pre_w = vec(p + ".pre.weight");
+            a.pre_b = vec(p + ".pre.bias");
+            a.z = d_z2_;
+            a.zch = ch0;
+            stack_layers(a, p + ".convs");
+            a.proj_w = P(cw(p + ".proj").packed);
+            a.proj_b = P(cw(p + ".proj").bias);
+            a.proj_cout = nth;
+            a.spline = 1;
+            a.nb = c.dp_num_bins;
+            a.tail = c.dp_tail_bound;
+            a.inv_sqrt_fc = 1.0f / sqrtf((float)H);
+            ProfScope ps(prof_, "convflow.stack", stack_flops * c.dp_dds_layers + 2.0 * B * (double)Tx * H * nth, 12.0 * B * H * Tx);
+            launch_dds_stack(a, H, stream_);
+            continue;
+        }
         {
             ProfScope ps(prof_, "convflow.pre", 0, 12.0 * B * H * Tx);
             launch_convflow_pre(d_z2_, ch0, vec(p + ".pre.weight"), vec(p + ".pre.bias"), d_h_, B, H, Tx, d_d0_, stream_);
@@ -1264,6 +1355,7 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     size_t need_a = pad(fBT * 8) + pad((size_t)B * 8) + 6 * pad((size_t)B * 4) + 3 * pad(fBT * 4);
     need_a += 3 * pad(fBT * H * 4) + pad(fBT * 3 * H * 4) + pad(fBT * F * 4) + pad(fBT * 2 * I * 4);  // x,x2,att,qkv,ffn,stats
     need_a += 4 * pad(fBT * H * 4) + pad(fBT * nth * 4) + 2 * pad(fBT * 2 * 4) + pad(fBT * 4);          // h,d0,d1,d2,theta,z2,noise_w,logw
+    if (F % 192 == 0 && F / 192 > 1 && H <= 256) need_a += pad(fBT * H * (F / 192) * 4);  // slice sums of the FFN's second conv
     if (gin) need_a += pad((size_t)B * H * 4) + pad((size_t)B * C0 * 4) + (size_t)c.flow_n_flows * pad((size_t)B * 2 * H * c.flow_wn_layers * 4);
     arena_a_.reserve(need_a + 4096, stream_);
     arena_a_.reset();
@@ -1282,6 +1374,7 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     d_att_ = arena_a_.alloc<float>(fBT * H);
     d_qkv_ = arena_a_.alloc<float>(fBT * 3 * H);
     d_ffn_ = arena_a_.alloc<float>(fBT * F);
+    d_part_ = (F % 192 == 0 && F / 192 > 1 && H <= 256) ? arena_a_.alloc<float>(fBT * H * (F / 192)) : nullptr;
     d_stats_ = arena_a_.alloc<float>(fBT * 2 * I);
     d_h_ = arena_a_.alloc<float>(fBT * H);
     d_d0_ = arena_a_.alloc<float>(fBT * H);

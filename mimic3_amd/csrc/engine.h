@@ -154,6 +154,7 @@ class Engine {
 
     // launch helpers
     void conv(const char* label, const ConvW& w, ConvArgs a);
+    bool enc_gemm(const ConvW& w, const ConvArgs& a) const;  // this conv runs on k_enc_b3 (phoneme-sized, split-bf16)
     void tap(const char* name, const float* dev, std::initializer_list<int64_t> dims);
     void text_encoder(int B, int Tx);
     void duration_predictor(int B, int Tx, const mi355vits_run_args& args);
@@ -169,6 +170,8 @@ class Engine {
     bool phase_b_ = false;       // inside flow_and_decoder (see Engine::conv)
     bool force_generic_ = false;
     int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
+    bool no_enc_gemm_ = false;   // MI355VITS_NO_ENC_GEMM=1: phoneme-sized convs on the general conv kernels (A/B + fallback)
+    bool no_dds_stack_ = false;  // MI355VITS_NO_DDS_STACK=1: one launch per DDS layer / pre / proj / spline (A/B + fallback)
     bool no_fused_dds_ = false;  // MI355VITS_NO_FUSED_DDS=1: DDS layers as three launches (A/B + fallback)
     // the math mode of the kernels that have no fp16 form of their own: in F16X2 they run as BF16X3 (the kernels that do —
     // fused MRF stages, fused WaveNet layers, staged convs, upsamplers — are switched where they are launched)
@@ -196,7 +199,7 @@ class Engine {
     long long *d_ids_ = nullptr, *d_sid_ = nullptr;
     int *d_len_ = nullptr, *d_wceil_ = nullptr, *d_cum_ = nullptr, *d_ylen_ = nullptr, *d_alen_ = nullptr,
         *d_forced_ = nullptr;
-    float *d_x_ = nullptr, *d_x2_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_ffn_ = nullptr,
+    float *d_x_ = nullptr, *d_x2_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_ffn_ = nullptr, *d_part_ = nullptr,
           *d_stats_ = nullptr;
     float *d_h_ = nullptr, *d_d0_ = nullptr, *d_d1_ = nullptr, *d_d2_ = nullptr, *d_theta_ = nullptr, *d_z2_ = nullptr,
           *d_logw_ = nullptr, *d_noise_w_ = nullptr;

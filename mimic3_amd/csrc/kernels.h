@@ -44,8 +44,17 @@ struct ConvArgs {
     int ablate = 0;  // timing experiments only (MI355VITS_CONV_ABLATE): 1 no MFMA loop, 2 no staging, 4 no epilogue
     int fixed_rule = 0;  // kernel choice from the layer shape alone, never from T (flow / decoder convs: T = frames depends on
                          // what a row is batched with, and a row's bits must not)
+    // launch_enc_conv_b3 only: the input channels in `ksplit` slices of 192, slice s of row b -> raw sums in
+    // part[((s * B + b) * Cout + co) * T + t] (no epilogue; launch_layernorm adds them up); ksplit = 1: y with the epilogue
+    int ksplit = 1;
+    float* part = nullptr;
 };
 
+// Short-sequence dense conv of the text encoder (q/k/v, o, FFN: T = phonemes) in MATH_BF16X3 / BF16W: 64 x 64 output tiles, a
+// 192-channel slice of the input staged ONCE per workgroup as three bf16 planes (k_enc_b3, kernels_conv.cpp).  Cin % 192 == 0,
+// K in {1, 3}, dil 1, EPI_STD, wb3 = layout-1 planes.
+bool enc_conv_b3_supported(int Cin, int Cout, int K, int dil);
+void launch_enc_conv_b3(const ConvArgs& a, hipStream_t s);
 // Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).
 void launch_conv1d_generic(const ConvArgs& a, hipStream_t s);
 // fp32-MFMA implicit-GEMM Conv1d (v_mfma_f32_32x32x2_f32).  Needs Cin even and packed weights.
@@ -174,6 +183,12 @@ struct LNArgs {
     int gelu = 0;
     const float* add_to = nullptr;  // y = add_to + f(LN(x))   (DDS residual) or null
     float eps = 1e-5f;
+    // x as `nparts` raw partial sums of a conv split over its input channels (x + p * part_stride, added in order p = 0, 1, ..),
+    // then the conv's epilogue: + bias[c], zero at t >= premask_len[b] (the FFN's mask before the residual); then + res, LN
+    int nparts = 1;
+    long part_stride = 0;
+    const float* bias = nullptr;
+    const int* premask_len = nullptr;
 };
 void launch_layernorm(const LNArgs& a, hipStream_t s);
 // relative-position multi-head attention on packed qkv [B, 3H, T] -> out [B, H, T]
@@ -195,6 +210,41 @@ bool dds_layer_fused_supported(int C);
 void launch_dds_layer(const float* x, float* y, const float* dw_w, const float* dw_b, const float* g1, const float* b1,
                       const float* w1x1_packed, const float* bias1x1, const float* g2, const float* b2, const int* len, int B,
                       int C, int T, int K, int dil, hipStream_t s);
+// the whole DDS stack with its pre (1x1 conv + cond, or ConvFlow's affine pre + g), its proj and, for a ConvFlow, the spline:
+// one launch (kernels_misc.cpp, k_dds_stack).  C = 192, K = 3, the taps' total reach <= 16 columns.
+constexpr int DDS_STACK_MAX_LAYERS = 4, DDS_STACK_W = 64, DDS_STACK_OFF = 16, DDS_STACK_K = 3;
+enum { DDS_PRE_CONV = 0, DDS_PRE_AFFINE = 1 };
+struct DdsStackArgs {
+    const float* src = nullptr;    // PRE_CONV: input of the 1x1 pre conv [B, C, T]; PRE_AFFINE: g [B, C, T]
+    int pre_mode = DDS_PRE_CONV;
+    const float* pre_w = nullptr;  // PRE_CONV: packed f32 A fragments [C/32][C/2][64]; PRE_AFFINE: [C]
+    const float* pre_b = nullptr;  // [C]
+    const float* cond = nullptr;   // PRE_CONV: + cond[b * cond_bs + c] (or null)
+    long cond_bs = 0;
+    float* z = nullptr;            // PRE_AFFINE: z [B, 2, T]; channel zch feeds pre, the spline rewrites channel 1 - zch
+    int zch = 0;
+    int n_layers = 0, K = 3;       // dilation of layer i = K^i
+    const float* dw_w[DDS_STACK_MAX_LAYERS] = {};
+    const float* dw_b[DDS_STACK_MAX_LAYERS] = {};
+    const float* g1[DDS_STACK_MAX_LAYERS] = {};
+    const float* b1[DDS_STACK_MAX_LAYERS] = {};
+    const float* w1x1[DDS_STACK_MAX_LAYERS] = {};     // packed f32 A fragments
+    const float* bias1x1[DDS_STACK_MAX_LAYERS] = {};
+    const float* g2[DDS_STACK_MAX_LAYERS] = {};
+    const float* b2[DDS_STACK_MAX_LAYERS] = {};
+    float* x_out = nullptr;        // the stack's x before proj [B, C, T] (tests) or null
+    const float* proj_w = nullptr; // packed f32 A fragments of proj (rows beyond proj_cout zero) or null: no proj
+    const float* proj_b = nullptr;
+    int proj_cout = 0;
+    float* out = nullptr;          // [B, proj_cout, T] or null (a ConvFlow's theta stays on the CU)
+    int spline = 0, nb = 0;
+    float tail = 0.0f, inv_sqrt_fc = 0.0f;
+    const int* len = nullptr;
+    int B = 1, T = 0;
+    int ablate = 0;  // lab build only
+};
+bool dds_stack_supported(int C, int K, int n_layers, int proj_cout);
+void launch_dds_stack(const DdsStackArgs& a, int C, hipStream_t s);
 // h[b,c,t] = w[c] * z[b,ch,t] + bias[c] + g[b,c,t]      (ConvFlow.pre on one channel + conditioning)
 void launch_convflow_pre(const float* z, int ch, const float* w, const float* bias, const float* g, int B, int C,
                          int T, float* h, hipStream_t s);

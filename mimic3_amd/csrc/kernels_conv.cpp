@@ -1270,6 +1270,84 @@ __global__ __launch_bounds__(256) void k_conv_direct_splitk(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Short-sequence dense convs of the text encoder (q/k/v, o, FFN conv_1 / conv_2: T = phonemes, 128 x 32 columns at the
+// bench shape) in MATH_BF16X3 / BF16W.  With so few columns a kernel is either bound by launching too few workgroups or by
+// re-streaming the weights, and k_conv1d_b3's stage / barrier / compute cycle per 32-channel chunk is mostly exposed
+// latency.  Here a workgroup owns a 64 x 64 output tile over ONE 192-channel slice of the input (the encoder's hidden
+// width; conv_2's 768 input channels are four slices = four workgroups whose raw sums the following LayerNorm launch adds
+// up in slice order): the slice (+ K - 1 halo columns) is staged ONCE as three bf16 planes (76 KiB: two workgroups per CU,
+// one stages while the other computes), then each of the four waves runs its 32 x 32 tile's whole k-range without another
+// barrier (b3_chunk: 36 groups x 6 products at K = 3), weights streamed from L2 (each fragment by two waves).
+// Grid at batch 32: q/k/v 576, o 192, conv_1 768, conv_2 4 x 192 workgroups; one utterance of 180 phonemes: 27 / 9 / 36 /
+// 36.  The tile shape and the slice order are fixed by the layer: a row's bits do not depend on what it is batched with.
+// ------------------------------------------------------------------------------------------------
+constexpr int ENC_CS = 192, ENC_NG = ENC_CS / 16, ENC_TB = 64;
+
+template <bool W1>
+__global__ __launch_bounds__(256) void k_enc_b3(ConvArgs a) {
+    DYN_SMEM(float, smem);
+    uint4* planes = reinterpret_cast<uint4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.z / a.ksplit, sl = blockIdx.z - b * a.ksplit;
+    const int t0 = blockIdx.x * ENC_TB;
+    const int c0 = sl * ENC_CS;
+    int tend = a.in_len ? a.in_len[b] : a.T;
+    if (tend > a.T) tend = a.T;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+    const int LD = ENC_TB + (a.K - 1) * a.dil;
+    const int PS = ENC_NG * 2 * LD;
+    if (!(LAB_ABLATE(a) & 2))
+        stage_planes<ENC_NG, 8>(a.x + (long)b * a.x_bs + (long)c0 * a.x_ld, a.x_ld, LD, t0 - a.pad, tend, a.in_slope, planes, PS, tid, 256);
+    __syncthreads();
+    const int rt = blockIdx.y * 2 + wm;  // 32-row tile of the output
+    if (32 * rt >= a.Cout) return;
+    f32x16 acc[1][1];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+    const int ngt = a.Cin / 16;
+    const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
+    if (!(LAB_ABLATE(a) & 1)) b3_chunk<1, 1, ENC_NG, 1, W1>(acc, wp, planes + brow * LD + bcol + wn * 32, PS, LD, a.K, ngt, a.dil);
+    const int t = t0 + wn * 32 + bcol;
+    if (t >= a.T) return;
+    if (a.ksplit == 1) {
+        epi_std_tile(a, b, 32 * rt, t, brow, acc[0][0], out_len);
+    } else {
+        float* pp = a.part + (((long)sl * a.B + b) * a.Cout + 32 * rt) * a.T + t;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r)
+            if (32 * rt + tile_row(r, brow) < a.Cout) pp[(long)tile_row(r, brow) * a.T] = acc[0][0][r];
+    }
+}
+
+bool enc_conv_b3_supported(int Cin, int Cout, int K, int dil) {
+    return Cin >= ENC_CS && Cin % ENC_CS == 0 && Cout >= 1 && (K == 1 || K == 3) && dil == 1;
+}
+
+void launch_enc_conv_b3(const ConvArgs& a_in, hipStream_t s) {
+    if (a_in.T <= 0 || a_in.B <= 0) return;
+    ConvArgs a = a_in;
+    if (!enc_conv_b3_supported(a.Cin, a.Cout, a.K, a.dil) || a.epi != EPI_STD || !a.wb3 || a.shuf_s || a.Tin >= 0)
+        throw std::runtime_error("enc_conv_b3: unsupported conv");
+    if (a.ksplit != a.Cin / ENC_CS) throw std::runtime_error("enc_conv_b3: one workgroup per 192-channel slice");
+    if (a.ksplit > 1 && !a.part) throw std::runtime_error("enc_conv_b3: split conv without a partial-sum buffer");
+    static const int ablate = lab_getenv("MI355VITS_CONV_ABLATE") ? atoi(lab_getenv("MI355VITS_CONV_ABLATE")) : 0;
+    a.ablate = ablate;
+    const int LD = ENC_TB + (a.K - 1) * a.dil;
+    const size_t shmem = (size_t)3 * ENC_NG * 2 * LD * 16;
+    dim3 grid((a.T + ENC_TB - 1) / ENC_TB, (a.Cout + 63) / 64, a.B * a.ksplit);
+    auto go = [&](auto kfn) {
+#ifndef MI355_EMU
+        set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
+#endif
+        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+    };
+    if (a.math == MATH_BF16W) go(k_enc_b3<true>);
+    else go(k_enc_b3<false>);
+}
+
 namespace {
 
 struct TileCfg { int MT, NT, WM, WN; };

@@ -91,6 +91,31 @@ __global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
             const int c = cg + i * LN_CG;
             v[i] = a.x[base + (long)(c < a.C ? c : a.C - 1) * a.T];  // clamped: unconditional loads, batched
         }
+        for (int p = 1; p < a.nparts; ++p) {  // split conv: the slices' sums in slice order
+            float q[LN_NPT];
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) {
+                const int c = cg + i * LN_CG;
+                q[i] = a.x[(long)p * a.part_stride + base + (long)(c < a.C ? c : a.C - 1) * a.T];
+            }
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) v[i] += q[i];
+        }
+        if (a.bias) {
+            float q[LN_NPT];
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) {
+                const int c = cg + i * LN_CG;
+                q[i] = a.bias[c < a.C ? c : a.C - 1];
+            }
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) v[i] += q[i];
+        }
+        if (a.premask_len) {
+            const bool dead = t >= a.premask_len[b];
+            MI355_UNROLL
+            for (int i = 0; i < LN_NPT; ++i) v[i] = dead ? 0.0f : v[i];
+        }
         if (a.res) {
             float r[LN_NPT];
             MI355_UNROLL
@@ -173,6 +198,7 @@ __global__ __launch_bounds__(256) void k_layernorm(LNArgs a) {
 }
 void launch_layernorm(const LNArgs& a, hipStream_t s) {
     if (a.T <= 0) return;
+    if ((a.nparts > 1 || a.bias || a.premask_len) && a.C > LN_CG * LN_NPT) throw std::runtime_error("layernorm: split-conv input needs C <= 256");
     if (a.C <= LN_CG * LN_NPT) LAUNCH_KERNEL(k_layernorm<true>, dim3((a.T + LN_TT - 1) / LN_TT, a.B), dim3(256), 256 * sizeof(float), s, a);
     else LAUNCH_KERNEL(k_layernorm<false>, dim3((a.T + LN_TT - 1) / LN_TT, a.B), dim3(256), 256 * sizeof(float), s, a);
 }
@@ -551,7 +577,66 @@ constexpr int NB_MAX = 16;
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
-// One thread per (b,t): rational-quadratic spline inverse with linear tails (HF modeling_vits.py:93-302).
+// Rational-quadratic spline inverse with linear tails (HF modeling_vits.py:93-302) of one value x1 inside the tail
+// bound; th[i * stride] = the 3 nb - 1 unnormalised parameters of this (b, t).
+__device__ __forceinline__ float spline_inverse_at(const float* th, long stride, float x1, int nb, float tb, float inv_sqrt_fc) {
+    const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
+    float cw[NB_MAX + 1], chh[NB_MAX + 1], dv[NB_MAX + 1];
+    // widths
+    {
+        float u[NB_MAX], mx = -3.0e38f, sum = 0.0f;
+        for (int i = 0; i < nb; ++i) { u[i] = th[(long)i * stride] * inv_sqrt_fc; mx = fmaxf(mx, u[i]); }
+        for (int i = 0; i < nb; ++i) { u[i] = expf(u[i] - mx); sum += u[i]; }
+        float cum = 0.0f;
+        cw[0] = -tb;
+        for (int i = 0; i < nb; ++i) {
+            cum += min_w + (1.0f - min_w * nb) * (u[i] / sum);
+            cw[i + 1] = 2.0f * tb * cum - tb;
+        }
+        cw[nb] = tb;
+    }
+    // heights
+    {
+        float u[NB_MAX], mx = -3.0e38f, sum = 0.0f;
+        for (int i = 0; i < nb; ++i) { u[i] = th[(long)(nb + i) * stride] * inv_sqrt_fc; mx = fmaxf(mx, u[i]); }
+        for (int i = 0; i < nb; ++i) { u[i] = expf(u[i] - mx); sum += u[i]; }
+        float cum = 0.0f;
+        chh[0] = -tb;
+        for (int i = 0; i < nb; ++i) {
+            cum += min_h + (1.0f - min_h * nb) * (u[i] / sum);
+            chh[i + 1] = 2.0f * tb * cum - tb;
+        }
+        chh[nb] = tb;
+    }
+    // derivatives: interior from theta, both ends = min_d + softplus(log(exp(1 - min_d) - 1))
+    {
+        const float cst = logf(expf(1.0f - min_d) - 1.0f);
+        dv[0] = min_d + softplus_f(cst);
+        dv[nb] = dv[0];
+        for (int i = 1; i < nb; ++i) dv[i] = min_d + softplus_f(th[(long)(2 * nb + i - 1) * stride]);
+    }
+    int bin = -1;
+    for (int i = 0; i <= nb; ++i) {
+        const float loc = (i == nb) ? chh[i] + 1e-6f : chh[i];
+        bin += (x1 >= loc) ? 1 : 0;
+    }
+    bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
+    const float in_cw = cw[bin], in_w = cw[bin + 1] - cw[bin];
+    const float in_ch = chh[bin], in_h = chh[bin + 1] - chh[bin];
+    const float delta = in_h / in_w;
+    const float d0 = dv[bin], d1 = dv[bin + 1];
+    const float t1 = d0 + d1 - 2.0f * delta;
+    const float u = x1 - in_ch;
+    const float t3 = u * t1;
+    const float qa = in_h * (delta - d0) + t3;
+    const float qb = in_h * d0 - t3;
+    const float qc = -delta * u;
+    const float disc = qb * qb - 4.0f * qa * qc;
+    const float root = (2.0f * qc) / (-qb - sqrtf(disc));
+    return root * in_w + in_cw;
+}
+
+// One thread per (b,t)
 __global__ __launch_bounds__(64) void k_spline_inverse(float* z, int ch_x0, const float* theta, const int* len, int T,
                                                        int nb, float tb, float inv_sqrt_fc) {
     const int b = blockIdx.y;
@@ -563,63 +648,7 @@ __global__ __launch_bounds__(64) void k_spline_inverse(float* z, int ch_x0, cons
     const bool valid = t < len[b];
     const float x1 = *z1;
     float outv = x1;
-    if (x1 >= -tb && x1 <= tb) {
-        const float* th = theta + (long)b * (3 * nb - 1) * T + t;
-        const float min_w = 1e-3f, min_h = 1e-3f, min_d = 1e-3f;
-        float cw[NB_MAX + 1], chh[NB_MAX + 1], dv[NB_MAX + 1];
-        // widths
-        {
-            float u[NB_MAX], mx = -3.0e38f, sum = 0.0f;
-            for (int i = 0; i < nb; ++i) { u[i] = th[(long)i * T] * inv_sqrt_fc; mx = fmaxf(mx, u[i]); }
-            for (int i = 0; i < nb; ++i) { u[i] = expf(u[i] - mx); sum += u[i]; }
-            float cum = 0.0f;
-            cw[0] = -tb;
-            for (int i = 0; i < nb; ++i) {
-                cum += min_w + (1.0f - min_w * nb) * (u[i] / sum);
-                cw[i + 1] = 2.0f * tb * cum - tb;
-            }
-            cw[nb] = tb;
-        }
-        // heights
-        {
-            float u[NB_MAX], mx = -3.0e38f, sum = 0.0f;
-            for (int i = 0; i < nb; ++i) { u[i] = th[(long)(nb + i) * T] * inv_sqrt_fc; mx = fmaxf(mx, u[i]); }
-            for (int i = 0; i < nb; ++i) { u[i] = expf(u[i] - mx); sum += u[i]; }
-            float cum = 0.0f;
-            chh[0] = -tb;
-            for (int i = 0; i < nb; ++i) {
-                cum += min_h + (1.0f - min_h * nb) * (u[i] / sum);
-                chh[i + 1] = 2.0f * tb * cum - tb;
-            }
-            chh[nb] = tb;
-        }
-        // derivatives: interior from theta, both ends = min_d + softplus(log(exp(1 - min_d) - 1))
-        {
-            const float cst = logf(expf(1.0f - min_d) - 1.0f);
-            dv[0] = min_d + softplus_f(cst);
-            dv[nb] = dv[0];
-            for (int i = 1; i < nb; ++i) dv[i] = min_d + softplus_f(th[(long)(2 * nb + i - 1) * T]);
-        }
-        int bin = -1;
-        for (int i = 0; i <= nb; ++i) {
-            const float loc = (i == nb) ? chh[i] + 1e-6f : chh[i];
-            bin += (x1 >= loc) ? 1 : 0;
-        }
-        bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
-        const float in_cw = cw[bin], in_w = cw[bin + 1] - cw[bin];
-        const float in_ch = chh[bin], in_h = chh[bin + 1] - chh[bin];
-        const float delta = in_h / in_w;
-        const float d0 = dv[bin], d1 = dv[bin + 1];
-        const float t1 = d0 + d1 - 2.0f * delta;
-        const float u = x1 - in_ch;
-        const float t3 = u * t1;
-        const float qa = in_h * (delta - d0) + t3;
-        const float qb = in_h * d0 - t3;
-        const float qc = -delta * u;
-        const float disc = qb * qb - 4.0f * qa * qc;
-        const float root = (2.0f * qc) / (-qb - sqrtf(disc));
-        outv = root * in_w + in_cw;
-    }
+    if (x1 >= -tb && x1 <= tb) outv = spline_inverse_at(theta + (long)b * (3 * nb - 1) * T + t, T, x1, nb, tb, inv_sqrt_fc);
     *z1 = valid ? outv : 0.0f;
     if (!valid) *z0 = 0.0f;
 }
@@ -628,6 +657,381 @@ void launch_spline_inverse(float* z, int ch_x0, const float* theta, const int* l
     if (nbins > NB_MAX) throw std::runtime_error("spline: too many bins");
     LAUNCH_KERNEL(k_spline_inverse, dim3((T + 63) / 64, B), dim3(64), 0, s, z, ch_x0, theta, len, T, nbins, tail,
                   inv_sqrt_fc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole DDS stack of the duration predictor (A.6 / A.7) in ONE launch, with what surrounds it:
+//   pre:    x = conv1x1(src) + bias (+ cond[b])                 (StochasticDurationPredictor.pre + cond)
+//        or x = w[c] * z[b, zch, t] + bias[c] + src[b, c, t]    (ConvFlow.pre on one channel + conditioning g)
+//   layers: x += gelu(LN2(conv1x1(gelu(LN1(dwconv_{K, K^i}(x * mask))))))        i = 0 .. n_layers - 1
+//   proj:   out = (conv1x1(x * mask) + bias) * mask             (dp.proj -> h, ConvFlow.proj -> theta)
+//   spline: z[b, 1 - zch] <- RQS^-1(z[b, 1 - zch]; theta), z *= mask            (theta never leaves the CU)
+// The text side of the graph is bound by launch latency, not by bytes ([32, 192, 128] is 3 MB): 5 + 3 x 6 launches become
+// 1 + 3.  A workgroup owns 32 output columns of all C channels and keeps a 64-column window of x in LDS (16 columns of halo
+// each side; the depthwise taps reach sum_i K^i (K - 1) / 2 = 13 columns at K = 3, three layers): every layer but the last
+// is computed on the whole window — a column of the window is right as long as its receptive field lies inside it, and the
+// 32 owned columns' fields do — the last one on the owned columns only.  Per element the arithmetic (tap order, the channel
+// groups' order in the LayerNorm sums, k order of the matrix-core 1x1 convs) is that of k_dds_layer / k_convflow_pre /
+// the pointwise conv kernels / k_spline_inverse, whatever the column's position in a window: results do not depend on
+// the tiling, the batch or the neighbours.
+// ------------------------------------------------------------------------------------------------
+template <int C, int W, int NCT>
+__device__ __forceinline__ void dds_mm(const float* __restrict__ wq /* packed A fragments of the row tile + lane */,
+                                       const float* __restrict__ yb /* LDS B operand: row brow, first column + bcol */,
+                                       f32x16 (&acc)[NCT], bool skip = false) {
+    MI355_UNROLL
+    for (int j = 0; j < NCT; ++j)
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    if (skip) return;  // lab build: timing without the matrix work
+    // weight fragments through a 16-register ring, 8 k-steps (>= 512 cycles of matrix work) ahead of their use
+    float ra[16];
+    MI355_UNROLL
+    for (int u = 0; u < 8; ++u) ra[u] = wq[u * 64];
+    for (int cp0 = 0; cp0 < C / 2; cp0 += 16) {
+        MI355_UNROLL
+        for (int u = 0; u < 16; ++u) {
+            const int nxt = cp0 + u + 8 < C / 2 ? cp0 + u + 8 : C / 2 - 1;  // the tail re-reads the last record
+            ra[(u + 8) & 15] = wq[nxt * 64];
+            MI355_UNROLL
+            for (int j = 0; j < NCT; ++j) acc[j] = MFMA_32x32x2_F32(ra[u], yb[(cp0 + u) * 2 * W + 32 * j], acc[j]);
+        }
+    }
+}
+
+// Every global load of the kernel is unconditional (clamped index, value selected afterwards) and sits in a batch ahead of
+// its first use: a load under a test makes hipcc branch around it and wait for each one in turn.
+template <int NW>  // C = 32 NW
+__global__ __launch_bounds__(64 * NW) void k_dds_stack(DdsStackArgs a) {
+    constexpr int C = 32 * NW, NCG = 2 * NW, NPT = 16, W = DDS_STACK_W, OFF = DDS_STACK_OFF, K = DDS_STACK_K;
+    static_assert((C / 2) % 16 == 0, "dds_mm walks the channel pairs 16 at a time");
+    DYN_SMEM(float, smem);
+    float* X = smem;                // [C][W] the running x of the stack (after proj: theta [nth][32])
+    float* Y = smem + C * W;        // [C][W] B operand of the 1x1 convs, then their raw result
+    float* red = smem + 2 * C * W;  // [NCG][W]
+    const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
+    const int col = tid & 31, cg = tid >> 5;
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 32 - OFF;  // time of window column 0
+    const int L = a.len[b];
+    const int tend = L < a.T ? L : a.T;
+    auto GELU = [&](float x) { return (LAB_ABLATE(a) & 1) ? x : gelu_erf(x); };
+    // per column (nh halves of the window per thread): sum over the channel groups in a fixed order
+    auto col_sum = [&](float (&v)[2], int nh, int cb) {
+        if (LAB_ABLATE(a) & 16) return;
+        __syncthreads();
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h)
+            if (h < nh) red[cg * W + cb + h * 32 + col] = v[h];
+        __syncthreads();
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h)
+            if (h < nh) {
+                float s = 0.0f;
+                MI355_UNROLL
+                for (int g = 0; g < NCG; ++g) s += red[g * W + cb + h * 32 + col];
+                v[h] = s;
+            }
+    };
+    int rowc[16];  // the 16 rows of a 32 x 32 accumulator tile this lane holds (tile row 0 = channel 32 w)
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) rowc[r] = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * brow;
+    // ---- pre
+    if (a.pre_mode == DDS_PRE_AFFINE) {
+        float pw[NPT], pb[NPT], zv[2], g[2][NPT];
+        bool in[2];
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) {
+            pw[i] = a.pre_w[cg + NCG * i];
+            pb[i] = a.pre_b[cg + NCG * i];
+        }
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + h * 32 + col;
+            in[h] = t >= 0 && t < a.T;
+            const int tc = in[h] ? t : 0;
+            zv[h] = a.z[((long)b * 2 + a.zch) * a.T + tc];
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) g[h][i] = a.src[((long)b * C + cg + NCG * i) * a.T + tc];
+        }
+        SCHED_FENCE();
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h)
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                const float v = fmaf(pw[i], zv[h], pb[i]) + g[h][i];
+                X[(cg + NCG * i) * W + h * 32 + col] = in[h] ? v : 0.0f;
+            }
+    } else {
+        float xv[2][NPT];
+        bool in[2];
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + h * 32 + col;
+            in[h] = t >= 0 && t < a.T;
+            const int tc = in[h] ? t : 0;
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) xv[h][i] = a.src[((long)b * C + cg + NCG * i) * a.T + tc];
+        }
+        float pb[16], cd[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            pb[r] = a.pre_b[rowc[r]];
+            cd[r] = a.cond ? a.cond[(long)b * a.cond_bs + rowc[r]] : 0.0f;
+        }
+        SCHED_FENCE();
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h)
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) Y[(cg + NCG * i) * W + h * 32 + col] = in[h] ? xv[h][i] : 0.0f;
+        __syncthreads();
+        f32x16 acc[2];
+        dds_mm<C, W, 2>(a.pre_w + (long)w * (C / 2) * 64 + lane, Y + brow * W + bcol, acc, LAB_ABLATE(a) & 2);
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r)
+            MI355_UNROLL
+            for (int j = 0; j < 2; ++j) {
+                float v = acc[j][r] + pb[r];
+                if (a.cond) v += cd[r];
+                X[rowc[r] * W + 32 * j + bcol] = v;
+            }
+    }
+    __syncthreads();
+    if (LAB_ABLATE(a) & 32) return;
+    // ---- DDS layers
+    int dil = 1;
+    for (int li = 0; li < ((LAB_ABLATE(a) & 64) ? 0 : a.n_layers); ++li) {
+        const bool last = li == a.n_layers - 1;
+        const int nh = last ? 1 : 2;   // halves of the window computed: all 64 columns, or the 32 owned ones
+        const int cb = last ? OFF : 0;  // first computed column
+        // the layer's per-channel parameters: one batch of loads
+        float dwb[NPT], dww[NPT][K], g1[NPT], b1[NPT];
+        {
+            const float* dw_w = a.dw_w[li];
+            const float* dw_b = a.dw_b[li];
+            const float* pg1 = a.g1[li];
+            const float* pb1 = a.b1[li];
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                const int c = cg + NCG * i;
+                dwb[i] = dw_b[c];
+                MI355_UNROLL
+                for (int k = 0; k < K; ++k) dww[i][k] = dw_w[c * K + k];
+                g1[i] = pg1[c];
+                b1[i] = pb1[c];
+            }
+        }
+        // depthwise conv of x * mask + LN1 + GELU -> Y
+        if (!(LAB_ABLATE(a) & 4)) {
+            float v[2][NPT];
+            const int pad = (K * dil - dil) / 2;
+            MI355_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) continue;
+                const int j = cb + h * 32 + col;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) v[h][i] = dwb[i];
+                MI355_UNROLL
+                for (int k = 0; k < K; ++k) {
+                    const int jj = j - pad + k * dil, tt = t0 + jj;
+                    const bool in = tt >= 0 && tt < tend && jj >= 0 && jj < W;
+                    const int jc = in ? jj : 0;
+                    MI355_UNROLL
+                    for (int i = 0; i < NPT; ++i) {
+                        const float xv = X[(cg + NCG * i) * W + jc];
+                        v[h][i] = fmaf(dww[i][k], in ? xv : 0.0f, v[h][i]);  // an absent tap adds w * 0: the value is unchanged
+                    }
+                }
+            }
+            float st[2] = {0.0f, 0.0f};
+            MI355_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) continue;
+                float sum = 0.0f;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) sum += v[h][i];
+                st[h] = sum;
+            }
+            col_sum(st, nh, cb);
+            float mean[2] = {0.0f, 0.0f}, sq[2] = {0.0f, 0.0f};
+            MI355_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) continue;
+                mean[h] = st[h] / (float)C;
+                float q = 0.0f;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) { const float d = v[h][i] - mean[h]; q += d * d; }
+                sq[h] = q;
+            }
+            col_sum(sq, nh, cb);
+            MI355_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) continue;
+                const float rstd = 1.0f / sqrtf(sq[h] / (float)C + 1e-5f);
+                const int j = cb + h * 32 + col;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) Y[(cg + NCG * i) * W + j] = GELU((v[h][i] - mean[h]) * rstd * g1[i] + b1[i]);
+            }
+        }
+        // the second half's parameters: their latency hides behind the matrix work
+        float bias[16], g2[NPT], b2[NPT];
+        {
+            const float* pbias = a.bias1x1[li];
+            const float* pg2 = a.g2[li];
+            const float* pb2 = a.b2[li];
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) bias[r] = pbias[rowc[r]];
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                g2[i] = pg2[cg + NCG * i];
+                b2[i] = pb2[cg + NCG * i];
+            }
+        }
+        __syncthreads();
+        // 1x1 conv on the f32 matrix cores: wave w -> rows 32 w .., the computed columns
+        {
+            f32x16 acc[2];
+            const float* wq = a.w1x1[li] + (long)w * (C / 2) * 64 + lane;
+            if (last) {
+                f32x16 a1[1];
+                dds_mm<C, W, 1>(wq, Y + brow * W + cb + bcol, a1, LAB_ABLATE(a) & 2);
+                acc[0] = a1[0];
+                acc[1] = a1[0];
+            } else {
+                dds_mm<C, W, 2>(wq, Y + brow * W + cb + bcol, acc, LAB_ABLATE(a) & 2);
+            }
+            __syncthreads();  // every wave is done reading Y: the raw conv result takes its place
+            MI355_UNROLL
+            for (int j = 0; j < 2; ++j) {
+                if (j >= nh) continue;
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) Y[rowc[r] * W + cb + 32 * j + bcol] = acc[j][r] + bias[r];
+            }
+        }
+        __syncthreads();
+        // LN2 + GELU + residual -> X
+        if (!(LAB_ABLATE(a) & 8)) {
+            float z[2][NPT];
+            float st[2] = {0.0f, 0.0f};
+            MI355_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) continue;
+                const int j = cb + h * 32 + col;
+                float sum = 0.0f;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) {
+                    z[h][i] = Y[(cg + NCG * i) * W + j];
+                    sum += z[h][i];
+                }
+                st[h] = sum;
+            }
+            col_sum(st, nh, cb);
+            float mean[2] = {0.0f, 0.0f}, sq[2] = {0.0f, 0.0f};
+            MI355_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) continue;
+                mean[h] = st[h] / (float)C;
+                float q = 0.0f;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) { const float d = z[h][i] - mean[h]; q += d * d; }
+                sq[h] = q;
+            }
+            col_sum(sq, nh, cb);
+            MI355_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) continue;
+                const float rstd = 1.0f / sqrtf(sq[h] / (float)C + 1e-5f);
+                const int j = cb + h * 32 + col;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) {
+                    const int c = cg + NCG * i;
+                    X[c * W + j] += GELU((z[h][i] - mean[h]) * rstd * g2[i] + b2[i]);
+                }
+            }
+        }
+        __syncthreads();
+        dil *= K;
+    }
+    // ---- x (the stack's result) to global, where somebody wants it (tests; the engine keeps it on chip)
+    const int t_own = t0 + OFF + col;
+    if (a.x_out && t_own < a.T) {
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) {
+            const int c = cg + NCG * i;
+            a.x_out[((long)b * C + c) * a.T + t_own] = X[c * W + OFF + col];
+        }
+    }
+    if (!a.proj_w) return;
+    // ---- proj: B operand = x * mask on the owned columns
+    {
+        const bool in = t_own < tend;
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) {
+            const int c = cg + NCG * i;
+            Y[c * W + OFF + col] = in ? X[c * W + OFF + col] : 0.0f;
+        }
+    }
+    const int ntp = (a.proj_cout + 31) / 32;
+    float pjb[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) pjb[r] = a.proj_b[rowc[r] < a.proj_cout ? rowc[r] : 0];
+    float x1 = 0.0f;  // the spline's input of this thread's column (threads 0 .. 31)
+    const int t_sp = t0 + OFF + (tid & 31);
+    if (a.spline) x1 = a.z[((long)b * 2 + (1 - a.zch)) * a.T + (t_sp < a.T ? t_sp : 0)];
+    __syncthreads();
+    {
+        f32x16 a1[1];
+        if (w < ntp) dds_mm<C, W, 1>(a.proj_w + (long)w * (C / 2) * 64 + lane, Y + brow * W + OFF + bcol, a1, LAB_ABLATE(a) & 2);
+        // theta takes the place of x (every thread has read its x above; the barrier below orders the spline's reads)
+        const int t = t0 + OFF + bcol;
+        if (w < ntp) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int co = rowc[r];
+                if (co < a.proj_cout) {
+                    float v = a1[0][r] + pjb[r];
+                    if (t >= tend) v = 0.0f;
+                    if (a.out && t < a.T) a.out[((long)b * a.proj_cout + co) * a.T + t] = v;
+                    if (a.spline) X[co * 32 + bcol] = v;
+                }
+            }
+        }
+    }
+    if (!a.spline) return;
+    __syncthreads();
+    if (tid < 32 && t_sp < a.T) {
+        float* z0 = a.z + ((long)b * 2 + a.zch) * a.T + t_sp;
+        float* z1 = a.z + ((long)b * 2 + (1 - a.zch)) * a.T + t_sp;
+        const bool valid = t_sp < L;
+        float outv = x1;
+        if (x1 >= -a.tail && x1 <= a.tail) outv = spline_inverse_at(X + tid, 32, x1, a.nb, a.tail, a.inv_sqrt_fc);
+        *z1 = valid ? outv : 0.0f;
+        if (!valid) *z0 = 0.0f;
+    }
+}
+
+bool dds_stack_supported(int C, int K, int n_layers, int proj_cout) {
+    if (C != 192 || K != DDS_STACK_K || n_layers < 1 || n_layers > DDS_STACK_MAX_LAYERS || proj_cout > C) return false;
+    int reach = 0, dil = 1;
+    for (int i = 0; i < n_layers; ++i) { reach += dil * (K - 1) / 2; dil *= K; }
+    return reach <= DDS_STACK_OFF;
+}
+
+void launch_dds_stack(const DdsStackArgs& a, int C, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    if (!dds_stack_supported(C, a.K, a.n_layers, a.proj_w ? a.proj_cout : 0)) throw std::runtime_error("dds_stack: unsupported shape");
+    if (a.spline && (a.nb > NB_MAX || 3 * a.nb - 1 != a.proj_cout)) throw std::runtime_error("dds_stack: spline parameter count");
+    static const int ablate = lab_getenv("MI355VITS_DDS_ABLATE") ? atoi(lab_getenv("MI355VITS_DDS_ABLATE")) : 0;
+    DdsStackArgs av = a;
+    av.ablate = ablate;
+    dim3 grid((a.T + 31) / 32, a.B);
+    const size_t sh = ((size_t)2 * C * DDS_STACK_W + (size_t)(C / 16) * DDS_STACK_W) * sizeof(float);
+    auto kfn = k_dds_stack<6>;
+#ifndef MI355_EMU
+    set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
+#endif
+    LAUNCH_KERNEL(kfn, grid, dim3(64 * 6), sh, s, av);
 }
 
 __global__ __launch_bounds__(64) void k_sdp_noise(float* z, const float* injected, int T, float noise_w,

@@ -28,3 +28,15 @@ def gpu_lib():
     from mimic3_amd._native import default_library
 
     return default_library()
+
+
+@pytest.fixture(scope="session")
+def lab_lib():
+    """The LAB build of the HIP library (-DMI355_LAB: kernel-choice switches for A/B tests) on the real device; built in-tree by
+    ``__graft_entry__.build()`` / ``python -m mimic3_amd.build lab``.  Test infrastructure: the product never opens it."""
+    from mimic3_amd._native import NativeLibrary
+
+    path = os.path.join(ROOT, "mimic3_amd", "csrc", "libmi355vits_lab.so")
+    if not os.path.exists(path):
+        pytest.skip("lab build of the library not present (python -m mimic3_amd.build lab)")
+    return NativeLibrary(path)

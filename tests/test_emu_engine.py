@@ -419,11 +419,12 @@ def test_bf16x3_engine_path_long_utterance_uses_the_staged_split_kernels(emu_lib
     eng.close()
 
 
-def test_wide_encoder_ffn_conv_on_the_split_kernel(emu_lib):
-    """The text encoder's 192 -> 768, k = 3 FFN conv (K Cin >= 512, >= 4 row blocks) runs on the split-bf16 staged kernel in
-    MATH_BF16X3 — a rule of the layer alone, so a row's bits do not depend on what it is batched with even though the
-    tile shape follows the grid size.  Encoder taps and waveform vs the oracle; batched == unbatched bitwise; and the
-    f32 kernel (MI355VITS_NO_ENC_B3=1) stays within the same tolerance of it."""
+def test_encoder_convs_on_the_slice_kernel(emu_lib):
+    """The text encoder's dense convs (q/k/v, o, FFN 192 -> 768 -> 192, k = 3) in MATH_BF16X3 run on k_enc_b3: 64 x 64 tiles over
+    one 192-channel slice staged once; the FFN's second conv is four slices whose raw sums the LayerNorm launch adds up.  A rule
+    of the layer alone, so a row's bits do not depend on what it is batched with.  Encoder taps and waveform vs the oracle;
+    batched == unbatched bitwise (rows ending inside a tile, 70 phonemes = two column tiles); and the general conv kernels
+    (MI355VITS_NO_ENC_GEMM=1) stay within the same tolerance of it."""
     import os
 
     cfg = VitsConfig.tiny_h192()
@@ -442,11 +443,11 @@ def test_wide_encoder_ffn_conv_on_the_split_kernel(emu_lib):
     L = int(one["lengths"][0])
     assert np.array_equal(full["audio"][1, :L], one["audio"][0, :L])
     eng.close()
-    os.environ["MI355VITS_NO_ENC_B3"] = "1"
+    os.environ["MI355VITS_NO_ENC_GEMM"] = "1"
     try:
         eng = Engine(blob, library=emu_lib)
     finally:
-        del os.environ["MI355VITS_NO_ENC_B3"]
+        del os.environ["MI355VITS_NO_ENC_GEMM"]
     eng.set_math("bf16x3")
     ref = eng.run(ids, lengths, (0.667, 1.0, 0.8), forced_durations=forced, seed=41)
     eng.close()
@@ -601,6 +602,40 @@ def test_fused_dds_layer_kernel(emu_lib, cfgname, monkeypatch):
     assert np.array_equal(fused[1], plain[1]) and np.abs(fused[0] - plain[0]).max() < 1e-4
 
 
+@pytest.mark.parametrize("n_speakers", [1, 3])
+def test_dds_stack_kernel(emu_lib, n_speakers, monkeypatch):
+    """k_dds_stack (pre + the DDS layers + proj, and for a ConvFlow the spline, in ONE launch over a 64-column window of x in LDS)
+    against one launch per piece (MI355VITS_NO_DDS_STACK=1): a ragged batch over three workgroups per row (row 1 ends inside the
+    second one, row 2 inside a window's halo) must give the same h, logw and durations bit for bit — the per-element arithmetic
+    is the same whatever the column's place in a window; and the oracle agrees (check_parity)."""
+    cfg = VitsConfig.tiny_h192(n_speakers=n_speakers)
+    w = W.synthetic_weights(cfg, seed=93, frames_per_id=2.5)
+    Tx = 75
+    ids = np.random.default_rng(10).integers(1, cfg.num_symbols, (3, Tx))
+    lengths = [Tx, 41, 66]
+    sid = np.array([2, 0, 1]) if cfg.is_multispeaker else None
+    res = {}
+    monkeypatch.setenv("MI355VITS_NO_ENC_GEMM", "1")  # the pieces' 1x1 convs on the f32 matrix cores, as in the stack
+    for tag in ("stack", "pieces"):
+        if tag == "pieces":
+            monkeypatch.setenv("MI355VITS_NO_DDS_STACK", "1")
+        eng = Engine(W.pack(cfg, w), library=emu_lib)
+        eng.profile_enable(True)
+        eng.run(ids, lengths, [0.3, 1, 0.8], sid, debug_taps=True, seed=5)
+        labels = set(eng.profile_report())
+        assert ("dp.stack" in labels) == (tag == "stack") and ("convflow.stack" in labels) == (tag == "stack"), labels
+        assert ("dds.layer" in labels) == (tag == "pieces") and ("spline" in labels) == (tag == "pieces"), labels
+        res[tag] = eng.tap("dp.h"), eng.tap("logw"), eng.tap("w_ceil")
+        eng.close()
+    for bi, L in enumerate(lengths):
+        assert np.array_equal(res["stack"][0][bi, :, :L], res["pieces"][0][bi, :, :L])
+        assert np.array_equal(res["stack"][1][bi, :, :L], res["pieces"][1][bi, :, :L])
+    assert np.array_equal(res["stack"][2], res["pieces"][2])
+    monkeypatch.delenv("MI355VITS_NO_DDS_STACK")
+    monkeypatch.delenv("MI355VITS_NO_ENC_GEMM")
+    check_parity(emu_lib, cfg, ids=ids, lengths=np.array(lengths), noise=True, seed=93, weights=w, sid=sid)
+
+
 @pytest.mark.parametrize("dils", [((1, 2), (2, 6), (3, 12)), ((1, 3), (1, 3), (1, 3)), ((3, 1), (2, 1), (1, 2))])
 def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
     """k_mrf_p (32-channel stage, MATH_BF16X3, the default path): x / x1 as bf16 planes split ONCE in LDS, the running conv's
@@ -639,3 +674,29 @@ def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
     for bi in range(3):
         L = int(outs["fused"]["lengths"][bi])
         assert rel_rms(outs["p"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
+
+
+ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
+             (1, 384, 100, 33, 3)]
+
+
+@pytest.mark.parametrize("case", ENC_CASES)
+def test_encoder_slice_kernel_vs_fp64(emu_lib, case):
+    """k_enc_b3 (impl 3) against an fp64 conv: pointwise and k = 3 convs of the encoder's shapes, one column, exactly one tile, one
+    column into the next tile, ragged input / output masks, an output width that is not a multiple of 32, and split convs (768 and
+    384 input channels: the slices' raw sums)."""
+    B, Cin, Cout, T, K = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    split = Cin > 192
+    bias = None if split else rng.standard_normal(Cout).astype(np.float32)
+    res = None if split else rng.standard_normal((B, Cout, T)).astype(np.float32)
+    in_len = np.array([T] + [max(1, T - 5)] * (B - 1), np.int32)
+    y = emu_lib.test_conv1d(x, w, bias, res, impl=3, in_len=in_len, out_len=None if split else in_len)
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).double()[:, None, :]
+    ref = F.conv1d(torch.from_numpy(x).double() * tm, torch.from_numpy(w).double(), None if split else torch.from_numpy(bias).double(),
+                   padding=(K - 1) // 2)
+    if not split:
+        ref = (ref + torch.from_numpy(res).double()) * tm
+    assert np.abs(y - ref.numpy()).max() < 5e-5, np.abs(y - ref.numpy()).max()

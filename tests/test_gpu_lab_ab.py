@@ -1,0 +1,76 @@
+"""A/B tests on the real MI355X between the default kernels and the paths they replaced, through the LAB build of the library
+(-DMI355_LAB: the product build reads no kernel-choice switch).  Same C ABI, same sources; the environment variables below are
+read when an engine is created."""
+import numpy as np
+import pytest
+
+from mimic3_amd import weights as W
+from mimic3_amd._native import Engine
+from mimic3_amd.config import VitsConfig
+from tests.util import REL_RMS_TOL, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("voice", ["apope_low", "vctk_low"])
+def test_dds_stack_equals_one_launch_per_piece(lab_lib, voice, monkeypatch):
+    """k_dds_stack (pre + DDS layers + proj (+ spline) in one launch, x in a 64-column LDS window) vs one launch per piece on the
+    device: durations equal, h and logw to f32 rounding on every valid column (the two sets of kernels are compiled separately and
+    hipcc contracts their multiply-adds differently; on the CPU model, tests/test_emu_engine.py, they agree bit for bit), audio to
+    the parity tolerance; ragged rows that end inside a workgroup's columns, inside a halo, and a one-phoneme row."""
+    cfg = VitsConfig.apope_low() if voice == "apope_low" else VitsConfig.vctk_low()
+    w = W.synthetic_weights(cfg, seed=31, frames_per_id=1.0)
+    blob = W.pack(cfg, w)
+    Tx = 150
+    rng = np.random.default_rng(3)
+    ids = rng.integers(1, cfg.num_symbols, (5, Tx))
+    lengths = [Tx, 97, 130, 1, 33]
+    sid = np.array([5, 0, 108, 17, 3]) if cfg.is_multispeaker else None
+    res = {}
+    monkeypatch.setenv("MI355VITS_NO_ENC_GEMM", "1")  # the pieces' 1x1 convs on the f32 matrix cores, as in the stack
+    for tag in ("stack", "pieces"):
+        if tag == "pieces":
+            monkeypatch.setenv("MI355VITS_NO_DDS_STACK", "1")
+        eng = Engine(blob, library=lab_lib, device=0)
+        eng.profile_enable(True)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], sid, debug_taps=True, seed=11)
+        labels = set(eng.profile_report())
+        assert ("dp.stack" in labels) == (tag == "stack") and ("dds.layer" in labels) == (tag == "pieces"), labels
+        res[tag] = eng.tap("dp.h"), eng.tap("logw"), eng.tap("w_ceil"), out["lengths"].copy(), out["audio"].copy()
+        eng.close()
+    for bi, L in enumerate(lengths):
+        h_s, h_p = res["stack"][0][bi, :, :L], res["pieces"][0][bi, :, :L]
+        assert np.abs(h_s - h_p).max() <= 2e-5 * max(1.0, np.abs(h_p).max()), (bi, np.abs(h_s - h_p).max())
+        assert np.abs(res["stack"][1][bi, :, :L] - res["pieces"][1][bi, :, :L]).max() < 1e-4
+    assert np.array_equal(res["stack"][2], res["pieces"][2]) and np.array_equal(res["stack"][3], res["pieces"][3])
+    for bi in range(len(lengths)):
+        n = int(res["stack"][3][bi])
+        assert rel_rms(res["stack"][4][bi, :n], res["pieces"][4][bi, :n]) < REL_RMS_TOL
+
+
+def test_encoder_slice_kernel_equals_general_conv_kernels(lab_lib, monkeypatch):
+    """k_enc_b3 (q/k/v, o, FFN and the duration predictor's pointwise convs: one 192-channel slice per workgroup, the FFN's second
+    conv as four slices added up by the LayerNorm launch) vs the general conv kernels (MI355VITS_NO_ENC_GEMM=1) on the device:
+    encoder output, prior statistics and h to f32 rounding, durations and lengths equal, audio to the parity tolerance."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=32, frames_per_id=1.0)
+    blob = W.pack(cfg, w)
+    Tx = 150
+    ids = np.random.default_rng(4).integers(1, cfg.num_symbols, (4, Tx))
+    lengths = [Tx, 65, 1, 129]
+    res = {}
+    for tag in ("slice", "general"):
+        if tag == "general":
+            monkeypatch.setenv("MI355VITS_NO_ENC_GEMM", "1")
+        eng = Engine(blob, library=lab_lib, device=0)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], debug_taps=True, seed=12)
+        res[tag] = eng.tap("x"), eng.tap("stats"), eng.tap("dp.h"), eng.tap("w_ceil"), out["lengths"].copy(), out["audio"].copy()
+        eng.close()
+    for bi, L in enumerate(lengths):
+        for k in range(3):
+            a, b = res["slice"][k][bi, :, :L], res["general"][k][bi, :, :L]
+            assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max()), (bi, k, np.abs(a - b).max())
+    assert np.array_equal(res["slice"][3], res["general"][3]) and np.array_equal(res["slice"][4], res["general"][4])
+    for bi in range(len(lengths)):
+        n = int(res["slice"][4][bi])
+        assert rel_rms(res["slice"][5][bi, :n], res["general"][5][bi, :n]) < REL_RMS_TOL

@@ -380,3 +380,29 @@ def test_bf16_weights_mode_at_its_own_tolerance(gpu_lib):
         L = int(out["lengths"][b])
         assert np.array_equal(out["pcm"][b, :L], audio_float_to_int16(out["audio"][b, :L]))
     eng.close()
+
+
+ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
+             (1, 384, 100, 33, 3)]
+
+
+@pytest.mark.parametrize("case", ENC_CASES)
+def test_encoder_slice_kernel_vs_fp64(gpu_lib, case):
+    """k_enc_b3 (impl 3) against an fp64 conv: pointwise and k = 3 convs of the encoder's shapes, one column, exactly one tile, one
+    column into the next tile, ragged input / output masks, an output width that is not a multiple of 32, and split convs (768 and
+    384 input channels: the slices' raw sums)."""
+    B, Cin, Cout, T, K = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    split = Cin > 192
+    bias = None if split else rng.standard_normal(Cout).astype(np.float32)
+    res = None if split else rng.standard_normal((B, Cout, T)).astype(np.float32)
+    in_len = np.array([T] + [max(1, T - 5)] * (B - 1), np.int32)
+    y = gpu_lib.test_conv1d(x, w, bias, res, impl=3, in_len=in_len, out_len=None if split else in_len)
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).double()[:, None, :]
+    ref = F.conv1d(torch.from_numpy(x).double() * tm, torch.from_numpy(w).double(), None if split else torch.from_numpy(bias).double(),
+                   padding=(K - 1) // 2)
+    if not split:
+        ref = (ref + torch.from_numpy(res).double()) * tm
+    assert np.abs(y - ref.numpy()).max() < 5e-5, np.abs(y - ref.numpy()).max()
