@@ -151,7 +151,11 @@ __global__ __launch_bounds__(64) void k_rel_attention_mfma(const float* __restri
 // instead of T / 32 (no spills at T = 512, a quarter of the dependent MFMA chain).  Softmax statistics and the PV
 // partial sums are combined across the waves through LDS in a fixed order (deterministic; key tiles beyond a row's
 // length contribute exact zeros, so the result does not depend on how far the batch pads it).
-template <int NKW>  // key tiles per wave: T <= 128 * NKW
+// DP > 0 (= d / 2, the head's channel pairs, known at compile time): EVERY global operand of the kernel — q, E_k, this wave's
+// K tiles and V tiles — is loaded up front in one batch (48 (3 + 2 NKW) registers at d = 96), so a workgroup waits for L2
+// once instead of once per trip of the two product loops (24 dependent round trips, most of the 30 us a launch took).  The
+// MFMA sequence per output is the same as with DP = 0: identical bits.
+template <int NKW, int DP = 0>  // key tiles per wave: T <= 128 * NKW
 __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __restrict__ qkv, const float* __restrict__ ek,
                                                              const float* __restrict__ ev, const int* __restrict__ len,
                                                              int T, int H, int nh, int W, float* __restrict__ out) {
@@ -180,32 +184,83 @@ __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __rest
     for (int m = 0; m < NKW; ++m)
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) st[m][r] = 0.0f;
-    constexpr int U = 4;
-    for (int cp0 = 0; cp0 < d / 2; cp0 += U) {
-        float qv[U], ekv[U], kv[U][NKW];
-        // loads through clamped indices, the out-of-range test applied to the VALUE: a test around each load makes hipcc
-        // wait for every load in turn (a chain of ~100 dependent L2 round trips per workgroup: 50 us per launch)
+    constexpr int NCT = DP > 0 ? (2 * DP + 31) / 32 : 1;  // 32-channel output tiles of O^T (prefetched V)
+    float vpre[NCT][NKW][16];
+    float evpre[NCT][16];  // wave 0: E_v[r = 2 s2 + brow][channel of this lane], s2 < 16 (window <= 15)
+    if constexpr (DP > 0) {
+        if (w == 0) {
+            MI355_UNROLL
+            for (int ct = 0; ct < NCT; ++ct)
+                MI355_UNROLL
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int r = 2 * s2 + brow, cr = ct * 32 + bcol;
+                    evpre[ct][s2] = ev[(r < nrel ? r : nrel - 1) * d + (cr < d ? cr : 0)];
+                }
+        }
+        float qv[DP], ekv[DP], kv[DP][NKW];
         MI355_UNROLL
-        for (int u = 0; u < U; ++u) {
-            const int c = 2 * (cp0 + u) + brow;
-            const bool cin = c < d;
-            const int cc = cin ? c : d - 1;
-            const float qraw = qb[(long)cc * T + (iq ? i : T - 1)];
-            const float eraw = ek[(bcol < nrel ? bcol : nrel - 1) * d + cc];
-            qv[u] = (iq && cin) ? qraw * scale : 0.0f;
-            ekv[u] = (w == 0 && bcol < nrel && cin) ? eraw : 0.0f;
+        for (int u = 0; u < DP; ++u) {
+            const int c = 2 * u + brow;
+            const float qraw = qb[(long)c * T + (iq ? i : T - 1)];
+            const float eraw = ek[(bcol < nrel ? bcol : nrel - 1) * d + c];
+            qv[u] = iq ? qraw * scale : 0.0f;
+            ekv[u] = (w == 0 && bcol < nrel) ? eraw : 0.0f;
             MI355_UNROLL
             for (int m = 0; m < NKW; ++m) {
                 const int j = (w + 4 * m) * 32 + bcol;
-                const float kraw = kb[(long)cc * T + (j < T ? j : T - 1)];
-                kv[u][m] = (j < T && cin) ? kraw : 0.0f;
+                const float kraw = kb[(long)c * T + (j < T ? j : T - 1)];
+                kv[u][m] = j < T ? kraw : 0.0f;
             }
         }
         MI355_UNROLL
-        for (int u = 0; u < U; ++u) {
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int cr = ct * 32 + bcol;
+            const float* vr = vb + (long)(cr < d ? cr : 0) * T;
+            MI355_UNROLL
+            for (int m = 0; m < NKW; ++m)
+                MI355_UNROLL
+                for (int g = 0; g < 4; ++g)
+                    MI355_UNROLL
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = (w + 4 * m) * 32 + 8 * g + 4 * brow + q;
+                        vpre[ct][m][4 * g + q] = vr[j < T ? j : T - 1];
+                    }
+        }
+        SCHED_FENCE();
+        MI355_UNROLL
+        for (int u = 0; u < DP; ++u) {
             if (w == 0) rl = MFMA_32x32x2_F32(ekv[u], qv[u], rl);
             MI355_UNROLL
             for (int m = 0; m < NKW; ++m) st[m] = MFMA_32x32x2_F32(kv[u][m], qv[u], st[m]);
+        }
+    } else {
+        constexpr int U = 4;
+        for (int cp0 = 0; cp0 < d / 2; cp0 += U) {
+            float qv[U], ekv[U], kv[U][NKW];
+            // loads through clamped indices, the out-of-range test applied to the VALUE: a test around each load makes hipcc
+            // wait for every load in turn (a chain of ~100 dependent L2 round trips per workgroup: 50 us per launch)
+            MI355_UNROLL
+            for (int u = 0; u < U; ++u) {
+                const int c = 2 * (cp0 + u) + brow;
+                const bool cin = c < d;
+                const int cc = cin ? c : d - 1;
+                const float qraw = qb[(long)cc * T + (iq ? i : T - 1)];
+                const float eraw = ek[(bcol < nrel ? bcol : nrel - 1) * d + cc];
+                qv[u] = (iq && cin) ? qraw * scale : 0.0f;
+                ekv[u] = (w == 0 && bcol < nrel && cin) ? eraw : 0.0f;
+                MI355_UNROLL
+                for (int m = 0; m < NKW; ++m) {
+                    const int j = (w + 4 * m) * 32 + bcol;
+                    const float kraw = kb[(long)cc * T + (j < T ? j : T - 1)];
+                    kv[u][m] = (j < T && cin) ? kraw : 0.0f;
+                }
+            }
+            MI355_UNROLL
+            for (int u = 0; u < U; ++u) {
+                if (w == 0) rl = MFMA_32x32x2_F32(ekv[u], qv[u], rl);
+                MI355_UNROLL
+                for (int m = 0; m < NKW; ++m) st[m] = MFMA_32x32x2_F32(kv[u][m], qv[u], st[m]);
+            }
         }
     }
     if (w == 0) {
@@ -253,7 +308,8 @@ __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __rest
     __syncthreads();
     const float inv = 1.0f / (((red[128 + bcol] + red[160 + bcol]) + red[192 + bcol]) + red[224 + bcol]);
 
-    for (int c0 = 0; c0 < d; c0 += 32) {
+    MI355_UNROLL  // (three straight-line tiles when the head size is a compile-time constant)
+    for (int c0 = 0; c0 < (DP > 0 ? 2 * DP : d); c0 += 32) {
         f32x16 o;
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) o[r] = 0.0f;
@@ -268,7 +324,8 @@ __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __rest
                 MI355_UNROLL
                 for (int q = 0; q < 4; ++q) {
                     const int j = (w + 4 * m) * 32 + 8 * g + 4 * brow + q;
-                    vraw[q] = vr[j < T ? j : T - 1];
+                    if constexpr (DP > 0) vraw[q] = vpre[c0 / 32][m][4 * g + q];
+                    else vraw[q] = vr[j < T ? j : T - 1];
                 }
                 MI355_UNROLL
                 for (int q = 0; q < 4; ++q) {
@@ -279,12 +336,24 @@ __global__ __launch_bounds__(256) void k_rel_attention_mfma4(const float* __rest
             }
         }
         if (w == 0) {
-            for (int s2 = 0; s2 < (nrel + 1) / 2; ++s2) {
-                const int r = 2 * s2 + brow;
-                const float eraw = ev[(r < nrel ? r : nrel - 1) * d + (cv ? cr : 0)];
-                const float evv = (cv && r < nrel) ? eraw : 0.0f;
-                const float pv = r < nrel ? tab[r * 32 + bcol] : 0.0f;
-                o = MFMA_32x32x2_F32(evv, pv, o);
+            if constexpr (DP > 0) {
+                MI355_UNROLL
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    if (s2 < (nrel + 1) / 2) {
+                        const int r = 2 * s2 + brow;
+                        const float evv = (cv && r < nrel) ? evpre[c0 / 32][s2] : 0.0f;
+                        const float pv = r < nrel ? tab[r * 32 + bcol] : 0.0f;
+                        o = MFMA_32x32x2_F32(evv, pv, o);
+                    }
+                }
+            } else {
+                for (int s2 = 0; s2 < (nrel + 1) / 2; ++s2) {
+                    const int r = 2 * s2 + brow;
+                    const float eraw = ev[(r < nrel ? r : nrel - 1) * d + (cv ? cr : 0)];
+                    const float evv = (cv && r < nrel) ? eraw : 0.0f;
+                    const float pv = r < nrel ? tab[r * 32 + bcol] : 0.0f;
+                    o = MFMA_32x32x2_F32(evv, pv, o);
+                }
             }
         }
         if (c0 > 0) __syncthreads();  // the previous tile's partials have been consumed
@@ -316,7 +385,15 @@ void launch_rel_attention_mfma(const float* qkv, const float* emb_rel_k, const f
     static const bool one_wave = lab_getenv("MI355VITS_ATTN_ONE_WAVE") != nullptr;  // the older single-wave kernel
     if (!one_wave) {
         const size_t sh4 = (32 * 32 + 2 * 4 * 32 + 4 * 16 * 64) * sizeof(float);
-        if (T <= 128) {
+        static const bool no_pre = lab_getenv("MI355VITS_ATTN_NO_PREFETCH") != nullptr;
+        const bool pre = H / n_heads == 96 && !no_pre;  // the "_low" / default voices' head: all operands prefetched
+        if (T <= 128 && pre) {
+            auto k = k_rel_attention_mfma4<1, 48>;
+            LAUNCH_KERNEL(k, grid, dim3(256), sh4, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+        } else if (T <= 256 && pre) {
+            auto k = k_rel_attention_mfma4<2, 48>;
+            LAUNCH_KERNEL(k, grid, dim3(256), sh4, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
+        } else if (T <= 128) {
             auto k = k_rel_attention_mfma4<1>;
             LAUNCH_KERNEL(k, grid, dim3(256), sh4, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);
         } else if (T <= 256) {

@@ -700,3 +700,23 @@ def test_encoder_slice_kernel_vs_fp64(emu_lib, case):
     if not split:
         ref = (ref + torch.from_numpy(res).double()) * tm
     assert np.abs(y - ref.numpy()).max() < 5e-5, np.abs(y - ref.numpy()).max()
+
+
+def test_attention_with_all_operands_prefetched_is_bitwise_the_same(emu_lib, monkeypatch):
+    """k_rel_attention_mfma4<NKW, 48> (head size 96: q, E_k, K, V, E_v loaded in one batch before the first product) runs the same
+    MFMA sequence as the trip-by-trip form (MI355VITS_ATTN_NO_PREFETCH=1): encoder output bit for bit, T <= 128 and T <= 256."""
+    cfg = VitsConfig.tiny_h192()
+    w = W.synthetic_weights(cfg, seed=55, frames_per_id=1.0)
+    blob = W.pack(cfg, w)
+    for Tx, lengths in ((70, [70, 33]), (150, [150, 129])):
+        ids = np.random.default_rng(Tx).integers(1, cfg.num_symbols, (2, Tx))
+        taps = {}
+        for tag in ("pre", "trips"):
+            if tag == "trips":
+                monkeypatch.setenv("MI355VITS_ATTN_NO_PREFETCH", "1")
+            eng = Engine(blob, library=emu_lib)
+            eng.run(ids, lengths, [0, 1, 0], debug_taps=True)
+            taps[tag] = eng.tap("x")
+            eng.close()
+        monkeypatch.delenv("MI355VITS_ATTN_NO_PREFETCH")
+        assert np.array_equal(taps["pre"], taps["trips"])
