@@ -366,6 +366,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         no_fused_dds_ = lane0.no_fused_dds_;
         no_dds_stack_ = lane0.no_dds_stack_;
         no_enc_gemm_ = lane0.no_enc_gemm_;
+        no_enc_o_ln_ = lane0.no_enc_o_ln_;
         enc_b3_ = lane0.enc_b3_;
         no_f16x2_convs_ = lane0.no_f16x2_convs_;
     } catch (...) {
@@ -397,6 +398,7 @@ void Engine::open_device(int device) {
     no_fused_dds_ = lab_getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
     no_dds_stack_ = lab_getenv("MI355VITS_NO_DDS_STACK") != nullptr;
     no_enc_gemm_ = lab_getenv("MI355VITS_NO_ENC_GEMM") != nullptr;
+    no_enc_o_ln_ = lab_getenv("MI355VITS_NO_ENC_O_LN") != nullptr;
     enc_b3_ = lab_getenv("MI355VITS_NO_ENC_B3") == nullptr;
     no_f16x2_convs_ = lab_getenv("MI355VITS_F16X2_NO_CONVS") != nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
@@ -728,8 +730,18 @@ void Engine::text_encoder(int B, int Tx) {
         o.y = d_x2_; o.y_bs = xbs; o.y_ld = Tx;
         o.res = d_x_; o.res_bs = xbs; o.res_ld = Tx;
         o.B = B; o.T = Tx;
-        conv("enc.o", cw(S("enc.%d.o", i)), o);
-        {
+        const ConvW& wo = cw(S("enc.%d.o", i));
+        if (enc_gemm(wo, o) && !no_enc_o_ln_ && enc_o_ln_supported(wo.Cin, wo.Cout, wo.K)) {
+            // o-proj + residual + LayerNorm in one launch, in place on x (k_enc_o_ln)
+            o.y = d_x_;
+            o.Cin = wo.Cin; o.Cout = wo.Cout; o.K = wo.K; o.bias = P(wo.bias);
+            o.wb3 = P(wo.packed_b3s);
+            o.math = kmath();
+            ProfScope ps(prof_, "enc.o_ln", 2.0 * B * (double)Tx * H * H, 4.0 * B * 3 * H * Tx);
+            launch_enc_o_ln(o, vec(S("enc_p.encoder.norm_layers_1.%d.gamma", i)), vec(S("enc_p.encoder.norm_layers_1.%d.beta", i)), nullptr,
+                            1e-5f, stream_);
+        } else {
+            conv("enc.o", wo, o);
             LNArgs ln;
             ln.x = d_x2_; ln.y = d_x_; ln.B = B; ln.C = H; ln.T = Tx;
             ln.gamma = vec(S("enc_p.encoder.norm_layers_1.%d.gamma", i));

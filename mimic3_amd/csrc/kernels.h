@@ -55,6 +55,11 @@ struct ConvArgs {
 // K in {1, 3}, dil 1, EPI_STD, wb3 = layout-1 planes.
 bool enc_conv_b3_supported(int Cin, int Cout, int K, int dil);
 void launch_enc_conv_b3(const ConvArgs& a, hipStream_t s);
+// y = LN_c(res + conv1x1(x) + bias) in one launch (the attention block's o-proj + residual + LayerNorm; 192 -> 192 channels):
+// `c` as for launch_enc_conv_b3 (x, wb3, bias, res, y, in_len, math; no output mask on the conv), then the LayerNorm's
+// gamma / beta / eps and its output mask.  y may be the residual buffer.
+bool enc_o_ln_supported(int Cin, int Cout, int K);
+void launch_enc_o_ln(const ConvArgs& c, const float* gamma, const float* beta, const int* ln_out_len, float eps, hipStream_t s);
 // Generic VALU/LDS-tiled Conv1d (any shape; reference implementation + fallback).
 void launch_conv1d_generic(const ConvArgs& a, hipStream_t s);
 // fp32-MFMA implicit-GEMM Conv1d (v_mfma_f32_32x32x2_f32).  Needs Cin even and packed weights.

@@ -1322,6 +1322,110 @@ __global__ __launch_bounds__(256) void k_enc_b3(ConvArgs a) {
     }
 }
 
+// The attention block's tail in one launch:  y = LN_c(res + conv1x1(x) + bias)   (o-proj + residual + LayerNorm; 192 channels).
+// A workgroup owns 32 columns of ALL 192 output rows (six waves = six 32-row tiles over the one 192-channel slice, staged once as
+// planes like k_enc_b3), so the LayerNorm's channel statistics never leave the CU: the conv result (+ bias + residual) goes through
+// LDS into the (column, channel group) layout, 12 groups of 16 channels summed in a fixed order.  In place on the residual allowed
+// (a workgroup reads and writes its own columns only).
+struct EncOLnArgs {
+    const float* x; long x_bs; int x_ld;       // conv input [B, 192, T]
+    const float* wb3;                          // layout-1 bf16 planes of the 1x1 conv [6][1][12][3][64] uint4
+    const float* bias;                         // [192] or null
+    const float* res; long res_bs; int res_ld; // residual [B, 192, T]
+    const float* gamma; const float* beta;
+    float* y; long y_bs; int y_ld;
+    const int* in_len;                         // mask of the conv input or null
+    const int* out_len;                        // y = 0 at t >= out_len[b] (after the LN) or null
+    int B, T;
+    float eps;
+};
+
+template <bool W1>
+__global__ __launch_bounds__(384) void k_enc_o_ln(EncOLnArgs a) {
+    constexpr int C = ENC_CS, NG = ENC_NG, TB = 32, NCG = 12, NPT = 16;
+    DYN_SMEM(float, smem);
+    uint4* planes = reinterpret_cast<uint4*>(smem);  // 3 planes x [12 groups][2 halves][32 columns] x 16 B = 36 KiB
+    float* V = smem;                                 // later: [C][TB] conv result + bias + residual (24 KiB)
+    float* red = smem + 3 * NG * 2 * TB * 4;         // [NCG][TB]
+    const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int col = tid & 31, cg = tid >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TB;
+    int tend = a.in_len ? a.in_len[b] : a.T;
+    if (tend > a.T) tend = a.T;
+    constexpr int PS = NG * 2 * TB;
+    stage_planes<NG, 2>(a.x + (long)b * a.x_bs, a.x_ld, TB, t0, tend, 1.0f, planes, PS, tid, 384);  // 12 column sets x 2 rows
+    // the epilogue's operands, loaded while the planes settle: bias and residual of this lane's 16 rows, gamma / beta of this
+    // thread's 16 channels (every load unconditional, clamped column)
+    const int t = t0 + bcol, tc = t < a.T ? t : a.T - 1;
+    float bv[16], rv[16], gm[NPT], bt[NPT];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * w + tile_row(r, brow);
+        bv[r] = a.bias ? a.bias[co] : 0.0f;
+        rv[r] = a.res[(long)b * a.res_bs + (long)co * a.res_ld + tc];
+    }
+    MI355_UNROLL
+    for (int i = 0; i < NPT; ++i) {
+        gm[i] = a.gamma[cg + NCG * i];
+        bt[i] = a.beta[cg + NCG * i];
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+    const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + (long)w * NG * 192 + lane};
+    b3_chunk<1, 1, NG, 1, W1>(acc, wp, planes + brow * TB + bcol, PS, TB, 1, NG, 1);
+    __syncthreads();  // every wave is done with the planes: the f32 tile takes their place
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) V[(32 * w + tile_row(r, brow)) * TB + bcol] = rv[r] + (acc[0][0][r] + bv[r]);
+    __syncthreads();
+    float v[NPT];
+    float sum = 0.0f;
+    MI355_UNROLL
+    for (int i = 0; i < NPT; ++i) {
+        v[i] = V[(cg + NCG * i) * TB + col];
+        sum += v[i];
+    }
+    auto col_sum = [&](float x) {
+        __syncthreads();
+        red[cg * TB + col] = x;
+        __syncthreads();
+        float s = 0.0f;
+        MI355_UNROLL
+        for (int g = 0; g < NCG; ++g) s += red[g * TB + col];
+        return s;
+    };
+    const float mean = col_sum(sum) / (float)C;
+    float sq = 0.0f;
+    MI355_UNROLL
+    for (int i = 0; i < NPT; ++i) { const float d = v[i] - mean; sq += d * d; }
+    const float rstd = 1.0f / sqrtf(col_sum(sq) / (float)C + a.eps);
+    const int to = t0 + col;
+    if (to >= a.T) return;
+    const bool masked = a.out_len && to >= a.out_len[b];
+    float* yo = a.y + (long)b * a.y_bs + to;
+    MI355_UNROLL
+    for (int i = 0; i < NPT; ++i) {
+        const float y = (v[i] - mean) * rstd * gm[i] + bt[i];
+        yo[(long)(cg + NCG * i) * a.y_ld] = masked ? 0.0f : y;
+    }
+}
+
+bool enc_o_ln_supported(int Cin, int Cout, int K) { return Cin == ENC_CS && Cout == ENC_CS && K == 1; }
+
+void launch_enc_o_ln(const ConvArgs& c, const float* gamma, const float* beta, const int* ln_out_len, float eps, hipStream_t s) {
+    if (c.T <= 0 || c.B <= 0) return;
+    if (!enc_o_ln_supported(c.Cin, c.Cout, c.K) || !c.wb3 || !c.res || c.epi != EPI_STD || c.relu || c.cond || c.accumulate || c.res_sub ||
+        c.out_scale != 1.0f || c.in_slope != 1.0f || c.out_len || c.shuf_s)
+        throw std::runtime_error("enc_o_ln: unsupported conv");
+    EncOLnArgs a{c.x, c.x_bs, c.x_ld, c.wb3, c.bias, c.res, c.res_bs, c.res_ld, gamma, beta, c.y, c.y_bs, c.y_ld, c.in_len, ln_out_len, c.B, c.T, eps};
+    dim3 grid((c.T + 31) / 32, c.B);
+    const size_t shmem = (size_t)3 * ENC_NG * 2 * 32 * 16 + (size_t)12 * 32 * sizeof(float);
+    if (c.math == MATH_BF16W) LAUNCH_KERNEL(k_enc_o_ln<true>, grid, dim3(384), shmem, s, a);
+    else LAUNCH_KERNEL(k_enc_o_ln<false>, grid, dim3(384), shmem, s, a);
+}
+
 bool enc_conv_b3_supported(int Cin, int Cout, int K, int dil) {
     return Cin >= ENC_CS && Cin % ENC_CS == 0 && Cout >= 1 && (K == 1 || K == 3) && dil == 1;
 }

@@ -720,3 +720,35 @@ def test_attention_with_all_operands_prefetched_is_bitwise_the_same(emu_lib, mon
             eng.close()
         monkeypatch.delenv("MI355VITS_ATTN_NO_PREFETCH")
         assert np.array_equal(taps["pre"], taps["trips"])
+
+
+def test_o_proj_residual_layernorm_in_one_launch(emu_lib, monkeypatch):
+    """k_enc_o_ln (o-proj + residual + LayerNorm, 192 channels, in place on x) vs the two launches (MI355VITS_NO_ENC_O_LN=1): the
+    encoder output to f32 rounding (the LayerNorm sums 12 groups of 16 channels instead of 16 of 12), batched == unbatched bit for
+    bit, rows ending inside a 32-column tile; labels show which path ran; the oracle agrees (check_parity)."""
+    cfg = VitsConfig.tiny_h192()
+    cfg.n_layers = 2
+    w = W.synthetic_weights(cfg, seed=57, frames_per_id=1.0)
+    blob = W.pack(cfg, w)
+    ids = np.random.default_rng(11).integers(1, cfg.num_symbols, (3, 70))
+    lengths = [70, 33, 1]
+    taps = {}
+    for tag in ("fused", "two"):
+        if tag == "two":
+            monkeypatch.setenv("MI355VITS_NO_ENC_O_LN", "1")
+        eng = Engine(blob, library=emu_lib)
+        eng.profile_enable(True)
+        eng.run(ids, lengths, [0, 1, 0], debug_taps=True)
+        labels = set(eng.profile_report())
+        assert ("enc.o_ln" in labels) == (tag == "fused") and ("enc.o" in labels) == (tag == "two"), labels
+        taps[tag] = eng.tap("x")
+        if tag == "fused":
+            one = eng.run(ids[1:2], lengths[1:2], [0, 1, 0], debug_taps=True, utterance_base=1)
+            x1 = eng.tap("x")
+            assert np.array_equal(x1[0, :, :33], taps["fused"][1, :, :33])
+        eng.close()
+    monkeypatch.delenv("MI355VITS_NO_ENC_O_LN")
+    for bi, L in enumerate(lengths):
+        assert np.abs(taps["fused"][bi, :, :L] - taps["two"][bi, :, :L]).max() < 2e-5
+    check_parity(emu_lib, cfg, ids=ids, lengths=np.array([70, 33, 9]), noise=True, seed=57, weights=w)  # (a one-phoneme row is a
+    # handful of samples: too few for the int16 difference-fraction criterion)

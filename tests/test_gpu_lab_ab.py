@@ -74,3 +74,32 @@ def test_encoder_slice_kernel_equals_general_conv_kernels(lab_lib, monkeypatch):
     for bi in range(len(lengths)):
         n = int(res["slice"][4][bi])
         assert rel_rms(res["slice"][5][bi, :n], res["general"][5][bi, :n]) < REL_RMS_TOL
+
+
+def test_o_proj_layernorm_fused_equals_two_launches(lab_lib, monkeypatch):
+    """k_enc_o_ln (o-proj + residual + LayerNorm in one launch, in place) vs conv + LayerNorm (MI355VITS_NO_ENC_O_LN=1) on the device:
+    encoder output to f32 rounding, durations and lengths equal, audio to the parity tolerance; rows ending inside a tile."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=33, frames_per_id=1.0)
+    blob = W.pack(cfg, w)
+    Tx = 150
+    ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (4, Tx))
+    lengths = [Tx, 65, 1, 129]
+    res = {}
+    for tag in ("fused", "two"):
+        if tag == "two":
+            monkeypatch.setenv("MI355VITS_NO_ENC_O_LN", "1")
+        eng = Engine(blob, library=lab_lib, device=0)
+        eng.profile_enable(True)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], debug_taps=True, seed=13)
+        labels = set(eng.profile_report())
+        assert ("enc.o_ln" in labels) == (tag == "fused"), labels
+        res[tag] = eng.tap("x"), eng.tap("w_ceil"), out["lengths"].copy(), out["audio"].copy()
+        eng.close()
+    for bi, L in enumerate(lengths):
+        a, b = res["fused"][0][bi, :, :L], res["two"][0][bi, :, :L]
+        assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max()), (bi, np.abs(a - b).max())
+    assert np.array_equal(res["fused"][1], res["two"][1]) and np.array_equal(res["fused"][2], res["two"][2])
+    for bi in range(len(lengths)):
+        n = int(res["fused"][2][bi])
+        assert rel_rms(res["fused"][3][bi, :n], res["two"][3][bi, :n]) < REL_RMS_TOL
