@@ -252,7 +252,7 @@ int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t) {
             HIP_CHECK(hipMemcpy(db3.p, b3.data(), b3.size() * 4, hipMemcpyHostToDevice));
             a.wb3 = db3.as<float>();
             a.math = MATH_BF16X3;
-            a.ksplit = t->Cin / 192;
+            a.ksplit = enc_conv_b3_slices(t->Cin);
             DevBuf dpart(ny * 4 * (size_t)a.ksplit);
             if (a.ksplit > 1) {
                 if (t->bias || t->res || t->relu || t->accumulate) throw EngineError(MI355VITS_ERR_INVALID, "split conv: raw sums only");

@@ -367,6 +367,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         no_dds_stack_ = lane0.no_dds_stack_;
         no_enc_gemm_ = lane0.no_enc_gemm_;
         no_enc_o_ln_ = lane0.no_enc_o_ln_;
+        no_flow_gemm_ = lane0.no_flow_gemm_;
         enc_b3_ = lane0.enc_b3_;
         no_f16x2_convs_ = lane0.no_f16x2_convs_;
     } catch (...) {
@@ -399,6 +400,7 @@ void Engine::open_device(int device) {
     no_dds_stack_ = lab_getenv("MI355VITS_NO_DDS_STACK") != nullptr;
     no_enc_gemm_ = lab_getenv("MI355VITS_NO_ENC_GEMM") != nullptr;
     no_enc_o_ln_ = lab_getenv("MI355VITS_NO_ENC_O_LN") != nullptr;
+    no_flow_gemm_ = lab_getenv("MI355VITS_NO_FLOW_GEMM") != nullptr;
     enc_b3_ = lab_getenv("MI355VITS_NO_ENC_B3") == nullptr;
     no_f16x2_convs_ = lab_getenv("MI355VITS_F16X2_NO_CONVS") != nullptr;
     math_ = MATH_BF16X3;  // default (see include/mi355vits.h: f32-grade results; MI355VITS_MATH=f32 for v_mfma_f32_*)
@@ -601,8 +603,10 @@ Engine::~Engine() { release(); }
 // launch helpers
 // =================================================================================================
 bool Engine::enc_gemm(const ConvW& w, const ConvArgs& a) const {
-    return !force_generic_ && !no_enc_gemm_ && !phase_b_ && math_on_bf16(kmath()) && w.packed_b3s != NO_OFF && a.epi == EPI_STD &&
-           w.epi == EPI_STD && !a.shuf_s && a.Tin < 0 && !a.accumulate && enc_conv_b3_supported(w.Cin, w.Cout, w.K, a.dil);
+    // phoneme-sized convs, and the pointwise convs around the coupling layers' WaveNet stacks (frames: K = 1 only)
+    return !force_generic_ && !no_enc_gemm_ && (!phase_b_ || (w.K == 1 && !no_flow_gemm_)) && math_on_bf16(kmath()) && w.packed_b3s != NO_OFF &&
+           a.epi == EPI_STD && w.epi == EPI_STD && !a.shuf_s && a.Tin < 0 && !a.accumulate && enc_conv_b3_supported(w.Cin, w.Cout, w.K, a.dil) &&
+           a.ksplit == enc_conv_b3_slices(w.Cin) && (a.ksplit == 1 || a.part);  // a split conv only where the caller adds up the slices
 }
 
 void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
@@ -627,7 +631,6 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     if (enc_gemm(w, a)) {  // phoneme-sized dense convs: one 192-channel slice per workgroup, staged once (k_enc_b3)
         a.wb3 = P(w.packed_b3s);
         a.math = kmath();
-        if (a.ksplit != w.Cin / 192) throw EngineError(MI355VITS_ERR_INTERNAL, "split encoder conv: the caller owns the partial sums");
         launch_enc_conv_b3(a, stream_);
         return;
     }
@@ -762,12 +765,12 @@ void Engine::text_encoder(int B, int Tx) {
         f2.res = d_x_; f2.res_bs = xbs; f2.res_ld = Tx;
         f2.B = B; f2.T = Tx;
         const ConvW& w2 = cw(S("enc.%d.ffn2", i));
-        const bool split2 = enc_gemm(w2, f2) && w2.Cin / 192 > 1 && d_part_ != nullptr;  // raw slice sums; the LayerNorm adds them up
-        if (split2) {
-            f2.ksplit = w2.Cin / 192;
+        bool split2 = false;  // conv_2 as 192-channel slices: raw sums, added up by the LayerNorm launch below
+        if (d_part_ && w2.Cout == H && enc_conv_b3_slices(w2.Cin) > 1 && enc_conv_b3_slices(w2.Cin) * 192 == F) {
+            f2.ksplit = enc_conv_b3_slices(w2.Cin);
             f2.part = d_part_;
-        } else if (enc_gemm(w2, f2) && w2.Cin / 192 > 1) {
-            throw EngineError(MI355VITS_ERR_INTERNAL, "split encoder conv without its buffer");
+            split2 = enc_gemm(w2, f2);
+            if (!split2) { f2.ksplit = 1; f2.part = nullptr; }
         }
         conv("enc.ffn2", w2, f2);
         {

@@ -170,6 +170,7 @@ class Engine {
     bool phase_b_ = false;       // inside flow_and_decoder (see Engine::conv)
     bool force_generic_ = false;
     int b3_min_work_ = 256;      // MATH_BF16X3: smallest K * Cin routed to the staged split-bf16 conv kernel
+    bool no_flow_gemm_ = false;  // MI355VITS_NO_FLOW_GEMM=1: flow.pre / flow.post on the general conv kernels (A/B + fallback)
     bool no_enc_o_ln_ = false;   // MI355VITS_NO_ENC_O_LN=1: o-proj and its LayerNorm as two launches (A/B + fallback)
     bool no_enc_gemm_ = false;   // MI355VITS_NO_ENC_GEMM=1: phoneme-sized convs on the general conv kernels (A/B + fallback)
     bool no_dds_stack_ = false;  // MI355VITS_NO_DDS_STACK=1: one launch per DDS layer / pre / proj / spline (A/B + fallback)

@@ -51,9 +51,10 @@ struct ConvArgs {
 };
 
 // Short-sequence dense conv of the text encoder (q/k/v, o, FFN: T = phonemes) in MATH_BF16X3 / BF16W: 64 x 64 output tiles, a
-// 192-channel slice of the input staged ONCE per workgroup as three bf16 planes (k_enc_b3, kernels_conv.cpp).  Cin % 192 == 0,
-// K in {1, 3}, dil 1, EPI_STD, wb3 = layout-1 planes.
+// 192-channel slice of the input staged ONCE per workgroup as three bf16 planes (k_enc_b3, kernels_conv.cpp).  Cin % 192 == 0
+// (or Cin = 96: the pointwise conv in front of a coupling layer's WaveNet), K in {1, 3}, dil 1, EPI_STD, wb3 = layout-1 planes.
 bool enc_conv_b3_supported(int Cin, int Cout, int K, int dil);
+int enc_conv_b3_slices(int Cin);  // workgroups along the input channels = ConvArgs.ksplit (Cin / 192; 1 for the 96-channel form)
 void launch_enc_conv_b3(const ConvArgs& a, hipStream_t s);
 // y = LN_c(res + conv1x1(x) + bias) in one launch (the attention block's o-proj + residual + LayerNorm; 192 -> 192 channels):
 // `c` as for launch_enc_conv_b3 (x, wb3, bias, res, y, in_len, math; no output mask on the conv), then the LayerNorm's

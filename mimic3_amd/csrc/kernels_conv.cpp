@@ -1284,7 +1284,9 @@ __global__ __launch_bounds__(256) void k_conv_direct_splitk(ConvArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int ENC_CS = 192, ENC_NG = ENC_CS / 16, ENC_TB = 64;
 
-template <bool W1>
+// NG 16-channel groups per slice: 12 (192 channels, the encoder's width) or 6 (96: the coupling layers' half of the latent,
+// flow.pre — the same kernel serves the two pointwise convs around each WaveNet stack at frame resolution)
+template <bool W1, int NG>
 __global__ __launch_bounds__(256) void k_enc_b3(ConvArgs a) {
     DYN_SMEM(float, smem);
     uint4* planes = reinterpret_cast<uint4*>(smem);
@@ -1293,14 +1295,14 @@ __global__ __launch_bounds__(256) void k_enc_b3(ConvArgs a) {
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.z / a.ksplit, sl = blockIdx.z - b * a.ksplit;
     const int t0 = blockIdx.x * ENC_TB;
-    const int c0 = sl * ENC_CS;
+    const int c0 = sl * 16 * NG;
     int tend = a.in_len ? a.in_len[b] : a.T;
     if (tend > a.T) tend = a.T;
     const int out_len = a.out_len ? a.out_len[b] : a.T;
     const int LD = ENC_TB + (a.K - 1) * a.dil;
-    const int PS = ENC_NG * 2 * LD;
+    const int PS = NG * 2 * LD;
     if (!(LAB_ABLATE(a) & 2))
-        stage_planes<ENC_NG, 8>(a.x + (long)b * a.x_bs + (long)c0 * a.x_ld, a.x_ld, LD, t0 - a.pad, tend, a.in_slope, planes, PS, tid, 256);
+        stage_planes<NG, NG == 12 ? 8 : 4>(a.x + (long)b * a.x_bs + (long)c0 * a.x_ld, a.x_ld, LD, t0 - a.pad, tend, a.in_slope, planes, PS, tid, 256);
     __syncthreads();
     const int rt = blockIdx.y * 2 + wm;  // 32-row tile of the output
     if (32 * rt >= a.Cout) return;
@@ -1309,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_enc_b3(ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
     const int ngt = a.Cin / 16;
     const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
-    if (!(LAB_ABLATE(a) & 1)) b3_chunk<1, 1, ENC_NG, 1, W1>(acc, wp, planes + brow * LD + bcol + wn * 32, PS, LD, a.K, ngt, a.dil);
+    if (!(LAB_ABLATE(a) & 1)) b3_chunk<1, 1, NG, 1, W1>(acc, wp, planes + brow * LD + bcol + wn * 32, PS, LD, a.K, ngt, a.dil);
     const int t = t0 + wn * 32 + bcol;
     if (t >= a.T) return;
     if (a.ksplit == 1) {
@@ -1427,20 +1429,22 @@ void launch_enc_o_ln(const ConvArgs& c, const float* gamma, const float* beta, c
 }
 
 bool enc_conv_b3_supported(int Cin, int Cout, int K, int dil) {
-    return Cin >= ENC_CS && Cin % ENC_CS == 0 && Cout >= 1 && (K == 1 || K == 3) && dil == 1;
+    return ((Cin >= ENC_CS && Cin % ENC_CS == 0) || Cin == ENC_CS / 2) && Cout >= 1 && (K == 1 || K == 3) && dil == 1;
 }
+int enc_conv_b3_slices(int Cin) { return Cin >= ENC_CS ? Cin / ENC_CS : 1; }
 
 void launch_enc_conv_b3(const ConvArgs& a_in, hipStream_t s) {
     if (a_in.T <= 0 || a_in.B <= 0) return;
     ConvArgs a = a_in;
     if (!enc_conv_b3_supported(a.Cin, a.Cout, a.K, a.dil) || a.epi != EPI_STD || !a.wb3 || a.shuf_s || a.Tin >= 0)
         throw std::runtime_error("enc_conv_b3: unsupported conv");
-    if (a.ksplit != a.Cin / ENC_CS) throw std::runtime_error("enc_conv_b3: one workgroup per 192-channel slice");
+    if (a.ksplit != enc_conv_b3_slices(a.Cin)) throw std::runtime_error("enc_conv_b3: one workgroup per 192-channel slice");
+    const int ng = a.Cin >= ENC_CS ? ENC_NG : ENC_NG / 2;
     if (a.ksplit > 1 && !a.part) throw std::runtime_error("enc_conv_b3: split conv without a partial-sum buffer");
     static const int ablate = lab_getenv("MI355VITS_CONV_ABLATE") ? atoi(lab_getenv("MI355VITS_CONV_ABLATE")) : 0;
     a.ablate = ablate;
     const int LD = ENC_TB + (a.K - 1) * a.dil;
-    const size_t shmem = (size_t)3 * ENC_NG * 2 * LD * 16;
+    const size_t shmem = (size_t)3 * ng * 2 * LD * 16;
     dim3 grid((a.T + ENC_TB - 1) / ENC_TB, (a.Cout + 63) / 64, a.B * a.ksplit);
     auto go = [&](auto kfn) {
 #ifndef MI355_EMU
@@ -1448,8 +1452,13 @@ void launch_enc_conv_b3(const ConvArgs& a_in, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
     };
-    if (a.math == MATH_BF16W) go(k_enc_b3<true>);
-    else go(k_enc_b3<false>);
+    if (ng == ENC_NG) {
+        if (a.math == MATH_BF16W) go(k_enc_b3<true, ENC_NG>);
+        else go(k_enc_b3<false, ENC_NG>);
+    } else {
+        if (a.math == MATH_BF16W) go(k_enc_b3<true, ENC_NG / 2>);
+        else go(k_enc_b3<false, ENC_NG / 2>);
+    }
 }
 
 namespace {

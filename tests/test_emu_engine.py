@@ -676,7 +676,7 @@ def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
         assert rel_rms(outs["p"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
 
 
-ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
+ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (2, 96, 192, 130, 1), (1, 96, 40, 65, 3), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
              (1, 384, 100, 33, 3)]
 
 
@@ -689,7 +689,7 @@ def test_encoder_slice_kernel_vs_fp64(emu_lib, case):
     rng = np.random.default_rng(sum(case))
     x = rng.standard_normal((B, Cin, T)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
-    split = Cin > 192
+    split = Cin > 192  # (96 input channels: the half-width slice of the coupling layers' flow.pre)
     bias = None if split else rng.standard_normal(Cout).astype(np.float32)
     res = None if split else rng.standard_normal((B, Cout, T)).astype(np.float32)
     in_len = np.array([T] + [max(1, T - 5)] * (B - 1), np.int32)
@@ -752,3 +752,36 @@ def test_o_proj_residual_layernorm_in_one_launch(emu_lib, monkeypatch):
         assert np.abs(taps["fused"][bi, :, :L] - taps["two"][bi, :, :L]).max() < 2e-5
     check_parity(emu_lib, cfg, ids=ids, lengths=np.array([70, 33, 9]), noise=True, seed=57, weights=w)  # (a one-phoneme row is a
     # handful of samples: too few for the int16 difference-fraction criterion)
+
+
+def test_flow_pointwise_convs_on_the_slice_kernel(emu_lib, monkeypatch):
+    """flow.pre (96 -> 192, the 96-channel slice form) and flow.post (192 -> 96, with the coupling's x1 - m epilogue) at frame
+    resolution on k_enc_b3 vs the general conv kernels (MI355VITS_NO_FLOW_GEMM=1): z to f32 rounding, batched == unbatched bit for bit
+    (frames depend on what a row is batched with; the kernel and its tile are fixed by the layer), oracle parity."""
+    cfg = VitsConfig.tiny_h192()
+    cfg.inter_channels = 192
+    w = W.synthetic_weights(cfg, seed=59, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    ids = np.random.default_rng(12).integers(1, cfg.num_symbols, (3, 40))
+    lengths = [40, 17, 33]
+    forced = np.full((3, 40), 2, np.int32)
+    forced[1, :] = 3
+    zs = {}
+    for tag in ("slice", "general"):
+        if tag == "general":
+            monkeypatch.setenv("MI355VITS_NO_FLOW_GEMM", "1")
+        eng = Engine(blob, library=emu_lib)
+        full = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
+        zs[tag] = eng.tap("z"), full["lengths"].copy()
+        if tag == "slice":
+            one = eng.run(ids[1:2], lengths[1:2], [0.667, 1.0, 0.8], forced_durations=forced[1:2], seed=3, utterance_base=1)
+            L = int(one["lengths"][0])
+            assert np.array_equal(full["audio"][1, :L], one["audio"][0, :L])
+        eng.close()
+    monkeypatch.delenv("MI355VITS_NO_FLOW_GEMM")
+    assert np.array_equal(zs["slice"][1], zs["general"][1])
+    for bi in range(3):
+        n = int(zs["slice"][1][bi]) // cfg.hop_length
+        a, b = zs["slice"][0][bi, :, :n], zs["general"][0][bi, :, :n]
+        assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max())
+    check_parity(emu_lib, cfg, ids=ids, lengths=np.array(lengths), forced=forced, noise=True, seed=59, weights=w)

@@ -103,3 +103,29 @@ def test_o_proj_layernorm_fused_equals_two_launches(lab_lib, monkeypatch):
     for bi in range(len(lengths)):
         n = int(res["fused"][2][bi])
         assert rel_rms(res["fused"][3][bi, :n], res["two"][3][bi, :n]) < REL_RMS_TOL
+
+
+def test_flow_pointwise_convs_slice_kernel_equals_general(lab_lib, monkeypatch):
+    """flow.pre / flow.post at frame resolution on k_enc_b3 (96- and 192-channel slices) vs the general conv kernels
+    (MI355VITS_NO_FLOW_GEMM=1) on the device: z to f32 rounding, lengths equal, audio to the parity tolerance."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=34, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 90
+    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (3, Tx))
+    lengths = [Tx, 41, 77]
+    res = {}
+    for tag in ("slice", "general"):
+        if tag == "general":
+            monkeypatch.setenv("MI355VITS_NO_FLOW_GEMM", "1")
+        eng = Engine(blob, library=lab_lib, device=0)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], debug_taps=True, seed=14)
+        res[tag] = eng.tap("z"), out["lengths"].copy(), out["audio"].copy()
+        eng.close()
+    assert np.array_equal(res["slice"][1], res["general"][1])
+    for bi in range(3):
+        n = int(res["slice"][1][bi])
+        fr = n // cfg.hop_length
+        a, b = res["slice"][0][bi, :, :fr], res["general"][0][bi, :, :fr]
+        assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max()), (bi, np.abs(a - b).max())
+        assert rel_rms(res["slice"][2][bi, :n], res["general"][2][bi, :n]) < REL_RMS_TOL

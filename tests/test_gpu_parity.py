@@ -382,7 +382,7 @@ def test_bf16_weights_mode_at_its_own_tolerance(gpu_lib):
     eng.close()
 
 
-ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
+ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (2, 96, 192, 130, 1), (1, 96, 40, 65, 3), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
              (1, 384, 100, 33, 3)]
 
 
@@ -395,7 +395,7 @@ def test_encoder_slice_kernel_vs_fp64(gpu_lib, case):
     rng = np.random.default_rng(sum(case))
     x = rng.standard_normal((B, Cin, T)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
-    split = Cin > 192
+    split = Cin > 192  # (96 input channels: the half-width slice of the coupling layers' flow.pre)
     bias = None if split else rng.standard_normal(Cout).astype(np.float32)
     res = None if split else rng.standard_normal((B, Cout, T)).astype(np.float32)
     in_len = np.array([T] + [max(1, T - 5)] * (B - 1), np.int32)

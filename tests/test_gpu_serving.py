@@ -194,6 +194,45 @@ def test_staged_conv_kernels_on_wide_dynamic_range(gpu_lib, impl):
         assert np.all(np.isfinite(y[clean])) and np.array_equal(y[clean], y0[clean]), bad
 
 
+def test_encoder_slice_kernel_on_wide_dynamic_range(gpu_lib):
+    """impl 3 (k_enc_b3: the text encoder's convs, one 192-channel slice staged once as three bf16 planes) on the same inputs as the
+    staged kernels above: x 2^+-100, per-channel scales 2^-20 .. 2^+20 inside one reduction, x 2^-120 (second / third split terms
+    subnormal: leading-term accuracy at worst, never garbage), and +inf / NaN staying inside their receptive field."""
+    B, Cin, Cout, T, K = 2, 192, 96, 150, 3
+    rng = np.random.default_rng(12)
+    x0 = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    zero_b = np.zeros(Cout, np.float32)
+
+    def rel_err(x):
+        y = gpu_lib.test_conv1d(x, w, zero_b, None, impl=3).astype(np.float64)
+        ref = _conv_ref(x, w, zero_b, 1)
+        return float(np.sqrt(np.mean((y - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+
+    base = rel_err(x0)
+    assert base < 5e-7, base
+    for e in (100, -100):
+        r = rel_err(np.ldexp(x0, e).astype(np.float32))
+        assert r < 2.0 * base + 1e-7, (e, r, base)
+    ch = np.ldexp(1.0, (np.arange(Cin) % 41) - 20).astype(np.float32)
+    r_mixed = rel_err(x0 * ch[None, :, None])
+    assert r_mixed < 5e-7, r_mixed
+    r_tiny = rel_err(np.ldexp(x0, -120).astype(np.float32))
+    print(f"\nimpl 3: rel rms vs fp64  N(0,1) {base:.2e}  mixed channel scales {r_mixed:.2e}  x 2^-120 {r_tiny:.2e}")
+    assert r_tiny < 2.0 ** -6, r_tiny
+    for bad in (np.inf, np.nan):
+        xb = x0.copy()
+        xb[1, 17, 70] = bad
+        y = gpu_lib.test_conv1d(xb, w, zero_b, None, impl=3)
+        hit = np.zeros(T, bool)
+        hit[69:72] = True
+        assert np.all(~np.isfinite(y[1][:, hit])), bad
+        clean = np.ones((B, Cout, T), bool)
+        clean[1][:, hit] = False
+        y0 = gpu_lib.test_conv1d(x0, w, zero_b, None, impl=3)
+        assert np.all(np.isfinite(y[clean])) and np.array_equal(y[clean], y0[clean]), bad
+
+
 def _scaled_decoder(w, s):
     """The HiFi-GAN decoder is positively homogeneous when its biases scale along: conv_pre's weight and every decoder bias
     x s  ->  every stage's activations x s (leaky-relu and the convs commute with a positive scale)."""
