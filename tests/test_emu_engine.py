@@ -750,8 +750,7 @@ def test_o_proj_residual_layernorm_in_one_launch(emu_lib, monkeypatch):
     monkeypatch.delenv("MI355VITS_NO_ENC_O_LN")
     for bi, L in enumerate(lengths):
         assert np.abs(taps["fused"][bi, :, :L] - taps["two"][bi, :, :L]).max() < 2e-5
-    check_parity(emu_lib, cfg, ids=ids, lengths=np.array([70, 33, 9]), noise=True, seed=57, weights=w)  # (a one-phoneme row is a
-    # handful of samples: too few for the int16 difference-fraction criterion)
+    check_parity(emu_lib, cfg, ids=ids, lengths=np.array(lengths), noise=True, seed=57, weights=w)
 
 
 def test_flow_pointwise_convs_on_the_slice_kernel(emu_lib, monkeypatch):
@@ -785,3 +784,14 @@ def test_flow_pointwise_convs_on_the_slice_kernel(emu_lib, monkeypatch):
         a, b = zs["slice"][0][bi, :, :n], zs["general"][0][bi, :, :n]
         assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max())
     check_parity(emu_lib, cfg, ids=ids, lengths=np.array(lengths), forced=forced, noise=True, seed=59, weights=w)
+
+
+@pytest.mark.parametrize("Tx", [1, 64, 65, 257])
+def test_sequence_length_extremes_at_the_real_hidden_width(emu_lib, Tx):
+    """The 192-channel text-side kernels at one phoneme, exactly / one past a 64-column tile, and past 256 phonemes (the attention
+    kernel without prefetch); ragged second row; noise on."""
+    cfg = VitsConfig.tiny_h192()
+    rng = np.random.default_rng(70 + Tx)
+    ids = rng.integers(1, cfg.num_symbols, (2, Tx))
+    lengths = np.array([Tx, max(1, Tx - 7)])
+    check_parity(emu_lib, cfg, ids=ids, lengths=lengths, noise=True, seed=70 + Tx, frames_per_id=1.1)

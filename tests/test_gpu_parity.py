@@ -224,6 +224,18 @@ def test_sequence_length_extremes(gpu_lib, Tx):
     check_parity(gpu_lib, VitsConfig.tiny(), B=1, Tx=Tx, seed=50 + Tx, frames_per_id=1.1)
 
 
+@pytest.mark.parametrize("Tx", [1, 31, 64, 65, 129, 257, 600])
+def test_sequence_length_extremes_at_the_real_hidden_width(gpu_lib, Tx):
+    """The 192-channel text-side kernels (k_enc_b3 slices, k_enc_o_ln, k_dds_stack windows, attention with prefetched operands up to
+    256 phonemes and the trip-by-trip / VALU forms beyond) at one phoneme, one column short of / exactly / one column past a 64-column
+    tile, across the attention kernel's key-tile variants; ragged second row; noise on (the duration predictor's flows run)."""
+    cfg = VitsConfig.tiny_h192()
+    rng = np.random.default_rng(70 + Tx)
+    ids = rng.integers(1, cfg.num_symbols, (2, Tx))
+    lengths = np.array([Tx, max(1, Tx - 7)])
+    check_parity(gpu_lib, cfg, ids=ids, lengths=lengths, noise=True, seed=70 + Tx, frames_per_id=1.1)
+
+
 def test_length_scale_and_rate(gpu_lib):
     check_parity(gpu_lib, VitsConfig.tiny_wide(), B=2, Tx=12, seed=61, scales=(0.0, 1.37, 0.0))
 
