@@ -1374,16 +1374,21 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     if (gin) need_a += pad((size_t)B * H * 4) + pad((size_t)B * C0 * 4) + (size_t)c.flow_n_flows * pad((size_t)B * 2 * H * c.flow_wn_layers * 4);
     arena_a_.reserve(need_a + 4096, stream_);
     arena_a_.reset();
+    // the call's host inputs sit side by side so that ONE host-to-device copy brings them all (each copy from pageable memory
+    // is a staging pass + a copy kernel: ~35 us apiece in the stream of a single utterance)
+    const size_t in_off = arena_a_.used();
     d_ids_ = arena_a_.alloc<long long>(fBT);
     d_sid_ = arena_a_.alloc<long long>(B);
     d_len_ = arena_a_.alloc<int>(B);
+    d_forced_ = nullptr;
+    if (args.forced_durations) d_forced_ = arena_a_.alloc<int>(fBT);
+    d_noise_w_ = nullptr;
+    if (args.noise_w) d_noise_w_ = arena_a_.alloc<float>(fBT * 2);
+    const size_t in_bytes = arena_a_.used() - in_off;
     d_ylen_ = arena_a_.alloc<int>(B);
-    d_alen_ = arena_a_.alloc<int>(B);
     d_peaks_ = arena_a_.alloc<unsigned>(B);
     d_wceil_ = arena_a_.alloc<int>(fBT);
     d_cum_ = arena_a_.alloc<int>(fBT);
-    d_forced_ = nullptr;
-    if (args.forced_durations) d_forced_ = arena_a_.alloc<int>(fBT);
     d_x_ = arena_a_.alloc<float>(fBT * H);
     d_x2_ = arena_a_.alloc<float>(fBT * H);
     d_att_ = arena_a_.alloc<float>(fBT * H);
@@ -1397,8 +1402,6 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     d_d2_ = arena_a_.alloc<float>(fBT * H);
     d_theta_ = arena_a_.alloc<float>(fBT * nth);
     d_z2_ = arena_a_.alloc<float>(fBT * 2);
-    d_noise_w_ = nullptr;
-    if (args.noise_w) d_noise_w_ = arena_a_.alloc<float>(fBT * 2);
     d_logw_ = arena_a_.alloc<float>(fBT);
     d_cond_dp_ = nullptr;
     d_cond_dec_ = nullptr;
@@ -1411,12 +1414,20 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
 
     HIP_CHECK(hipEventRecord(ev_start_, stream_));
     timed_ = false;
-    HIP_CHECK(hipMemcpyAsync(d_ids_, args.ids, fBT * 8, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_len_, len32.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream_));
-    if (multi) HIP_CHECK(hipMemcpyAsync(d_sid_, args.sid, (size_t)B * 8, hipMemcpyHostToDevice, stream_));
-    if (args.forced_durations) HIP_CHECK(hipMemcpyAsync(d_forced_, args.forced_durations, fBT * 4, hipMemcpyHostToDevice, stream_));
-    if (args.noise_w) HIP_CHECK(hipMemcpyAsync(d_noise_w_, args.noise_w, fBT * 2 * 4, hipMemcpyHostToDevice, stream_));
-    // len32 must stay alive until the copy has been consumed: pageable copies are staged synchronously by HIP.
+    {
+        h_in_.assign(in_bytes, 0);
+        unsigned char* h0 = h_in_.data();
+        auto put = [&](const void* dev, const void* src, size_t bytes) {
+            memcpy(h0 + (reinterpret_cast<const unsigned char*>(dev) - reinterpret_cast<const unsigned char*>(d_ids_)), src, bytes);
+        };
+        put(d_ids_, args.ids, fBT * 8);
+        put(d_len_, len32.data(), (size_t)B * 4);
+        if (multi) put(d_sid_, args.sid, (size_t)B * 8);
+        if (args.forced_durations) put(d_forced_, args.forced_durations, fBT * 4);
+        if (args.noise_w) put(d_noise_w_, args.noise_w, fBT * 2 * 4);
+        // h_in_ is a member: it outlives the copy whatever HIP does with pageable sources
+        HIP_CHECK(hipMemcpyAsync(d_ids_, h0, in_bytes, hipMemcpyHostToDevice, stream_));
+    }
 
     if (gin) {
         ProfScope ps(prof_, "speaker_cond");
@@ -1478,7 +1489,7 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     size_t need_b = pad(fBTy * I * 4) + 4 * pad(fBTy * H * 4);
     if (args.noise_z && args.scales[0] != 0.0f) need_b += pad((size_t)B * I * args.noise_z_frames * 4);
     need_b += 4 * pad((size_t)B * max_stage * 4) + pad((size_t)B * L_ * 4) + pad((size_t)B * L_ * 2);
-    need_b += pad((size_t)(c.n_upsamples + 1) * B * 4);
+    need_b += pad((size_t)(c.n_upsamples + 2) * B * 4);
     arena_b_.reserve(need_b + 4096, stream_);
     arena_b_.reset();
     d_z_ = arena_b_.alloc<float>(fBTy * I);
@@ -1497,19 +1508,19 @@ void Engine::run(const mi355vits_run_args& args, mi355vits_result* out) {
     d_bufC_ = arena_b_.alloc<float>((size_t)B * max_stage);
     d_audio_ = arena_b_.alloc<float>((size_t)B * L_);
     d_pcm_ = arena_b_.alloc<int16_t>((size_t)B * L_);
-    std::vector<int> alen(B);
-    for (int b = 0; b < B; ++b) alen[b] = (int)(h_ylen_[b] * hop);
-    HIP_CHECK(hipMemcpyAsync(d_alen_, alen.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream_));
-    std::vector<int> slen((size_t)(c.n_upsamples + 1) * B);
+    // per-stage valid lengths and (last row) the audio lengths: one copy
+    h_slen_.assign((size_t)(c.n_upsamples + 2) * B, 0);
     {
         long f = 1;
         for (int i = 0; i <= c.n_upsamples; ++i) {
-            for (int b = 0; b < B; ++b) slen[(size_t)i * B + b] = (int)(h_ylen_[b] * f);
+            for (int b = 0; b < B; ++b) h_slen_[(size_t)i * B + b] = (int)(h_ylen_[b] * f);
             if (i < c.n_upsamples) f *= c.upsample_rates[i];
         }
+        for (int b = 0; b < B; ++b) h_slen_[(size_t)(c.n_upsamples + 1) * B + b] = (int)(h_ylen_[b] * hop);
     }
-    d_slen_ = arena_b_.alloc<int>(slen.size());
-    HIP_CHECK(hipMemcpyAsync(d_slen_, slen.data(), slen.size() * 4, hipMemcpyHostToDevice, stream_));
+    d_slen_ = arena_b_.alloc<int>(h_slen_.size());
+    d_alen_ = d_slen_ + (size_t)(c.n_upsamples + 1) * B;
+    HIP_CHECK(hipMemcpyAsync(d_slen_, h_slen_.data(), h_slen_.size() * 4, hipMemcpyHostToDevice, stream_));
 
     flow_and_decoder(B, Ty, args);
 

@@ -41,6 +41,7 @@ class DeviceArena {
     void reset() { off_ = 0; }
     template <typename T> T* alloc(size_t n) { return reinterpret_cast<T*>(alloc_bytes(n * sizeof(T))); }
     size_t capacity() const { return cap_; }
+    size_t used() const { return off_; }
     static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
   private:
@@ -216,6 +217,8 @@ class Engine {
     unsigned* d_peaks_ = nullptr;
     int* d_slen_ = nullptr;  // [n_upsamples + 1][B] valid frames per decoder stage
     std::vector<int> h_ylen_;
+    std::vector<unsigned char> h_in_;  // the call's host inputs, laid out like their device block (one upload)
+    std::vector<int> h_slen_;         // per-stage valid lengths + audio lengths (one upload)
 };
 
 void free_result_impl(mi355vits_result* r);
