@@ -365,6 +365,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         no_mrf_p_ = lane0.no_mrf_p_;
         no_fused_dds_ = lane0.no_fused_dds_;
         no_dds_stack_ = lane0.no_dds_stack_;
+        no_dds_stack_b3_ = lane0.no_dds_stack_b3_;
         no_enc_gemm_ = lane0.no_enc_gemm_;
         no_enc_o_ln_ = lane0.no_enc_o_ln_;
         no_flow_gemm_ = lane0.no_flow_gemm_;
@@ -398,6 +399,7 @@ void Engine::open_device(int device) {
     no_mrf_p_ = lab_getenv("MI355VITS_NO_MRF_P") != nullptr;
     no_fused_dds_ = lab_getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
     no_dds_stack_ = lab_getenv("MI355VITS_NO_DDS_STACK") != nullptr;
+    no_dds_stack_b3_ = lab_getenv("MI355VITS_NO_DDS_STACK_B3") != nullptr;
     no_enc_gemm_ = lab_getenv("MI355VITS_NO_ENC_GEMM") != nullptr;
     no_enc_o_ln_ = lab_getenv("MI355VITS_NO_ENC_O_LN") != nullptr;
     no_flow_gemm_ = lab_getenv("MI355VITS_NO_FLOW_GEMM") != nullptr;
@@ -856,18 +858,26 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
     // the whole stack in one launch each (k_dds_stack): pre + DDS layers + proj, and for a ConvFlow the spline too
     const bool stack = !force_generic_ && !no_fused_dds_ && !no_dds_stack_ &&
                        dds_stack_supported(H, c.dp_kernel_size, c.dp_dds_layers, H) && nth <= H && c.dp_num_bins <= 16 &&
-                       cw("dp.pre").packed != NO_OFF && cw("dp.proj").packed != NO_OFF;
+                       cw("dp.pre").packed != NO_OFF && cw("dp.proj").packed != NO_OFF && cw("dp.pre").packed_b3s != NO_OFF &&
+                       cw("dp.proj").packed_b3s != NO_OFF;
+    // the stack's 1x1 convs: bf16 planes in the split-bf16 math modes (k_dds_stack_b3), f32 A fragments in MATH_F32
+    const bool stack_b3 = math_on_bf16(kmath()) && !no_dds_stack_b3_;
+    auto stack_w = [&](const ConvW& w) -> const float* {
+        const size_t off = stack_b3 ? w.packed_b3s : w.packed;
+        return off == NO_OFF ? nullptr : P(off);
+    };
     auto stack_layers = [&](DdsStackArgs& a, const std::string& key) {
+        a.math = stack_b3 ? kmath() : (int)MATH_F32;
         a.n_layers = c.dp_dds_layers;
         a.K = c.dp_kernel_size;
         for (int i = 0; i < c.dp_dds_layers; ++i) {
             const ConvW& w = cw(key + S(".convs_1x1.%d", i));
-            if (w.packed == NO_OFF) throw EngineError(MI355VITS_ERR_INTERNAL, "dds stack: 1x1 conv without packed weights");
+            if (stack_w(w) == nullptr) throw EngineError(MI355VITS_ERR_INTERNAL, "dds stack: 1x1 conv without packed weights");
             a.dw_w[i] = vec(key + S(".convs_sep.%d.weight", i));
             a.dw_b[i] = vec(key + S(".convs_sep.%d.bias", i));
             a.g1[i] = vec(key + S(".norms_1.%d.gamma", i));
             a.b1[i] = vec(key + S(".norms_1.%d.beta", i));
-            a.w1x1[i] = P(w.packed);
+            a.w1x1[i] = stack_w(w);
             a.bias1x1[i] = P(w.bias);
             a.g2[i] = vec(key + S(".norms_2.%d.gamma", i));
             a.b2[i] = vec(key + S(".norms_2.%d.beta", i));
@@ -881,12 +891,12 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
         DdsStackArgs a;
         a.src = d_x_;
         a.pre_mode = DDS_PRE_CONV;
-        a.pre_w = P(cw("dp.pre").packed);
+        a.pre_w = stack_w(cw("dp.pre"));
         a.pre_b = P(cw("dp.pre").bias);
         a.cond = d_cond_dp_;
         a.cond_bs = H;
         stack_layers(a, "dp.convs");
-        a.proj_w = P(cw("dp.proj").packed);
+        a.proj_w = stack_w(cw("dp.proj"));
         a.proj_b = P(cw("dp.proj").bias);
         a.proj_cout = H;
         a.out = d_h_;
@@ -919,7 +929,7 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
     for (int j = c.dp_n_flows - 1; j >= 1; --j) {
         ch0 ^= 1;  // Flip
         const std::string p = S("dp.flows.%d", 1 + 2 * j);
-        if (stack && cw(p + ".proj").packed != NO_OFF) {
+        if (stack && stack_w(cw(p + ".proj")) != nullptr) {
             DdsStackArgs a;
             a.src = d_h_;
             a.pre_mode = DDS_PRE_AFFINE;
@@ -928,7 +938,7 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
             a.z = d_z2_;
             a.zch = ch0;
             stack_layers(a, p + ".convs");
-            a.proj_w = P(cw(p + ".proj").packed);
+            a.proj_w = stack_w(cw(p + ".proj"));
             a.proj_b = P(cw(p + ".proj").bias);
             a.proj_cout = nth;
             a.spline = 1;

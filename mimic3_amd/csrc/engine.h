@@ -174,6 +174,7 @@ class Engine {
     bool no_flow_gemm_ = false;  // MI355VITS_NO_FLOW_GEMM=1: flow.pre / flow.post on the general conv kernels (A/B + fallback)
     bool no_enc_o_ln_ = false;   // MI355VITS_NO_ENC_O_LN=1: o-proj and its LayerNorm as two launches (A/B + fallback)
     bool no_enc_gemm_ = false;   // MI355VITS_NO_ENC_GEMM=1: phoneme-sized convs on the general conv kernels (A/B + fallback)
+    bool no_dds_stack_b3_ = false;  // MI355VITS_NO_DDS_STACK_B3=1: the f32-MFMA form of the stack in every math mode (A/B)
     bool no_dds_stack_ = false;  // MI355VITS_NO_DDS_STACK=1: one launch per DDS layer / pre / proj / spline (A/B + fallback)
     bool no_fused_dds_ = false;  // MI355VITS_NO_FUSED_DDS=1: DDS layers as three launches (A/B + fallback)
     // the math mode of the kernels that have no fp16 form of their own: in F16X2 they run as BF16X3 (the kernels that do —

@@ -247,6 +247,7 @@ struct DdsStackArgs {
     float tail = 0.0f, inv_sqrt_fc = 0.0f;
     const int* len = nullptr;
     int B = 1, T = 0;
+    int math = MATH_F32;  // MATH_BF16X3 / BF16W: pre_w (conv mode), w1x1[], proj_w are layout-1 bf16 planes (k_dds_stack_b3)
     int ablate = 0;  // lab build only
 };
 bool dds_stack_supported(int C, int K, int n_layers, int proj_cout);

@@ -2,6 +2,7 @@
 // attention, the duration predictor's depthwise/spline pieces, length regulator + prior sampling,
 // speaker conditioning.  All HBM/latency-bound; one pass over their tensors, pointwise work fused.
 #include "kernels.h"
+#include "b3.h"
 
 namespace m355 {
 
@@ -1011,6 +1012,270 @@ __global__ __launch_bounds__(64 * NW) void k_dds_stack(DdsStackArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same stack in MATH_BF16X3 / BF16W (the default math): twelve waves per workgroup and the 1x1 convs on the bf16 matrix
+// cores.  k_dds_stack above spends a layer's 22 us as 6 + 5 us of VALU phases on six waves (two SIMDs carry two of them) and
+// 9 us of f32 MFMA (a sixteenth of the bf16 rate); here
+//   * a thread owns ONE window column and the 16 channels of one 16-channel group (= wave w: channels 16 w ..), i.e. exactly the
+//     two B-operand records (group w, halves 0 / 1) of that column: LayerNorm + GELU results are split into their three bf16
+//     terms in registers and stored as planes [plane][group][half][64 columns] with 16-byte stores, no transpose through LDS;
+//   * the 1x1 conv is b3_chunk (K = 1, twelve groups, six products per step) on 32 x 32 tiles: wave w -> row tile w % 6 of
+//     column tile w / 6 (the last layer and proj have six tiles: waves 0 .. 5); its f32 result overlays the dead planes;
+//   * per-channel parameters are wave-uniform (one channel group per wave).
+// Arithmetic per element does not depend on the tiling (fixed channel order inside a thread, fixed wave order across), so
+// "batched == unbatched" holds as before; results differ from the f32-MFMA stack by f32 rounding only (operands are split
+// exactly, f32 accumulate).
+// ------------------------------------------------------------------------------------------------
+template <bool W1>
+__global__ __launch_bounds__(768) void k_dds_stack_b3(DdsStackArgs a) {
+    constexpr int C = 192, NG = 12, NPT = 16, W = DDS_STACK_W, OFF = DDS_STACK_OFF, K = DDS_STACK_K, PS = NG * 2 * W;
+    DYN_SMEM(float, smem);
+    float* X = smem;                                             // [C][W] the running x of the stack (after proj: theta [nth][32])
+    uint4* planes = reinterpret_cast<uint4*>(smem + C * W);      // 3 x [NG][2][W] records (72 KiB)
+    float* R = smem + C * W;                                     // [C][W] raw 1x1 result, over the dead planes
+    float* red = smem + C * W + 3 * PS * 4;                      // [NG][W]
+    const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
+    const int col = lane;  // window column of this thread in the VALU phases; its channels: 16 w + i
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 32 - OFF;
+    const int L = a.len[b];
+    const int tend = L < a.T ? L : a.T;
+    const int rt = w % 6, ct = w / 6;  // matrix phases: 32-row tile, 32-column tile
+    auto GELU = [&](float x) { return (LAB_ABLATE(a) & 1) ? x : gelu_erf(x); };
+    auto col_sum = [&](float v, bool on) {  // per column: sum over the twelve channel groups (waves), fixed order
+        __syncthreads();
+        if (on) red[w * W + col] = v;
+        __syncthreads();
+        float s = 0.0f;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) s += red[g * W + col];
+        return s;
+    };
+    // a column's 16 values of channel group w -> the two records (halves 0 / 1) of the three planes
+    auto store_planes = [&](const float (&v)[NPT], int j) {
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            // record slot e <-> channel 16 g + 8 (e >> 2) + 4 h + (e & 3)   (layout 1, b3.h / pack_conv_weights_bf16x3_mode)
+            uint4 hi, mi, lo;
+            split3_pk(v[4 * h + 0], v[4 * h + 1], hi.x, mi.x, lo.x);
+            split3_pk(v[4 * h + 2], v[4 * h + 3], hi.y, mi.y, lo.y);
+            split3_pk(v[8 + 4 * h + 0], v[8 + 4 * h + 1], hi.z, mi.z, lo.z);
+            split3_pk(v[8 + 4 * h + 2], v[8 + 4 * h + 3], hi.w, mi.w, lo.w);
+            const int o = (w * 2 + h) * W + j;
+            planes[o] = hi;
+            planes[PS + o] = mi;
+            planes[2 * PS + o] = lo;
+        }
+    };
+    // one 32 x 32 tile of W x planes: rows 32 q .., window columns c0 .. c0 + 31
+    auto mm = [&](const float* wb3, int q, int c0, f32x16& acc) {
+        f32x16 t[1][1];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) t[0][0][r] = 0.0f;
+        if (!(LAB_ABLATE(a) & 2)) {
+            const uint4* wp[1] = {reinterpret_cast<const uint4*>(wb3) + (long)q * NG * 192 + lane};
+            b3_chunk<1, 1, NG, 1, W1>(t, wp, planes + brow * W + bcol + c0, PS, W, 1, NG, 1);
+        }
+        acc = t[0][0];
+    };
+    int rowc[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) rowc[r] = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * brow;
+    // ---- pre
+    {
+        const int t = t0 + col;
+        const bool in = t >= 0 && t < a.T;
+        const int tc = in ? t : 0;
+        float sv[NPT];
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) sv[i] = a.src[((long)b * C + 16 * w + i) * a.T + tc];
+        if (a.pre_mode == DDS_PRE_AFFINE) {
+            const float zv = a.z[((long)b * 2 + a.zch) * a.T + tc];
+            float pw[NPT], pb[NPT];
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) { pw[i] = a.pre_w[16 * w + i]; pb[i] = a.pre_b[16 * w + i]; }
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) X[(16 * w + i) * W + col] = in ? fmaf(pw[i], zv, pb[i]) + sv[i] : 0.0f;
+        } else {
+            float pb[16], cd[16];
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                pb[r] = a.pre_b[rowc[r]];
+                cd[r] = a.cond ? a.cond[(long)b * a.cond_bs + rowc[r]] : 0.0f;
+            }
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) sv[i] = in ? sv[i] : 0.0f;
+            store_planes(sv, col);
+            __syncthreads();
+            f32x16 acc;
+            mm(a.pre_w, rt, 32 * ct, acc);
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[r] + pb[r];
+                if (a.cond) v += cd[r];
+                X[rowc[r] * W + 32 * ct + bcol] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (LAB_ABLATE(a) & 32) return;
+    // ---- DDS layers
+    int dil = 1;
+    for (int li = 0; li < ((LAB_ABLATE(a) & 64) ? 0 : a.n_layers); ++li) {
+        const bool last = li == a.n_layers - 1;
+        // the last layer is computed on the 32 owned columns only: window columns OFF .. OFF + 31
+        const bool on = !last || (col >= OFF && col < OFF + 32);
+        float dwb[NPT], dww[NPT][K], g1[NPT], b1[NPT];
+        {
+            const float* dw_w = a.dw_w[li];
+            const float* dw_b = a.dw_b[li];
+            const float* pg1 = a.g1[li];
+            const float* pb1 = a.b1[li];
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                const int c = 16 * w + i;
+                dwb[i] = dw_b[c];
+                MI355_UNROLL
+                for (int k = 0; k < K; ++k) dww[i][k] = dw_w[c * K + k];
+                g1[i] = pg1[c];
+                b1[i] = pb1[c];
+            }
+        }
+        // depthwise conv of x * mask + LN1 + GELU -> planes
+        {
+            float v[NPT];
+            const int pad = (K * dil - dil) / 2;
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) v[i] = dwb[i];
+            MI355_UNROLL
+            for (int k = 0; k < K; ++k) {
+                const int jj = col - pad + k * dil, tt = t0 + jj;
+                const bool in = tt >= 0 && tt < tend && jj >= 0 && jj < W;
+                const int jc = in ? jj : 0;
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) {
+                    const float xv = X[(16 * w + i) * W + jc];
+                    v[i] = fmaf(dww[i][k], in ? xv : 0.0f, v[i]);
+                }
+            }
+            float sum = 0.0f;
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) sum += v[i];
+            const float mean = col_sum(sum, true) / (float)C;
+            float sq = 0.0f;
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) { const float d = v[i] - mean; sq += d * d; }
+            const float rstd = 1.0f / sqrtf(col_sum(sq, true) / (float)C + 1e-5f);
+            if (!(LAB_ABLATE(a) & 4)) {
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) v[i] = GELU((v[i] - mean) * rstd * g1[i] + b1[i]);
+            }
+            store_planes(v, col);
+        }
+        float bias[16], g2[NPT], b2[NPT];
+        {
+            const float* pbias = a.bias1x1[li];
+            const float* pg2 = a.g2[li];
+            const float* pb2 = a.b2[li];
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) bias[r] = pbias[rowc[r]];
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                g2[i] = pg2[16 * w + i];
+                b2[i] = pb2[16 * w + i];
+            }
+        }
+        __syncthreads();
+        // 1x1 conv: wave -> (row tile, column tile); the last layer's six tiles (columns OFF ..) on waves 0 .. 5
+        {
+            f32x16 acc;
+            const bool mine = !last || ct == 0;
+            const int c0 = last ? OFF : 32 * ct;
+            if (mine) mm(a.w1x1[li], rt, c0, acc);
+            __syncthreads();  // every wave is done reading the planes: the raw result takes their place
+            if (mine) {
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) R[rowc[r] * W + c0 + bcol] = acc[r] + bias[r];
+            }
+        }
+        __syncthreads();
+        // LN2 + GELU + residual -> X
+        {
+            float z[NPT];
+            float sum = 0.0f;
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) {
+                z[i] = R[(16 * w + i) * W + col];
+                sum += z[i];
+            }
+            const float mean = col_sum(sum, true) / (float)C;
+            float sq = 0.0f;
+            MI355_UNROLL
+            for (int i = 0; i < NPT; ++i) { const float d = z[i] - mean; sq += d * d; }
+            const float rstd = 1.0f / sqrtf(col_sum(sq, true) / (float)C + 1e-5f);
+            if (on && !(LAB_ABLATE(a) & 8)) {
+                MI355_UNROLL
+                for (int i = 0; i < NPT; ++i) X[(16 * w + i) * W + col] += GELU((z[i] - mean) * rstd * g2[i] + b2[i]);
+            }
+        }
+        __syncthreads();
+        dil *= K;
+    }
+    const bool own = col >= OFF && col < OFF + 32;
+    const int t_own = t0 + col;
+    if (a.x_out && own && t_own < a.T) {
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) a.x_out[((long)b * C + 16 * w + i) * a.T + t_own] = X[(16 * w + i) * W + col];
+    }
+    if (!a.proj_w) return;
+    // ---- proj: B operand = x * mask (all window columns are written; only the owned ones are used)
+    {
+        float v[NPT];
+        const bool in = t_own >= 0 && t_own < tend;
+        MI355_UNROLL
+        for (int i = 0; i < NPT; ++i) v[i] = in ? X[(16 * w + i) * W + col] : 0.0f;
+        store_planes(v, col);
+    }
+    const int ntp = (a.proj_cout + 31) / 32;
+    float pjb[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) pjb[r] = a.proj_b[rowc[r] < a.proj_cout ? rowc[r] : 0];
+    float x1 = 0.0f;
+    const int t_sp = t0 + OFF + (tid & 31);
+    if (a.spline) x1 = a.z[((long)b * 2 + (1 - a.zch)) * a.T + (t_sp < a.T ? t_sp : 0)];
+    __syncthreads();
+    {
+        const bool mine = ct == 0 && rt < ntp;
+        f32x16 acc;
+        if (mine) mm(a.proj_w, rt, OFF, acc);
+        const int t = t0 + OFF + bcol;
+        if (mine) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int co = rowc[r];
+                if (co < a.proj_cout) {
+                    float v = acc[r] + pjb[r];
+                    if (t >= tend) v = 0.0f;
+                    if (a.out && t < a.T) a.out[((long)b * a.proj_cout + co) * a.T + t] = v;
+                    if (a.spline) X[co * 32 + bcol] = v;
+                }
+            }
+        }
+    }
+    if (!a.spline) return;
+    __syncthreads();
+    if (tid < 32 && t_sp < a.T) {
+        float* z0 = a.z + ((long)b * 2 + a.zch) * a.T + t_sp;
+        float* z1 = a.z + ((long)b * 2 + (1 - a.zch)) * a.T + t_sp;
+        const bool valid = t_sp < L;
+        float outv = x1;
+        if (x1 >= -a.tail && x1 <= a.tail) outv = spline_inverse_at(X + tid, 32, x1, a.nb, a.tail, a.inv_sqrt_fc);
+        *z1 = valid ? outv : 0.0f;
+        if (!valid) *z0 = 0.0f;
+    }
+}
+
 bool dds_stack_supported(int C, int K, int n_layers, int proj_cout) {
     if (C != 192 || K != DDS_STACK_K || n_layers < 1 || n_layers > DDS_STACK_MAX_LAYERS || proj_cout > C) return false;
     int reach = 0, dil = 1;
@@ -1026,6 +1291,18 @@ void launch_dds_stack(const DdsStackArgs& a, int C, hipStream_t s) {
     DdsStackArgs av = a;
     av.ablate = ablate;
     dim3 grid((a.T + 31) / 32, a.B);
+    if (math_on_bf16(a.math)) {  // weights: layout-1 bf16 planes; twelve waves, 1x1 convs on the bf16 matrix cores
+        const size_t shb = ((size_t)C * DDS_STACK_W + (size_t)3 * 12 * 2 * DDS_STACK_W * 4 + (size_t)12 * DDS_STACK_W) * sizeof(float);
+        auto go = [&](auto kfn) {
+#ifndef MI355_EMU
+            set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
+#endif
+            LAUNCH_KERNEL(kfn, grid, dim3(768), shb, s, av);
+        };
+        if (a.math == MATH_BF16W) go(k_dds_stack_b3<true>);
+        else go(k_dds_stack_b3<false>);
+        return;
+    }
     const size_t sh = ((size_t)2 * C * DDS_STACK_W + (size_t)(C / 16) * DDS_STACK_W) * sizeof(float);
     auto kfn = k_dds_stack<6>;
 #ifndef MI355_EMU

@@ -604,10 +604,14 @@ def test_fused_dds_layer_kernel(emu_lib, cfgname, monkeypatch):
 
 @pytest.mark.parametrize("n_speakers", [1, 3])
 def test_dds_stack_kernel(emu_lib, n_speakers, monkeypatch):
-    """k_dds_stack (pre + the DDS layers + proj, and for a ConvFlow the spline, in ONE launch over a 64-column window of x in LDS)
-    against one launch per piece (MI355VITS_NO_DDS_STACK=1): a ragged batch over three workgroups per row (row 1 ends inside the
-    second one, row 2 inside a window's halo) must give the same h, logw and durations bit for bit — the per-element arithmetic
-    is the same whatever the column's place in a window; and the oracle agrees (check_parity)."""
+    """The duration predictor's stacks in ONE launch each (pre + the DDS layers + proj, and for a ConvFlow the spline, over a
+    64-column window of x in LDS) against one launch per piece (MI355VITS_NO_DDS_STACK=1), on a ragged batch over three workgroups per
+    row (row 1 ends inside the second one, row 2 inside a window's halo):
+    * k_dds_stack (f32 matrix cores; MI355VITS_NO_DDS_STACK_B3=1, and the path of MATH_F32) gives the same h, logw and durations BIT
+      FOR BIT — the per-element arithmetic is that of the pieces whatever the column's place in a window;
+    * k_dds_stack_b3 (the default math: twelve waves, the 1x1 convs on the bf16 matrix cores with exactly split operands) agrees to
+      f32 rounding with equal durations;
+    and the oracle agrees with the default (check_parity)."""
     cfg = VitsConfig.tiny_h192(n_speakers=n_speakers)
     w = W.synthetic_weights(cfg, seed=93, frames_per_id=2.5)
     Tx = 75
@@ -615,23 +619,27 @@ def test_dds_stack_kernel(emu_lib, n_speakers, monkeypatch):
     lengths = [Tx, 41, 66]
     sid = np.array([2, 0, 1]) if cfg.is_multispeaker else None
     res = {}
-    monkeypatch.setenv("MI355VITS_NO_ENC_GEMM", "1")  # the pieces' 1x1 convs on the f32 matrix cores, as in the stack
-    for tag in ("stack", "pieces"):
-        if tag == "pieces":
-            monkeypatch.setenv("MI355VITS_NO_DDS_STACK", "1")
+    monkeypatch.setenv("MI355VITS_NO_ENC_GEMM", "1")  # the pieces' 1x1 convs on the f32 matrix cores, as in the f32 stack
+    for tag, env in (("stack_b3", None), ("stack_f32", "MI355VITS_NO_DDS_STACK_B3"), ("pieces", "MI355VITS_NO_DDS_STACK")):
+        if env:
+            monkeypatch.setenv(env, "1")
         eng = Engine(W.pack(cfg, w), library=emu_lib)
         eng.profile_enable(True)
         eng.run(ids, lengths, [0.3, 1, 0.8], sid, debug_taps=True, seed=5)
         labels = set(eng.profile_report())
-        assert ("dp.stack" in labels) == (tag == "stack") and ("convflow.stack" in labels) == (tag == "stack"), labels
+        assert ("dp.stack" in labels) == (tag != "pieces") and ("convflow.stack" in labels) == (tag != "pieces"), labels
         assert ("dds.layer" in labels) == (tag == "pieces") and ("spline" in labels) == (tag == "pieces"), labels
         res[tag] = eng.tap("dp.h"), eng.tap("logw"), eng.tap("w_ceil")
         eng.close()
+        if env:
+            monkeypatch.delenv(env)
     for bi, L in enumerate(lengths):
-        assert np.array_equal(res["stack"][0][bi, :, :L], res["pieces"][0][bi, :, :L])
-        assert np.array_equal(res["stack"][1][bi, :, :L], res["pieces"][1][bi, :, :L])
-    assert np.array_equal(res["stack"][2], res["pieces"][2])
-    monkeypatch.delenv("MI355VITS_NO_DDS_STACK")
+        assert np.array_equal(res["stack_f32"][0][bi, :, :L], res["pieces"][0][bi, :, :L])
+        assert np.array_equal(res["stack_f32"][1][bi, :, :L], res["pieces"][1][bi, :, :L])
+        h_b, h_p = res["stack_b3"][0][bi, :, :L], res["pieces"][0][bi, :, :L]
+        assert np.abs(h_b - h_p).max() <= 2e-5 * max(1.0, np.abs(h_p).max()), (bi, np.abs(h_b - h_p).max())
+        assert np.abs(res["stack_b3"][1][bi, :, :L] - res["pieces"][1][bi, :, :L]).max() < 1e-4
+    assert np.array_equal(res["stack_f32"][2], res["pieces"][2]) and np.array_equal(res["stack_b3"][2], res["pieces"][2])
     monkeypatch.delenv("MI355VITS_NO_ENC_GEMM")
     check_parity(emu_lib, cfg, ids=ids, lengths=np.array(lengths), noise=True, seed=93, weights=w, sid=sid)
 
