@@ -803,3 +803,30 @@ def test_sequence_length_extremes_at_the_real_hidden_width(emu_lib, Tx):
     ids = rng.integers(1, cfg.num_symbols, (2, Tx))
     lengths = np.array([Tx, max(1, Tx - 7)])
     check_parity(emu_lib, cfg, ids=ids, lengths=lengths, noise=True, seed=70 + Tx, frames_per_id=1.1)
+
+
+def test_bf16_weights_mode_on_the_text_side_kernels(emu_lib):
+    """MATH_BF16W through the 192-channel text-side kernels (k_enc_b3<W1>, k_enc_o_ln<W1>, k_dds_stack_b3<W1>: the weights' leading bf16
+    term only): encoder output, h and the waveform at the reduced-precision tolerance against the f32 oracle, clearly worse than
+    MATH_BF16X3 on the same inputs, and the f32-grade mode at its own tolerance; forced durations so that both modes make the same
+    number of frames."""
+    cfg = VitsConfig.tiny_h192()
+    cfg.filter_channels = 768
+    w = W.synthetic_weights(cfg, seed=61, frames_per_id=2.0)
+    ids = np.random.default_rng(13).integers(1, cfg.num_symbols, (2, 70))
+    lengths = np.array([70, 41])
+    forced = np.full((2, 70), 2, np.int32)
+    ora = VitsOracle(cfg, w).infer(ids, lengths, (0.0, 1.0, 0.0), forced_durations=forced)
+    errs = {}
+    for mode in ("bf16x3", "bf16w"):
+        eng = Engine(W.pack(cfg, w), library=emu_lib)
+        eng.set_math(mode)
+        eng.profile_enable(True)
+        out = eng.run(ids, lengths, (0.0, 1.0, 0.0), forced_durations=forced, debug_taps=True)
+        assert {"enc.o_ln", "dp.stack", "enc.ffn2"} <= set(eng.profile_report())
+        assert np.array_equal(out["lengths"], ora["audio_lengths"])
+        L = int(out["lengths"][0])
+        errs[mode] = rel_rms(eng.tap("x"), ora["x"]), rel_rms(out["audio"][0, :L], ora["audio"][0, 0, :L])
+        eng.close()
+    assert errs["bf16x3"][0] < 1e-5 and errs["bf16x3"][1] < 1e-5, errs
+    assert 1e-5 < errs["bf16w"][0] < 2e-2 and 1e-5 < errs["bf16w"][1] < 2e-2, errs
