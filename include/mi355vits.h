@@ -131,7 +131,7 @@ int mi355vits_create_from_buffer(const void* blob, size_t blob_bytes, int device
 int mi355vits_clone(mi355vits_handle src, mi355vits_handle* out);
 void mi355vits_destroy(mi355vits_handle h);
 /* Which matrix-core path the dense Conv1d stacks of the flow and the decoder take on this handle
- * (default: environment MI355VITS_MATH = "f32" | "bf16x3", else BF16X3):
+ * (default: environment MI355VITS_MATH = "f32" | "bf16x3" | "bf16w" | "f16x2", read when the handle is created, else BF16X3):
  *   MI355VITS_MATH_F32     v_mfma_f32_32x32x2_f32 — f32 operands, bit-exact f32 FMA chains;
  *   MI355VITS_MATH_BF16X3  the f32 operands split EXACTLY into three bf16 terms each (x = h + m + l) and the six leading
  *                          partial products on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16 / _16x16x32_bf16) with f32 accumulation: every retained product is
@@ -141,12 +141,17 @@ void mi355vits_destroy(mi355vits_handle h);
  *                          matrix-core time (bf16 MFMA = 16 x the f32 MFMA rate on MI355X).  f32 in, f32 out, f32
  *                          accumulate: nothing is stored or rounded in bf16 except the exact split terms.
  * Results of the two differ at f32 rounding level (like two f32 BLAS builds); each is deterministic, and within a mode a
- * batched call is bitwise equal to separate calls.  The text encoder / duration predictor always run on the f32 MFMA. */
+ * batched call is bitwise equal to separate calls.  The text side (encoder convs, duration-predictor stacks) follows the
+ * mode as well (k_enc_b3 / k_enc_o_ln / k_dds_stack_b3 in the split modes, the f32-MFMA kernels in MATH_F32), with ONE
+ * exception: it never runs with rounded weights — in BF16W it takes the exact BF16X3 path, so the durations
+ * ceil(exp(logw) * length_scale), hence every utterance length, are bitwise those of the default mode (Engine::tmath;
+ * tests/test_gpu_parity.py::test_bf16_weights_mode_natural_durations_200_sentences).  Attention itself is an f32-MFMA chain. */
 #define MI355VITS_MATH_F32 0
 #define MI355VITS_MATH_BF16X3 1
 /* "bf16 weights" (BASELINE.json configs[4]): BF16X3 with the weights' leading bf16 term only — the weights are rounded to
  * bf16, the activations stay exact f32 (three terms), f32 accumulate: three MFMA products per multiply-add.  A REDUCED
- * precision variant: separate tolerance (rel. RMS <= 2e-2 vs the f32 oracle), never the default, reported separately. */
+ * precision variant: separate tolerance (rel. RMS <= 2e-2 vs the f32 oracle), never the default, reported separately.
+ * Applies to the frame-rate convs (flow, decoder) only; the text side stays exact (see above): same lengths as the default. */
 #define MI355VITS_MATH_BF16W 2
 /* experimental, opt-in: every kernel of the three-term bf16 split (fused MRF stages, fused WaveNet layers, staged convs,
  * polyphase upsamplers) with both operands split into TWO fp16 terms (11 + 11 significant bits, three products per multiply-add
@@ -219,8 +224,8 @@ int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t);
 int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Cout, int Tin, int K, int stride,
                                     const float* x, const float* w, const float* bias, float in_slope, float* y);
 /* Kernel micro-benchmark hook (tools/convbench.py): times `reps` launches of one MFMA Conv1d on random device data.
- * epi: 0 = standard epilogue (bias + residual), 1 = WaveNet gate (Cout = 2*H), 2 = res/skip.  Tile shape and C_in
- * chunk can be forced with MI355VITS_CONV_CFG="MT,NT,WM,WN" / MI355VITS_CONV_CHUNK. */
+ * epi: 0 = standard epilogue (bias + residual), 1 = WaveNet gate (Cout = 2*H), 2 = res/skip.  (The tile-shape overrides
+ * MI355VITS_CONV_CFG / MI355VITS_CONV_CHUNK exist in the lab build of the library only, csrc/hipx.h lab_getenv.) */
 int mi355vits_bench_conv1d(int device, int B, int Cin, int Cout, int T, int K, int dilation, int epi, int reps,
                            float* ms_per_launch);
 /* MFMA fragment-layout self test: returns 0 when the 32x32x2 and 16x16x4 f32 MFMA lane maps

@@ -82,16 +82,23 @@ def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = 
 
 
 def build_emu(force: bool = False) -> str:
+    """The CPU model: one object per source (in parallel, rebuilt only when the source or a header changed), then one link."""
     extra = [os.path.join(EMU, "hip_emu.h"), os.path.join(EMU, "hip_emu_impl.cpp")]
-    if not force and not _stale(EMU_LIB, _deps(extra)):
-        return EMU_LIB
+    hdrs = [d for d in _deps(extra) if d.endswith(".h")]
+    objdir = os.path.join(EMU, "build")
+    os.makedirs(objdir, exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DMI355_EMU", "-Wno-psabi", "-Wno-unused-result",
-           "-I", EMU, "-I", os.path.join(ROOT, "include")]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(EMU, "hip_emu_impl.cpp")]
-    cmd += ["-o", EMU_LIB + ".tmp", "-lpthread"]
-    _run(cmd)
-    os.replace(EMU_LIB + ".tmp", EMU_LIB)
+    base = [cxx, "-O2", "-std=c++17", "-fPIC", "-DMI355_EMU", "-Wno-psabi", "-Wno-unused-result", "-I", EMU, "-I", os.path.join(ROOT, "include")]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(EMU, "hip_emu_impl.cpp")]
+    objs = [os.path.join(objdir, os.path.basename(s).replace(".cpp", ".o")) for s in srcs]
+    jobs = [base + ["-c", s, "-o", o] for s, o in zip(srcs, objs) if force or _stale(o, [s] + hdrs)]
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or _stale(EMU_LIB, objs):
+        _run([cxx, "-shared", "-fPIC"] + objs + ["-o", EMU_LIB + ".tmp", "-lpthread"])
+        os.replace(EMU_LIB + ".tmp", EMU_LIB)
     return EMU_LIB
 
 

@@ -606,7 +606,7 @@ Engine::~Engine() { release(); }
 // =================================================================================================
 bool Engine::enc_gemm(const ConvW& w, const ConvArgs& a) const {
     // phoneme-sized convs, and the pointwise convs around the coupling layers' WaveNet stacks (frames: K = 1 only)
-    return !force_generic_ && !no_enc_gemm_ && (!phase_b_ || (w.K == 1 && !no_flow_gemm_)) && math_on_bf16(kmath()) && w.packed_b3s != NO_OFF &&
+    return !force_generic_ && !no_enc_gemm_ && (!phase_b_ || (w.K == 1 && !no_flow_gemm_)) && math_on_bf16(pmath()) && w.packed_b3s != NO_OFF &&
            a.epi == EPI_STD && w.epi == EPI_STD && !a.shuf_s && a.Tin < 0 && !a.accumulate && enc_conv_b3_supported(w.Cin, w.Cout, w.K, a.dil) &&
            a.ksplit == enc_conv_b3_slices(w.Cin) && (a.ksplit == 1 || a.part);  // a split conv only where the caller adds up the slices
 }
@@ -632,7 +632,7 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     ProfScope ps(prof_, label, flops, bytes);
     if (enc_gemm(w, a)) {  // phoneme-sized dense convs: one 192-channel slice per workgroup, staged once (k_enc_b3)
         a.wb3 = P(w.packed_b3s);
-        a.math = kmath();
+        a.math = pmath();
         launch_enc_conv_b3(a, stream_);
         return;
     }
@@ -641,10 +641,10 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
         // split-bf16 staged kernel where it pays: convs with little work per staged chunk (1x1 convs, the last
         // upsampler: K * Cin < 256) spend more on splitting the chunk than the faster matrix-core loop saves
         // (measured: flow.pre / post, res_skip, upsample 64 -> 32); MI355VITS_B3_MIN_WORK overrides the threshold (tests)
-        if (math_on_bf16(kmath()) && w.packed_b3s != NO_OFF &&
+        if (math_on_bf16(pmath()) && w.packed_b3s != NO_OFF &&
             (math_on_bf16(a.math) || ((w.K * w.Cin >= b3_min_work_ || (a.shuf_s && w.Cin % 64 == 0)) && a.epi == EPI_STD))) {
             a.wb3 = P(w.packed_b3s);
-            a.math = kmath();
+            a.math = pmath();
             if (math_ == MATH_F16X2 && w.packed_h2s != NO_OFF && a.epi == EPI_STD && !no_f16x2_convs_) {  // two fp16 terms per operand
                 a.wb3 = P(w.packed_h2s);
                 a.math = MATH_F16X2;
@@ -741,7 +741,7 @@ void Engine::text_encoder(int B, int Tx) {
             o.y = d_x_;
             o.Cin = wo.Cin; o.Cout = wo.Cout; o.K = wo.K; o.bias = P(wo.bias);
             o.wb3 = P(wo.packed_b3s);
-            o.math = kmath();
+            o.math = tmath();
             ProfScope ps(prof_, "enc.o_ln", 2.0 * B * (double)Tx * H * H, 4.0 * B * 3 * H * Tx);
             launch_enc_o_ln(o, vec(S("enc_p.encoder.norm_layers_1.%d.gamma", i)), vec(S("enc_p.encoder.norm_layers_1.%d.beta", i)), nullptr,
                             1e-5f, stream_);
@@ -861,13 +861,13 @@ void Engine::duration_predictor(int B, int Tx, const mi355vits_run_args& args) {
                        cw("dp.pre").packed != NO_OFF && cw("dp.proj").packed != NO_OFF && cw("dp.pre").packed_b3s != NO_OFF &&
                        cw("dp.proj").packed_b3s != NO_OFF;
     // the stack's 1x1 convs: bf16 planes in the split-bf16 math modes (k_dds_stack_b3), f32 A fragments in MATH_F32
-    const bool stack_b3 = math_on_bf16(kmath()) && !no_dds_stack_b3_;
+    const bool stack_b3 = math_on_bf16(tmath()) && !no_dds_stack_b3_;
     auto stack_w = [&](const ConvW& w) -> const float* {
         const size_t off = stack_b3 ? w.packed_b3s : w.packed;
         return off == NO_OFF ? nullptr : P(off);
     };
     auto stack_layers = [&](DdsStackArgs& a, const std::string& key) {
-        a.math = stack_b3 ? kmath() : (int)MATH_F32;
+        a.math = stack_b3 ? tmath() : (int)MATH_F32;  // exact in MATH_BF16W too: durations must not move
         a.n_layers = c.dp_dds_layers;
         a.K = c.dp_kernel_size;
         for (int i = 0; i < c.dp_dds_layers; ++i) {

@@ -180,6 +180,10 @@ class Engine {
     // the math mode of the kernels that have no fp16 form of their own: in F16X2 they run as BF16X3 (the kernels that do —
     // fused MRF stages, fused WaveNet layers, staged convs, upsamplers — are switched where they are launched)
     int kmath() const { return math_ == MATH_F16X2 ? (int)MATH_BF16X3 : math_; }
+    // the text side (phase A: encoder, duration predictor) never rounds its weights: ceil(exp(logw) * length_scale) is
+    // discontinuous, so in MATH_BF16W it runs the exact three-term split and utterance lengths equal the default mode's
+    int tmath() const { return kmath() == MATH_BF16W ? (int)MATH_BF16X3 : kmath(); }
+    int pmath() const { return phase_b_ ? kmath() : tmath(); }  // math of the launch helpers shared by both phases
     bool no_f16x2_convs_ = false;  // MI355VITS_F16X2_NO_CONVS=1: in MATH_F16X2 keep the staged convs / upsamplers on bf16x3
     bool enc_b3_ = true;           // the encoder's wide FFN conv on the split-bf16 staged kernel (MI355VITS_NO_ENC_B3=1: f32 kernel)
     bool no_mrf_p_ = false;      // MI355VITS_NO_MRF_P=1: keep the on-the-fly split MRF kernel (A/B against k_mrf_p)

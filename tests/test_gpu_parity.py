@@ -370,8 +370,9 @@ def test_f16x2_mode_bench_workload_matches_oracle(gpu_lib):
 def test_bf16_weights_mode_at_its_own_tolerance(gpu_lib):
     """BASELINE.json configs[4] first slice: MATH_BF16W — bf16-rounded weights (leading split term), exact f32 activations,
     f32 accumulate on v_mfma_f32_32x32x16_bf16 — on the full-size apope_low graph, bench-shaped rows.  Reduced precision:
-    its OWN tolerance (rel. RMS <= 2e-2 vs the f32 oracle, durations still exactly equal: the duration predictor stays
-    f32), and demonstrably not f32-grade (so it can never be mistaken for the default)."""
+    its OWN tolerance (rel. RMS <= 2e-2 vs the f32 oracle, durations still exactly equal: the text side — encoder, duration
+    predictor — runs the exact three-term split in this mode too, Engine::tmath), and demonstrably not f32-grade (so it can
+    never be mistaken for the default)."""
     cfg = VitsConfig.apope_low()
     B, Tx = 4, 128
     ids, lengths = _bench_batch(B, Tx)
@@ -392,6 +393,43 @@ def test_bf16_weights_mode_at_its_own_tolerance(gpu_lib):
         L = int(out["lengths"][b])
         assert np.array_equal(out["pcm"][b, :L], audio_float_to_int16(out["audio"][b, :L]))
     eng.close()
+
+
+def test_bf16_weights_mode_natural_durations_200_sentences(gpu_lib):
+    """MATH_BF16W at NATURAL durations (BASELINE configs[4] is long-form text: the lengths are what the duration predictor says):
+    208 sentences of 40-160 ids, stochastic duration noise on.  ceil(exp(logw) * length_scale) is discontinuous, so the mode
+    keeps the whole text side on the exact three-term split: durations, lengths, encoder output and prior statistics are BITWISE
+    those of the default mode for every sentence (0 length mismatches), and the first batch's durations equal the f32 oracle's.
+    Reference: mimic3_tts/voice.py:182-189 (scales) -> the frame counts that size every later tensor."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    rng = np.random.default_rng(404)
+    B, NB = 16, 13
+    sc = (0.667, 1.0, 0.8)
+    engs = {m: _engine_in(m, cfg, w) for m in ("bf16x3", "bf16w")}
+    mismatches, total = 0, 0
+    for nb in range(NB):
+        lengths = rng.integers(40, 161, B).astype(np.int64)
+        Tx = int(lengths.max())
+        ids = rng.integers(1, cfg.num_symbols, (B, Tx)).astype(np.int64)
+        for b in range(B):
+            ids[b, lengths[b]:] = 0
+        nw = rng.standard_normal((B, 2, Tx)).astype(np.float32)
+        got = {}
+        for m, eng in engs.items():
+            out = eng.run(ids, lengths, sc, noise_w=nw, seed=5, utterance_base=nb * B, debug_taps=True)
+            got[m] = (out["lengths"].copy(), eng.tap("w_ceil"), eng.tap("x"), eng.tap("stats"))
+        mismatches += int((got["bf16x3"][0] != got["bf16w"][0]).sum())
+        total += B
+        for k in range(1, 4):
+            assert np.array_equal(got["bf16x3"][k], got["bf16w"][k]), (nb, k)
+        if nb == 0:
+            ora = VitsOracle(cfg, w).infer(ids, lengths, (0.0, sc[1], sc[2]), noise_w=nw, stage_rows=())  # durations do not depend on noise_scale
+            assert np.array_equal(got["bf16w"][1], ora["w_ceil"]) and np.array_equal(got["bf16w"][0], ora["audio_lengths"])
+    print(f"\nbf16w natural durations: {mismatches} length mismatches in {total} sentences")
+    assert total >= 200 and mismatches == 0
+    for e in engs.values():
+        e.close()
 
 
 ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (2, 96, 192, 130, 1), (1, 96, 40, 65, 3), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
