@@ -46,11 +46,17 @@ def _install_recorder(tts_cls) -> None:
             plan = getattr(_recording, "plan", None)
             if plan is None:
                 return original(self, sent_phonemes, settings=settings)
-            settings = settings or self.settings
-            plan.append((list(sent_phonemes), deepcopy(settings)))  # the caller clears its list right after the call
+            settings = deepcopy(settings or self.settings)
+            if not settings.voice:
+                settings.voice = self.voice  # resolved NOW: a later request may change tts.voice while this one still streams
+            plan.append((list(sent_phonemes), settings))  # (the caller clears its phoneme list right after the call)
             from opentts_abc import AudioResult
 
-            return AudioResult(sample_rate_hz=self.settings.sample_rate, audio_bytes=b"", sample_width_bytes=2, num_channels=1)
+            # the sample rate is the VOICE's, as in the original (tts.py:545-551); loading is what the original would do next
+            voice = self._get_or_load_voice(settings.voice or self.voice)
+            ph = AudioResult(sample_rate_hz=voice.config.audio.sample_rate, audio_bytes=b"", sample_width_bytes=2, num_channels=1)
+            ph._mi355_placeholder = True  # told apart from a zero-length break by this mark, not by emptiness
+            return ph
 
         tts_cls._speak_sentence_phonemes = _speak_sentence_phonemes
         tts_cls._mi355_speak_sentence_original = original
@@ -58,7 +64,9 @@ def _install_recorder(tts_cls) -> None:
 
 
 def plan_request(tts, text: str, ssml: bool = False, text_language: Optional[str] = None) -> List[Tuple[str, Any]]:
-    """The request as the reference's front end splits it: ``[("speak", (phonemes, settings)) | ("bytes", pcm_bytes), ...]``."""
+    """The request as the reference's front end splits it: ``[("rate", hz), ("speak", (phonemes, settings)) | ("bytes", pcm_bytes),
+    ...]`` — the first entry is the sample rate of the first audio result (what ``do_synthesis`` puts in the WAV header,
+    ``synthesis.py:64-69``), absent when the request produces no audio at all."""
     _install_recorder(type(tts))
     from opentts_abc import AudioResult
 
@@ -79,24 +87,42 @@ def plan_request(tts, text: str, ssml: bool = False, text_language: Optional[str
     it = iter(sentences)
     for r in results:
         if isinstance(r, AudioResult):
-            if r.audio_bytes:
-                plan.append(("bytes", r.audio_bytes))  # a break: zero samples from add_break
-            else:
+            if not plan:
+                plan.append(("rate", int(r.sample_rate_hz)))
+            if getattr(r, "_mi355_placeholder", False):
                 plan.append(("speak", next(it)))
+            elif r.audio_bytes:
+                plan.append(("bytes", r.audio_bytes))  # a break: zero samples from add_break (an empty one adds nothing)
     return plan
 
 
-def stream_request(tts, text: str, ssml: bool = False, text_language: Optional[str] = None, look_ahead: int = 16,
-                   sample_rate: Optional[int] = None) -> Iterator[bytes]:
-    """WAV stream of one request: header, then one chunk per sentence / break, in order, ``look_ahead`` sentences in flight."""
+_POOLS: dict = {}
+_pools_lock = threading.Lock()
+
+
+def _shared_pool(look_ahead: int) -> ThreadPoolExecutor:
+    """One pool per look-ahead width for the whole process (requests share it: a pool per request costs thread start-up on
+    every call and puts no bound on the threads a burst of requests creates)."""
+    with _pools_lock:
+        pool = _POOLS.get(look_ahead)
+        if pool is None:
+            pool = _POOLS[look_ahead] = ThreadPoolExecutor(max_workers=2 * look_ahead,
+                                                           thread_name_prefix="mi355vits-http-stream")
+        return pool
+
+
+def stream_plan(tts, plan: List[Tuple[str, Any]], look_ahead: int = 16, sample_rate: Optional[int] = None) -> Iterator[bytes]:
+    """WAV stream of a planned request: header, then one chunk per sentence / break, in order, ``look_ahead`` sentences in
+    flight.  Touches no per-request state of ``tts`` (every sentence carries its own deep-copied settings), so any number of
+    these generators may run at once on one ``tts`` object."""
     if look_ahead < 1:
         raise ValueError("look_ahead must be >= 1")
-    plan = plan_request(tts, text, ssml=ssml, text_language=text_language)
     original = type(tts)._mi355_speak_sentence_original
-    yield wav_stream_header(sample_rate or tts.settings.sample_rate)
-    pool = ThreadPoolExecutor(max_workers=look_ahead, thread_name_prefix="mi355vits-http-stream")
+    rate = next((v for k, v in plan if k == "rate"), None)
+    yield wav_stream_header(sample_rate or rate or tts.settings.sample_rate)
+    pool = _shared_pool(look_ahead)
     pending: list = []
-    todo = iter(plan)
+    todo = iter([e for e in plan if e[0] != "rate"])
 
     def submit_next() -> bool:
         try:
@@ -123,7 +149,14 @@ def stream_request(tts, text: str, ssml: bool = False, text_language: Optional[s
         for f in pending:
             if not isinstance(f, (bytes, bytearray)):
                 f.cancel()
-        pool.shutdown(wait=True)
+
+
+def stream_request(tts, text: str, ssml: bool = False, text_language: Optional[str] = None, look_ahead: int = 16,
+                   sample_rate: Optional[int] = None) -> Iterator[bytes]:
+    """plan + stream in one call (single caller: the plan step reads ``tts.settings`` / ``tts.voice``)."""
+    if look_ahead < 1:
+        raise ValueError("look_ahead must be >= 1")
+    yield from stream_plan(tts, plan_request(tts, text, ssml=ssml, text_language=text_language), look_ahead, sample_rate)
 
 
 def add_stream_route(app, tts, quart_module, args=None, look_ahead: int = 16, rule: str = "/api/tts/stream"):
@@ -132,7 +165,11 @@ def add_stream_route(app, tts, quart_module, args=None, look_ahead: int = 16, ru
     ``voice.py:277-292``); ``quart_module``: the imported ``quart``.  Query parameters as ``/api/tts`` (``app.py:157-219``):
     ``voice``, ``noiseScale``, ``noiseW``, ``lengthScale``, ``ssml``, ``textLanguage``; text in the POST body or ``?text=``."""
     request, Response = quart_module.request, quart_module.Response
-    lock = threading.Lock()  # one request at a time plans on this tts object (its settings are per-request state)
+    lock = threading.Lock()  # one request at a time PLANS on this tts object (its settings / voice are per-request state)
+    try:
+        from mimic3_tts import DEFAULT_VOICE
+    except ImportError:  # pragma: no cover - the route only exists next to the reference
+        DEFAULT_VOICE = "en_UK/apope_low"
 
     @app.route(rule, methods=["GET", "POST"])
     async def app_tts_stream():
@@ -146,20 +183,19 @@ def add_stream_route(app, tts, quart_module, args=None, look_ahead: int = 16, ru
             text = text[: args.max_text_length]
         ssml_str = a.get("ssml")
         ssml = (ssml_str.strip().lower() in {"true", "1", "yes", "on"}) if ssml_str else request.content_type == "application/ssml+xml"
-        voice = a.get("voice") or (getattr(args, "voice", None) if args is not None else None)
+        voice = a.get("voice") or (getattr(args, "voice", None) if args is not None else None) or DEFAULT_VOICE  # app.py:168
+        # the plan step is the only part that touches tts.settings / tts.voice: done here, under the lock, exactly as
+        # do_synthesis sets them (synthesis.py:41-47: ALL of them on every request, None = the voice's own default), so that
+        # nothing leaks from one request into the next.  The stream itself runs outside the lock: concurrent requests overlap.
+        with lock:
+            tts.speaker = None
+            tts.voice = str(voice)
+            for key, name in (("noiseScale", "noise_scale"), ("noiseW", "noise_w"), ("lengthScale", "length_scale")):
+                v = a.get(key)
+                base = getattr(args, name, None) if args is not None else None
+                setattr(tts.settings, name, float(v) if v else base)
+            plan = plan_request(tts, text, ssml=ssml, text_language=a.get("textLanguage"))
 
-        def chunks():
-            with lock:
-                tts.speaker = None
-                if voice:
-                    tts.voice = str(voice)
-                for key, name in (("noiseScale", "noise_scale"), ("noiseW", "noise_w"), ("lengthScale", "length_scale")):
-                    v = a.get(key)
-                    base = getattr(args, name, None) if args is not None else None
-                    if v or base is not None:
-                        setattr(tts.settings, name, float(v) if v else base)
-                yield from stream_request(tts, text, ssml=ssml, text_language=a.get("textLanguage"), look_ahead=look_ahead)
-
-        return Response(chunks(), mimetype="audio/wav")
+        return Response(stream_plan(tts, plan, look_ahead=look_ahead), mimetype="audio/wav")
 
     return app_tts_stream

@@ -193,6 +193,7 @@ class _LanePool:
         from collections import deque
 
         self._free = list(engines)
+        self._shut = False
         self._waiters = deque()
         self._lock = threading.Lock()
         self.size = len(engines)
@@ -213,6 +214,8 @@ class _LanePool:
 
     def acquire(self):
         with self._lock:
+            if self._shut:
+                raise RuntimeError("session is closed")
             if self._free and not self._waiters:
                 best = min(range(len(self._free)), key=lambda i: (self._busy[self._free[i].device],
                                                                     self._last_use[self._free[i].device], i))
@@ -233,7 +236,18 @@ class _LanePool:
                     raise
             self.release(slot[0])
             raise
+        if slot[0] is None:  # woken by shutdown(): the session was closed while this caller queued
+            raise RuntimeError("session is closed")
         return slot[0]
+
+    def shutdown(self) -> None:
+        """After close() has collected every lane: later callers fail at once, callers still queued are woken with an error
+        (they would wait forever: no lane is ever released again)."""
+        with self._lock:
+            self._shut = True
+            waiters, self._waiters = list(self._waiters), type(self._waiters)()
+        for ev, _slot in waiters:
+            ev.set()
 
     def release(self, eng) -> None:
         with self._lock:
@@ -537,6 +551,7 @@ class InferenceSession:
         # mi355vits_run must not find its engine freed under it)
         for _ in range(self._free_lanes.size):
             self._free_lanes.acquire()
+        self._free_lanes.shutdown()  # a caller that passed the _closed check just before and queued behind us: woken with an error
         for e in reversed(self._engines):  # clones before the handles whose weights they share
             e.close()
 

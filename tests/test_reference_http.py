@@ -131,6 +131,30 @@ def test_unmodified_server_answers_long_form_ssml_through_the_engine_and_streams
     a = _pcm_of(asyncio.run(asyncio.run(app.dispatch("POST", "/api/tts", args={"ssml": "true"}, body=with_break.encode())).get_data()))
     b = b"".join(list(asyncio.run(app.dispatch("POST", "/api/tts/stream", args={"ssml": "true"}, body=with_break.encode())).response)[1:])
     assert np.array_equal(a, np.frombuffer(b, dtype=np.int16)) and int(0.1 * 22050) * 2 <= len(b)
+
+    # per-request settings do not leak into the next request (do_synthesis assigns all of them every time, synthesis.py:41-47):
+    # a request with lengthScale=2 is longer, the next one WITHOUT the parameter is the default again and equals /api/tts
+    two = "<speak><s>said the gull</s><s>a big red hen</s></speak>"
+
+    def stream_pcm(extra=None, body=two):
+        r = asyncio.run(app.dispatch("POST", "/api/tts/stream", args=dict({"ssml": "true"}, **(extra or {})), body=body.encode()))
+        return np.frombuffer(b"".join(list(r.response)[1:]), dtype=np.int16)
+
+    base = _pcm_of(asyncio.run(asyncio.run(app.dispatch("POST", "/api/tts", args={"ssml": "true"}, body=two.encode())).get_data()))
+    slow = stream_pcm({"lengthScale": "2"})
+    assert len(slow) > 1.5 * len(base)
+    assert np.array_equal(stream_pcm(), base)
+    assert tts.settings.length_scale == args.length_scale and tts.voice == (args.voice or mimic3_tts.DEFAULT_VOICE)
+    # a zero-length break is not mistaken for a recorded sentence (it used to consume one and fail the request)
+    zero = "<speak><s>said the gull</s><break time=\"0ms\"/><s>a big red hen</s></speak>"
+    assert np.array_equal(stream_pcm(body=zero), base)
+    # two stream requests at once: the lock covers the plan step only, both streams run and both are right
+    import threading
+    res = {}
+    ths = [threading.Thread(target=lambda k=k: res.__setitem__(k, stream_pcm({"lengthScale": "2"} if k else None))) for k in (0, 1)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert np.array_equal(res[0], base) and np.array_equal(res[1], slow)
     plain.close()
     tts._loaded_voices.clear()
 

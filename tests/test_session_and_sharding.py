@@ -397,6 +397,51 @@ def test_session_close_releases_engines_and_dispatcher(emu_lib):
     assert {t.name for t in threading.enumerate() if t.name.startswith("mi355vits-microbatch")} <= before
 
 
+def test_lane_pool_shutdown_wakes_queued_callers():
+    """a caller that passed the session's _closed check just before close() and queued behind close()'s own lane
+    collection must not wait forever — shutdown() wakes it with "session is closed"; later acquires fail at once."""
+    import threading
+    import time
+
+    from mimic3_amd.session import _LanePool
+
+    class E:
+        device = 0
+
+    e = E()
+    pool = _LanePool([e])
+    assert pool.acquire() is e  # a call in flight
+    order = []
+
+    def closer():  # close(): collects the lane, then shuts the pool down
+        pool.acquire()
+        order.append("closer got the lane")
+        pool.shutdown()
+
+    def late():  # queued behind the closer
+        try:
+            pool.acquire()
+            order.append("late got a lane")
+        except RuntimeError as ex:
+            order.append(str(ex))
+
+    tc = threading.Thread(target=closer)
+    tc.start()
+    while len(pool._waiters) < 1:
+        time.sleep(0.001)
+    tl = threading.Thread(target=late)
+    tl.start()
+    while len(pool._waiters) < 2:
+        time.sleep(0.001)
+    pool.release(e)  # the call in flight ends
+    tc.join(5.0)
+    tl.join(5.0)
+    assert not tc.is_alive() and not tl.is_alive()
+    assert order == ["closer got the lane", "session is closed"]
+    with pytest.raises(RuntimeError, match="closed"):
+        pool.acquire()
+
+
 def test_lane_pool_waiter_interrupted_does_not_swallow_a_lane():
     """a caller interrupted while queued for a lane leaves the queue; a lane handed to it meanwhile goes
     back to the pool."""
