@@ -27,9 +27,13 @@ The JSON line also carries
   "host_ms_per_step" — one handle driven sequentially: call wall time vs device time
   "cpu_baseline" — the PyTorch-CPU oracle (onnxruntime is not installed here) timed on this host's cores on
                    a bounded sample of the same workload (rank 0, N = 1 only), with the engine checked against it
-  "extra"        — vctk_low b32 (configs[2]), the whole batch-256 configuration on ONE GPU, the f32-MFMA / bf16-weights /
-                   f16x2 math modes; they run after the headline's handles are closed (open idle handles alias HIP
-                   streams onto shared hardware queues: tools/floor_diag2.py).
+  "extra"        — vctk_low b32 (configs[2]), the whole batch-256 configuration on ONE GPU, long-form streaming (configs[4]:
+                   120 sentences through mimic3_amd.streaming on one session, default math and bf16 weights), the f32-MFMA /
+                   bf16-weights / f16x2 math modes; they run after the headline's handles are closed (open idle handles alias
+                   HIP streams onto shared hardware queues: tools/floor_diag2.py).
+  "device"       — shader / memory / fabric clocks, socket power and cap, partition modes of the HIP device from sysfs, sampled
+                   every 10 ms over the timed loop and over the per-kernel table; one-line summaries of it, of the batch-1
+                   latency, the batch-256 leg and the streaming leg sit in "config" (the driver's record keeps that object).
 """
 from __future__ import annotations
 
@@ -51,6 +55,131 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); MATH_BF16X3 spen
 PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 SAMPLE_RATE = 22050
+
+
+class DeviceMonitor:
+    """What the box was doing while the numbers were taken: the HIP device's sysfs node (matched by PCI bus id) gives the
+    shader / memory / fabric clock levels, the power cap, the performance level and the compute / memory partition modes;
+    a sampler thread reads the live shader clock and socket power every 10 ms inside a window (the timed loop, the
+    per-kernel table).  A slow box then explains itself in the JSON line (one kernel 40 % slower on the driver's
+    box with nothing in the record to say why).  Everything is best effort: missing files give None, never an error."""
+
+    def __init__(self, torch_index=0):
+        import glob
+
+        self.dir = self.hwmon = None
+        try:
+            import torch
+
+            p = torch.cuda.get_device_properties(torch_index)
+            bus = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if os.path.basename(os.path.realpath(d)) == bus:
+                    self.dir = d
+                    break
+            self.bus = bus
+        except Exception:  # noqa: BLE001 - diagnostics only
+            self.bus = None
+        if self.dir is None:  # a box that shows exactly one GPU node: that one
+            cands = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+            if len(cands) == 1:
+                self.dir = cands[0]
+        if self.dir:
+            hw = sorted(glob.glob(os.path.join(self.dir, "hwmon", "hwmon*")))
+            self.hwmon = hw[0] if hw else None
+        self._stop = None
+        self._samples = []
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    def _level(self, name):
+        """(current MHz, [levels MHz]) of a pp_dpm_* file."""
+        txt = self._read(os.path.join(self.dir, name)) if self.dir else None
+        if not txt:
+            return None, []
+        cur, levels = None, []
+        for line in txt.splitlines():
+            try:
+                mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+            except (IndexError, ValueError):
+                continue
+            levels.append(mhz)
+            if line.rstrip().endswith("*"):
+                cur = mhz
+        return cur, levels
+
+    def _num(self, name, scale):
+        v = self._read(os.path.join(self.hwmon, name)) if self.hwmon else None
+        try:
+            return float(v) * scale
+        except (TypeError, ValueError):
+            return None
+
+    def snapshot(self):
+        if not self.dir:
+            return {"available": False, "pci_bus": self.bus}
+        sclk, sclk_levels = self._level("pp_dpm_sclk")
+        return {
+            "available": True, "pci_bus": self.bus, "sysfs": self.dir,
+            "sclk_mhz": self._num("freq1_input", 1e-6) or sclk, "sclk_levels_mhz": sclk_levels,
+            "mclk_mhz": self._level("pp_dpm_mclk")[0], "fclk_mhz": self._level("pp_dpm_fclk")[0], "socclk_mhz": self._level("pp_dpm_socclk")[0],
+            "power_w": self._num("power1_input", 1e-6), "power_cap_w": self._num("power1_cap", 1e-6),
+            "temp_c": self._num("temp2_input", 1e-3),
+            "perf_level": self._read(os.path.join(self.dir, "power_dpm_force_performance_level")),
+            "compute_partition": self._read(os.path.join(self.dir, "current_compute_partition")),
+            "memory_partition": self._read(os.path.join(self.dir, "current_memory_partition")),
+        }
+
+    def start(self):
+        self._samples = []
+        if not self.hwmon:
+            return
+        self._stop = threading.Event()
+
+        def loop(stop=self._stop, out=self._samples):
+            while not stop.is_set():
+                out.append((self._num("freq1_input", 1e-6), self._num("power1_input", 1e-6)))
+                stop.wait(0.01)
+
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        """-> {"sclk_mhz": {min, median, max}, "power_w": {mean, max}, "samples": n} of the window, or None."""
+        if self._stop is None:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=1.0)
+        self._stop = None
+        f = [a for a, _ in self._samples if a]
+        w = [b for _, b in self._samples if b]
+        if not f:
+            return None
+        return {"sclk_mhz": {"min": min(f), "median": float(np.median(f)), "max": max(f)},
+                "power_w": {"mean": float(np.mean(w)) if w else None, "max": max(w) if w else None}, "samples": len(f)}
+
+    @staticmethod
+    def brief(snap, window):
+        """One line (< 128 characters: the driver's record keeps strings that short) for `config.device`."""
+        if not snap.get("available"):
+            return "device state unavailable (no sysfs node for the HIP device)"
+        w = window or {}
+        sc = w.get("sclk_mhz") or {}
+        pw = w.get("power_w") or {}
+        return ("sclk %s-%s MHz (median %s) mclk %s fclk %s; %s W mean (cap %s); %s/%s perf=%s" % (
+            _i(sc.get("min")), _i(sc.get("max")), _i(sc.get("median")), _i(snap.get("mclk_mhz")), _i(snap.get("fclk_mhz")),
+            _i(pw.get("mean")), _i(snap.get("power_cap_w")), snap.get("compute_partition"), snap.get("memory_partition"),
+            snap.get("perf_level")))[:127]
+
+
+def _i(v):
+    return "?" if v is None else str(int(round(v)))
 
 
 def make_batch(B, Tx, base):
@@ -287,9 +416,13 @@ def main():
         return el, out
 
     wl.size_workspaces()
+    mon = DeviceMonitor(local_rank)
+    dev_before = mon.snapshot()
     # in single-process mode K "steps" = K batches per device = K * n_gpus engine calls
     calls = args.steps * (n_gpus if single else 1)
+    mon.start()  # (sampling starts with the warm-up steps; it reads two sysfs files every 10 ms)
     elapsed, out = timed(wl, calls, args.warmup * (n_gpus if single else 1))
+    dev_window = mon.stop()
     samples_per_call = int(out["lengths"].sum())
     samples_per_step = samples_per_call * n_gpus
     value = samples_per_step * args.steps / elapsed
@@ -315,9 +448,8 @@ def main():
         "math": math,
         "data": f"synthetic (seeded random-init weights of the {args.voice} shapes, seeded phoneme ids)",
         "config": {
-            "workload": f"{'en_UK/apope_low' if args.voice == 'apope_low' else 'en_US/vctk_low'}, {B} utterances/GPU x {Tx} "
-                        f"phoneme ids, forced {fpi} frames/id ({Tx * fpi} frames = {Tx * fpi * cfg.hop_length} samples each); "
-                        "8 GPUs = BASELINE batch 256",
+            "workload": (f"{'en_UK/apope_low' if args.voice == 'apope_low' else 'en_US/vctk_low'}, {B} utt/GPU x {Tx} ids x {fpi} frames/id = "
+                         f"{Tx * fpi * cfg.hop_length} samples each: the per-GPU shard of BASELINE batch {B * 8} on 8 GPUs")[:127],
             "global_batch": B * n_gpus, "phonemes": Tx, "frames": Tx * fpi,
             "parallelism": f"batch-shard x{n_gpus}" + (" (one process, one host thread per engine handle)" if single else ""),
             "streams_per_gpu": max(1, args.streams),
@@ -327,7 +459,9 @@ def main():
         "rtf": elapsed / args.steps / (samples_per_step / SAMPLE_RATE),
         "x_realtime": (samples_per_step / SAMPLE_RATE) / (elapsed / args.steps),
         "timed_region_s": elapsed,
+        "device": {"before": dev_before, "timed_window": dev_window},
     }
+    result["config"]["device"] = DeviceMonitor.brief(dev_before, dev_window)
 
     if rank == 0:
         print(f"headline: {value:.4g} samples/s, {ms_per_step:.3f} ms/step over {elapsed:.2f} s (host-to-host)", file=sys.stderr)
@@ -394,15 +528,33 @@ def main():
             "ms_median": med * 1e3, "ms_min": float(min(lat)) * 1e3, "rtf": med / (n1 / SAMPLE_RATE),
             "x_realtime": (n1 / SAMPLE_RATE) / med, "device_ms": dev_ms,
         }
+        if not args.no_roofline:
+            result["latency_b1"]["launches"] = sum(r["launches_per_step"] for r in rows1)
+            result["latency_b1"]["kernel_ms"] = tot1 / 3
+        # the metric's batch-1 half where the driver's record keeps it (it keeps `config`, strings up to 128 characters)
+        result["config"]["batch1"] = ("%.3f ms host-to-host = %.0f x real time (180 ids -> 991 frames = 11.5 s), %s launches, kernels %s ms" % (
+            med * 1e3, (n1 / SAMPLE_RATE) / med, result["latency_b1"].get("launches", "?"),
+            ("%.3f" % result["latency_b1"]["kernel_ms"]) if "kernel_ms" in result["latency_b1"] else "?"))[:127]
 
     if rank == 0 and not args.no_roofline:
         nsteps = 3
+        for i in range(3):  # the batch-1 leg above leaves the chip mostly idle: back to the loaded clocks before the table
+            wl.step(i, device_only=True)
+        mon.start()
         rep, table, tot_ms = kernel_table(eng, lambda i: wl.step(i, device_only=True), nsteps)
+        table_window = mon.stop()
         traffic = None
         if n_gpus == 1 and not args.no_traffic:
             tail = ["--batch", str(B), "--tx", str(Tx), "--frames-per-id", str(fpi), "--voice", args.voice] + (["--math", math] if args.math else [])
             traffic = measure_traffic_in_run(table[0]["kernel"], tail)
         result["roofline"] = roofline_of(rep, table, tot_ms, nsteps, [B, Tx, fpi], args.voice, math, traffic)
+        # the whole per-kernel table, flat (the driver's record keeps first-level scalars of `roofline`): ms per step by label
+        for row in table[:16]:
+            result["roofline"]["ms:" + row["kernel"]] = round(row["ms_per_step"], 4)
+        if table_window:
+            result["roofline"]["sclk_mhz_during_table"] = table_window["sclk_mhz"]["median"]
+            result["roofline"]["power_w_during_table"] = table_window["power_w"]["mean"]
+        result["device"]["kernel_table_window"] = table_window
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w") as f:
             json.dump(table, f, indent=1)
@@ -453,7 +605,18 @@ def main():
             repg, tableg, totg = kernel_table(bigw.engines[0], lambda i: bigw.step(i, device_only=True), 2)
             big["roofline"] = roofline_of(repg, tableg, totg, 2, [256, Tx, fpi], args.voice, math)
         result["extra"]["apope_low_b256_1gpu"] = big
+        result["config"]["batch256_1gpu"] = ("%.4g samples/s = %.2f ms per 256 utterances on ONE GPU (%.0f x real time), %d steps" % (
+            big["value"], big["ms_per_step"], big["x_realtime"], bsteps))[:127]
         bigw.close()
+        # ---- BASELINE.json configs[4]: long-form text streamed sentence by sentence, default math and bf16 weights
+        lf = {"default": longform_stream(cfg, weights, args.math), "bf16w": longform_stream(cfg, weights, "bf16w")}
+        lf["lengths_equal_across_modes"] = lf["default"].pop("det_lengths") == lf["bf16w"].pop("det_lengths")
+        result["extra"]["longform_stream"] = lf
+        result["config"]["longform_stream"] = (
+            "120 sentences %.0f s audio: first audio %.1f ms, all in %.0f ms = %.0f x RT; bf16w %.1f / %.0f ms; chunks==calls %s, lengths== %s" % (
+                lf["default"]["audio_s"], lf["default"]["first_audio_ms"], lf["default"]["total_ms"], lf["default"]["x_realtime"],
+                lf["bf16w"]["first_audio_ms"], lf["bf16w"]["total_ms"],
+                lf["default"]["chunks_equal_single_calls"] and lf["bf16w"]["chunks_equal_single_calls"], lf["lengths_equal_across_modes"]))[:127]
         if math != "f32":
             # ---- the same headline workload on the pure f32-MFMA path (v_mfma_f32_32x32x2_f32 everywhere), for reference
             fw = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
@@ -569,10 +732,11 @@ def cpu_baseline(cfg, weights, wl, budget_s):
                 "engine_vs_oracle": {"rel_rms_worst_row": rel, "tolerance": 1e-4, "lengths_equal": same_len,
                                      "int16_max_lsb": worst_lsb, "math": wl.math}}
 
-    # more threads than ~32 only slows the small ops down (and all 128 SMT threads oversubscribe badly): the second leg
-    # buys throughput by batching four utterances into one call instead
-    th = min(ncpu, 32)
-    legs = [leg(1, th, budget_s * 0.5), leg(min(4, wl.B), th, budget_s * 0.5)]
+    # thread sweep inside the same wall budget (32 of the box's 256 hardware threads understates "the same box's
+    # host cores"): one utterance per call on 32 threads (the reference's own call shape, B = 1 per sentence), then four
+    # utterances per call on 32 / 64 / 128 threads; the best leg is the reported baseline, with ITS thread count in `cores`
+    sweep = [(1, min(ncpu, 32))] + [(min(4, wl.B), t) for t in (32, 64, 128) if t <= ncpu]
+    legs = [leg(nb, th, budget_s / len(sweep)) for nb, th in sweep]
     best = max(legs, key=lambda l: l["samples_per_s"])
     return {
         "value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
@@ -580,9 +744,60 @@ def cpu_baseline(cfg, weights, wl, budget_s):
                   f"{fpi} frames/id = {best['samples']} samples per call, median of {best['runs']} calls after 1 warm-up, "
                   "run + int16",
         "ms_median": best["ms_median"], "x_realtime": best["samples_per_s"] / SAMPLE_RATE,
+        "thread_sweep": "; ".join(f"{l['utterances_per_call']}x{l['threads']}thr: {l['samples_per_s']:.3g}/s" for l in legs)[:127],
+        "engine_vs_oracle_rel_rms": best["engine_vs_oracle"]["rel_rms_worst_row"],
+        "engine_vs_oracle_lengths_equal": best["engine_vs_oracle"]["lengths_equal"],
+        "engine_vs_oracle_int16_max_lsb": best["engine_vs_oracle"]["int16_max_lsb"],
         "engine_vs_oracle": best["engine_vs_oracle"],
         "legs": legs, "host_cpus": ncpu, "cpu": _cpu_model(), "torch": torch.__version__,
     }
+
+
+def longform_stream(cfg, weights, math, n_sentences=120, look_ahead=32):
+    """BASELINE.json configs[4] (its GPU half): a long-form request — 120 sentences of 40-160 phoneme ids, about 10k characters,
+    NATURAL durations, stochastic scales — delivered as an ordered chunk stream by ``mimic3_amd.streaming.stream_sentences``
+    (what ``/api/tts/stream`` runs per request, mimic3_amd/http_stream.py; the reference joins the sentences of
+    ``end_utterance`` into one WAV, mimic3_http/app.py:157-227, tts.py:470-515) on ONE shared session: 3 lanes per device, 1 ms
+    micro-batch window, every visible device (``devices="all"``).  first_audio_ms = request start -> first chunk in the caller's
+    hands; total_ms = last chunk.  In-leg check at deterministic scales: the streamed chunks are BITWISE the per-sentence calls."""
+    from mimic3_amd import streaming as ST
+    from mimic3_amd import weights as W
+    from mimic3_amd.session import InferenceSession, SessionOptions
+
+    so = SessionOptions()
+    so.lanes = 3
+    so.micro_batch_window_ms = 1.0
+    so.devices = "all"
+    so.math = math
+    so.seed = 4242
+    sess = InferenceSession(W.pack(cfg, weights), sess_options=so)
+    try:
+        rng = np.random.default_rng(0)
+        sentences = [rng.integers(1, 50, int(rng.integers(40, 161))).astype(np.int64).tolist() for _ in range(n_sentences)]
+        list(ST.stream_sentences(sess, sentences[:look_ahead], look_ahead=look_ahead))  # warm-up: workspaces of every lane sized
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            first, n = None, 0
+            for audio in ST.stream_sentences(sess, sentences, look_ahead=look_ahead):
+                if first is None:
+                    first = time.perf_counter() - t0
+                n += audio.shape[0]
+            runs.append((time.perf_counter() - t0, first, n))
+        total, first, n = sorted(runs)[1]  # the median run
+        # the check: deterministic scales (a call's Philox draws are keyed by its utterance number, which concurrent calls take
+        # in arrival order), 16 sentences streamed with 16 in flight == the same sentences one call at a time, bit for bit
+        det = (0.0, 1.0, 0.0)
+        streamed = list(ST.stream_sentences(sess, sentences[:16], scales=det, look_ahead=16))
+        single = [sess.run_pcm16(ST._feed(ids, det, None))[0][0] for ids in sentences[:16]]
+        same = all(np.array_equal(a, b) for a, b in zip(streamed, single))
+        return {"math": sess.engine.math, "sentences": n_sentences, "phoneme_ids": int(sum(len(x) for x in sentences)), "look_ahead": look_ahead,
+                "lanes_per_device": 3, "micro_batch_window_ms": 1.0, "devices": list(sess.devices),
+                "first_audio_ms": first * 1e3, "total_ms": total * 1e3, "audio_s": n / SAMPLE_RATE,
+                "x_realtime": n / SAMPLE_RATE / total, "samples_per_s": n / total, "runs_total_ms": [r[0] * 1e3 for r in runs],
+                "chunks_equal_single_calls": bool(same), "det_lengths": [int(a.shape[0]) for a in streamed]}
+    finally:
+        sess.close()
 
 
 # profiler label -> substring of the kernel name as rocprofv3 prints it (the label's launches are that kernel's)

@@ -67,6 +67,10 @@ class SessionOptions:
         # shared by its lanes, and every call goes to the least-loaded device.  None = one device (device_id /
         # provider options / MI355VITS_DEVICE / LOCAL_RANK).  Also MI355VITS_DEVICES="0,1,2,3" or "all".
         self.devices: Union[None, str, Sequence[int]] = os.environ.get("MI355VITS_DEVICES") or None
+        # matrix-core path of the dense convs on every handle of this session: "bf16x3" (default, f32-grade), "f32",
+        # "bf16w" (BASELINE configs[4]: bf16 weights, reduced precision, same utterance lengths), "f16x2".  None = the
+        # library's own default (environment MI355VITS_MATH, read when a handle is created).  include/mi355vits.h.
+        self.math: Optional[str] = None
 
 
 class NodeArg:
@@ -428,6 +432,9 @@ class InferenceSession:
             for _ in range(lanes - 1):
                 for f in firsts:
                     self._engines.append(f.clone())
+            if getattr(self._sess_options, "math", None):
+                for e in self._engines:
+                    e.set_math(self._sess_options.math)
         except BaseException:
             for e in reversed(self._engines):  # clones before the handles whose weights they share
                 e.close()
