@@ -17,9 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
-SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
+SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
 PER_FILE_FLAGS = {}
-LAB_FILE_FLAGS = {"kernels_mrfp.cpp": ["-fno-slp-vectorize", "-DMRFP_SCALAR"]}  # the lab build's side of the current A/B
+LAB_FILE_FLAGS = {}  # per-file flags of the lab build's side of a running A/B (none at the moment)
 HIP_LIB = os.path.join(CSRC, "libmi355vits.so")
 EMU_LIB = os.path.join(EMU, "libmi355vits_emu.so")
 

@@ -1162,8 +1162,18 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
                     m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
-                    ProfScope ps(prof_, i == 1 ? "dec.mrf_p.s1" : (i == 2 ? "dec.mrf_p.s2" : "dec.mrf_p"), flops, 8.0 * B * (double)T * ch);
-                    launch_mrf_p(m, stream_);
+                    // large grids: the row sweep (k_mrf_s: fragments register-resident per segment, no halo recompute); small ones:
+                    // (row, column block) items (k_mrf_p).  The two agree bit for bit, so the choice may follow the grid.
+                    int seg = mrf_s_supported(ch, nk, m.k, m.d1, m.d2) ? mrf_s_segment(ch, B, (int)T, current_device_cu_count()) : 0;
+                    if (const char* f = lab_getenv("MI355VITS_MRF_SWEEP_SEG")) seg = mrf_s_supported(ch, nk, m.k, m.d1, m.d2) ? atoi(f) : 0;  // lab / tests
+                    if (seg > 0) {
+                        m.seg = seg;
+                        ProfScope ps(prof_, i == 1 ? "dec.mrf_s.s1" : (i == 2 ? "dec.mrf_s.s2" : "dec.mrf_s"), flops, 8.0 * B * (double)T * ch);
+                        launch_mrf_s(m, stream_);
+                    } else {
+                        ProfScope ps(prof_, i == 1 ? "dec.mrf_p.s1" : (i == 2 ? "dec.mrf_p.s2" : "dec.mrf_p"), flops, 8.0 * B * (double)T * ch);
+                        launch_mrf_p(m, stream_);
+                    }
                     n_fused = nk;
                 }
                 // the longest prefix of resblocks whose tiles fit LDS together (128 channels: only the narrow ones)

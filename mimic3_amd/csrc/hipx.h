@@ -20,6 +20,7 @@ typedef hipemu_f32x4 f32x4;
     hipemu::launch((kernel), (grid), (block), (size_t)(shmem), __VA_ARGS__)
 #define DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu::tl_worker->dyn_smem)
 #define MI355_UNROLL
+#define MI355_NOUNROLL
 #define WAVE_UNIFORM(x) (x)
 #define FAST_EXPF(x) expf(x)
 #define FAST_RCPF(x) (1.0f / (x))
@@ -28,6 +29,11 @@ typedef hipemu_f32x4 f32x4;
 #define SCHED_GROUP(mask, n) ((void)0)
 #define OPAQUE_V(x) ((void)0)
 #define OPAQUE_S(x) ((void)0)
+// buffer addressing (see the product side below): base pointer + per-lane byte offset + wave-uniform byte offset
+struct BufRsrc { char* p; };
+static inline BufRsrc buf_rsrc(const void* base) { return BufRsrc{const_cast<char*>(static_cast<const char*>(base))}; }
+static inline float buf_load_f32(const BufRsrc& r, unsigned voff, unsigned soff) { return *reinterpret_cast<const float*>(r.p + voff + soff); }
+static inline void buf_store_f32(const BufRsrc& r, unsigned voff, unsigned soff, float v) { *reinterpret_cast<float*>(r.p + voff + soff) = v; }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -60,6 +66,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char _dyn_smem_raw[]; \
     type* name = reinterpret_cast<type*>(_dyn_smem_raw)
 #define MI355_UNROLL _Pragma("unroll")
+#define MI355_NOUNROLL _Pragma("unroll 1")
 // value known to be identical in all lanes of a wave: move it to an SGPR so branches on it are scalar
 #define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // hardware transcendental paths (v_exp_f32 / v_rcp_f32, ~1 ulp): used where the result feeds a bounded
@@ -76,6 +83,19 @@ __device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
 // loop-invariant address arithmetic from being hoisted out — and held in registers across the whole body
 #define OPAQUE_V(x) asm volatile("" : "+v"(x))
 #define OPAQUE_S(x) asm volatile("" : "+s"(x))
+// buffer_load / buffer_store_dword: a wave-uniform base (four SGPRs), a per-lane 32-bit byte offset and a wave-uniform byte
+// offset in an SGPR — "row pointer + lane offset" costs no vector ALU at all (a global_load needs a 64-bit address per lane).
+// Raw buffer, no stride, 2 GiB range, DATA_FORMAT_32 (gfx9 descriptor word 3 = 0x00020000).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc buf_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f32(BufRsrc r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
 // register budget: ask the compiler to keep the kernel within 512 / n registers per lane
 #define MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif

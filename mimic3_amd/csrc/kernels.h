@@ -130,6 +130,7 @@ struct MrfArgs {
     float out_scale = 0.0f;  // 0: y = mean of the nrb resblocks; > 0: y = out_scale * sum (a stage fused only in part:
                              // the remaining resblocks are accumulated onto y by the conv-by-conv path)
     int ablate = 0;  // profiling only (MI355VITS_MRF_ABLATE): 1 = skip MFMA loops, 2 = skip staging, 4 = skip output
+    int seg = 0;     // launch_mrf_s: columns per work item (a multiple of the kernel's step), from mrf_s_segment
 };
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);
@@ -139,6 +140,12 @@ size_t p16_packed_words(int Cout, int Cin, int K);
 void pack_conv_weights_p16(const float* w, int Cout, int Cin, int K, uint32_t* out);
 bool mrf_p_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_p(MrfArgs a, hipStream_t s);
+// The same stage, same bits, as a row sweep (kernels_mrfs.cpp): work item = (row, segment), one pass per resblock with the
+// waves specialised by conv, every conv's fragments in registers for the whole segment, no halo recompute; y accumulates the
+// resblocks in place.  mrf_s_segment: the segment length for a grid, 0 = the stage is too small for the sweep to pay.
+bool mrf_s_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
+int mrf_s_segment(int C, int B, int T, int cus);
+void launch_mrf_s(MrfArgs a, hipStream_t s);
 int current_device_cu_count();  // compute units of the current device (persistent grids), looked up once per device
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, current device)
 void set_max_dynamic_lds(const void* fn, int bytes);

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         }
     };
     auto no_fill = [&](int) MI355_INLINE_LAMBDA {};
-    const float n_rb = (float)a.nrb;
+    const float inv_rb = 1.0f / (float)a.nrb;  // the mean as one multiply per element (k_mrf_s does the same: the two agree bit for bit)
 
     for (; item < item_end; item += nslot) {
         // lane / wave coordinates, re-derived per item from values the optimiser cannot see through: everything computed
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                 if (t < a.T && !(LAB_ABLATE(a) & 4)) {
                     float* yp = a.y + (long)b * a.y_bs + (long)co0 * a.y_ld + t;
                     MI355_UNROLL
-                    for (int r = 0; r < 4; ++r) yp[(long)r * a.y_ld] = decltype(MEAN)::value ? out[i][r] / n_rb : out[i][r] * a.out_scale;
+                    for (int r = 0; r < 4; ++r) yp[(long)r * a.y_ld] = decltype(MEAN)::value ? out[i][r] * inv_rb : out[i][r] * a.out_scale;
                 }
             }
         };

@@ -684,6 +684,42 @@ def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
         assert rel_rms(outs["p"]["audio"][bi, :L], outs["fused"]["audio"][bi, :L]) < 2e-5
 
 
+@pytest.mark.parametrize("dils,seg", [(((1, 2), (2, 6), (3, 12)), 96), (((1, 2), (2, 6), (3, 12)), 288), (((1, 3), (1, 3), (1, 3)), 192), (((3, 1), (2, 1), (1, 2)), 96)])
+def test_mrf_row_sweep_is_bitwise_the_block_kernel(emu_lib, dils, seg, monkeypatch):
+    """k_mrf_s (kernels_mrfs.cpp): the 64- and 32-channel MRF stages as a row sweep — work item = (row, segment), one pass per
+    resblock, conv1 / conv2 on specialised waves with their fragments in registers for the whole segment, x / x1 planes in LDS
+    rings addressed modulo their length, y accumulating the resblocks in place — against k_mrf_p on the same inputs: every decoder
+    stage tap and the waveform BIT FOR BIT (same MFMA sequences, same order of additions), for the "_low" dilations, a narrow
+    set, one with r1 > r2; segments of one, two and three steps' multiples; ragged batch (row 1 ends inside a segment, row 2 one
+    frame short); more work items than the CPU model's 8 "CUs" (the persistent loop runs more than once)."""
+    cfg = VitsConfig.tiny_wide()
+    cfg.resblock_dilation_sizes = dils
+    w = W.synthetic_weights(cfg, seed=78, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 24
+    forced = np.full((3, Tx), 4, np.int32)
+    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (3, Tx))
+    lengths = np.array([Tx, Tx - 9, Tx - 1])
+    outs, taps = {}, {}
+    for tag in ("p", "s"):
+        if tag == "s":
+            monkeypatch.setenv("MI355VITS_MRF_SWEEP_SEG", str(seg))
+        else:
+            monkeypatch.setenv("MI355VITS_MRF_SWEEP_SEG", "0")
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math("bf16x3")
+        eng.profile_enable(True)
+        outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=78, weights=w, engine=eng)
+        labels = set(eng.profile_report())
+        assert ("dec.mrf_s.s1" in labels) == (tag == "s") and ("dec.mrf_p.s1" in labels) == (tag == "p"), labels
+        assert ("dec.mrf_s" in labels) == (tag == "s"), labels  # the 64-channel stage
+        taps[tag] = {k: eng.tap(k) for k in ("dec.mrf.0", "dec.mrf.1")}
+        eng.close()
+    for k in taps["p"]:
+        assert np.array_equal(taps["p"][k], taps["s"][k]), k
+    assert np.array_equal(outs["p"]["audio"], outs["s"]["audio"])
+
+
 ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (2, 96, 192, 130, 1), (1, 96, 40, 65, 3), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
              (1, 384, 100, 33, 3)]
 

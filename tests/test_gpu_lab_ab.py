@@ -129,3 +129,33 @@ def test_flow_pointwise_convs_slice_kernel_equals_general(lab_lib, monkeypatch):
         a, b = res["slice"][0][bi, :, :fr], res["general"][0][bi, :, :fr]
         assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max()), (bi, np.abs(a - b).max())
         assert rel_rms(res["slice"][2][bi, :n], res["general"][2][bi, :n]) < REL_RMS_TOL
+
+
+def test_mrf_row_sweep_equals_block_kernel_bitwise_on_the_device(lab_lib, monkeypatch):
+    """k_mrf_s (row sweep: segments, one pass per resblock, conv-specialised waves, fragments in registers, LDS rings; the default
+    of the 64-channel stage on large grids) vs k_mrf_p (MI355VITS_MRF_SWEEP_SEG=0) on the MI355X at full-size shapes: both MRF
+    stage taps and the waveform BIT FOR BIT — the launcher may pick either by grid size.  Also with the sweep forced onto the
+    32-channel stage (segments of 1,632 columns: a multiple of both stages' steps), ragged rows ending inside a segment."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    blob = W.pack(cfg, w)
+    B, Tx = 8, 128
+    ids = np.random.default_rng(8).integers(1, 50, (B, Tx))
+    lengths = np.array([Tx, Tx, 97, Tx, 64, Tx, 1, 127])
+    forced = np.full((B, Tx), 6, np.int32)
+    res = {}
+    for tag, env in (("default", None), ("block", "0"), ("sweep_both", "1632")):
+        if env is None:
+            monkeypatch.delenv("MI355VITS_MRF_SWEEP_SEG", raising=False)
+        else:
+            monkeypatch.setenv("MI355VITS_MRF_SWEEP_SEG", env)
+        eng = Engine(blob, library=lab_lib, device=0)
+        eng.profile_enable(True)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
+        labels = set(eng.profile_report())
+        assert ("dec.mrf_s.s1" in labels) == (tag != "block") and ("dec.mrf_s.s2" in labels) == (tag == "sweep_both"), (tag, labels)
+        res[tag] = eng.tap("dec.mrf.1"), eng.tap("dec.mrf.2"), out["audio"].copy()
+        eng.close()
+    for tag in ("default", "sweep_both"):
+        for k in range(3):
+            assert np.array_equal(res[tag][k], res["block"][k]), (tag, k)
