@@ -32,8 +32,13 @@ typedef hipemu_f32x4 f32x4;
 // buffer addressing (see the product side below): base pointer + per-lane byte offset + wave-uniform byte offset
 struct BufRsrc { char* p; };
 static inline BufRsrc buf_rsrc(const void* base) { return BufRsrc{const_cast<char*>(static_cast<const char*>(base))}; }
-static inline float buf_load_f32(const BufRsrc& r, unsigned voff, unsigned soff) { return *reinterpret_cast<const float*>(r.p + voff + soff); }
-static inline void buf_store_f32(const BufRsrc& r, unsigned voff, unsigned soff, float v) { *reinterpret_cast<float*>(r.p + voff + soff) = v; }
+static inline float buf_load_f32(const BufRsrc& r, unsigned voff, unsigned soff) {
+    return voff < 0x80000000u ? *reinterpret_cast<const float*>(r.p + voff + soff) : 0.0f;
+}
+constexpr unsigned BUF_OOB = 0x80000000u;  // a lane offset past the buffer's range: loads return 0, stores are dropped
+static inline void buf_store_f32(const BufRsrc& r, unsigned voff, unsigned soff, float v) {
+    if (voff < BUF_OOB) *reinterpret_cast<float*>(r.p + voff + soff) = v;
+}
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -93,6 +98,9 @@ __device__ __forceinline__ BufRsrc buf_rsrc(const void* base) {
 __device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// a lane whose offset is >= the range (0x7fffffff bytes) is out of bounds: its load returns 0, its store is dropped — the
+// branch-free way to switch single lanes off (the wave-uniform soffset does not take part in the range check)
+constexpr unsigned BUF_OOB = 0x80000000u;
 __device__ __forceinline__ void buf_store_f32(BufRsrc r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }

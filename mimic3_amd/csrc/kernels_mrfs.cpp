@@ -153,9 +153,8 @@ template <int C, int K0, int K1, int K2, typename SH>
 __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
     static_assert(C == 64 || C == 32, "four or two 16-row tiles");
     constexpr int G = C / 32, NMT = C / 16, NCH = 4 / NMT, NT = MRFS_NT, TS = 16 * NT * NCH, TAP = G * 3 * 64;
-    constexpr int AH = 1;
     constexpr int NREC = TS * (C / 8);         // 8-channel records of one staged block: one per thread, threads 0 .. NREC - 1
-    static_assert(NREC <= 512, "one record per thread");
+    static_assert(NREC <= 512 && 2 * NREC >= 512, "one record per thread; threads past NREC repeat records 0 .. 511 - NREC");
     DYN_SMEM(float, smem);
     const int XR = SH::XR ? SH::XR : a.ldx, X1R = SH::X1R ? SH::X1R : a.ld1, RR = SH::RR ? SH::RR : a.R;
     const unsigned XR16 = 16u * XR, X1R16 = 16u * X1R, RR16 = 16u * RR;
@@ -201,6 +200,12 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
         auto sweep = [&](auto KC, auto JC, auto FIRSTC, auto LASTC) MI355_INLINE_LAMBDA {
             constexpr int K = decltype(KC)::value, j = decltype(JC)::value;
             constexpr bool FIRST = decltype(FIRSTC)::value, LAST = decltype(LASTC)::value;
+            // B fragments ahead of their MFMAs (MRFS_AH overrides for experiments)
+#ifdef MRFS_AH
+            constexpr int AH = MRFS_AH;
+#else
+            constexpr int AH = G == 1 ? 2 : 1;  // measured: 32 channels 2.61 (2) vs 2.75 (1) / 2.76 (3) ms; 64 channels 1.97 (1) vs 2.32 (2: spills at k = 7)
+#endif
             const int d1 = SH::d1(j) ? SH::d1(j) : a.d1[j], d2 = SH::d2(j) ? SH::d2(j) : a.d2[j];
             const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
             const int W1 = (2 * r2 + TS - 1) / TS + 1;  // iterations conv1 runs ahead of conv2
@@ -226,40 +231,45 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
             // ---- staging of x block u = it as planes, by threads 0 .. NREC - 1 (both roles): a thread takes one record = eight
             // channels of one column: eight 4-byte loads issued at the top of the iteration (in flight behind the tiles), then
             // leaky-relu, split and one conflict-free 16-byte store per plane before the iteration's barrier
+            // Branch-free on purpose (as are the tile loops below): a conditional block between a load's issue and its use makes
+            // hipcc's wait-count pass give up on counting and emit s_waitcnt vmcnt(0) — a full drain of every outstanding load
+            // and store, i.e. one exposed memory round trip per tile.  So: every thread stages (threads past NREC repeat the
+            // first records: same bytes to the same slots), in every iteration (blocks past the last needed one land in ring
+            // slots nobody reads any more), loads through clamped indices, stores past the row dropped by the buffer range check.
             auto stage_load = [&](int it, float (&sv)[8]) MI355_INLINE_LAMBDA {
+                if (LAB_ABLATE(a) & 2) return;
                 int t2 = tid;
                 OPAQUE_V(t2);  // everything derived from it is recomputed per iteration (hoisted, the row offsets spill)
-                if (it < NS && t2 < NREC && !(LAB_ABLATE(a) & 2)) {
-                    const int rec = t2 / TS, col = t2 - rec * TS;
-                    const int t = s0 + it * TS + col;
-                    const int tc = t < 0 ? 0 : (t > last ? last : t);  // every load unconditional (clamped), masked afterwards
-                    const unsigned o = 4u * (unsigned)(8 * rec * a.x_ld + tc);  // one lane offset, eight uniform row pointers
-                    MI355_UNROLL
-                    for (int e = 0; e < 8; ++e) sv[e] = buf_load_f32(xbuf, o, (unsigned)e * xrow);
-                }
+                t2 = t2 < NREC ? t2 : t2 - NREC;
+                const int rec = t2 / TS, col = t2 - rec * TS;
+                const int t = s0 + it * TS + col;
+                const int tc = t < 0 ? 0 : (t > last ? last : t);  // every load unconditional (clamped), masked afterwards
+                const unsigned o = 4u * (unsigned)(8 * rec * a.x_ld + tc);  // one lane offset, eight uniform row offsets
+                MI355_UNROLL
+                for (int e = 0; e < 8; ++e) sv[e] = buf_load_f32(xbuf, o, (unsigned)e * xrow);
+                SCHED_FENCE();  // issued HERE, a whole iteration ahead of stage_store (unfenced, hipcc sinks the loads to their use)
             };
             auto stage_store = [&](int it, const float (&sv)[8], unsigned& xsw) MI355_INLINE_LAMBDA {
-                if (!(it < NS) || (LAB_ABLATE(a) & 2)) return;
+                if (LAB_ABLATE(a) & 2) return;
                 int t2 = tid;
                 OPAQUE_V(t2);
-                if (t2 < NREC) {
-                    const int rec = t2 / TS, col = t2 - rec * TS;
-                    const int t = s0 + it * TS + col;
-                    const bool s_in = t >= 0 && t < len;
-                    float v[8];
-                    MI355_UNROLL
-                    for (int e = 0; e < 8; ++e) v[e] = s_in ? lrelu_f(sv[e], 0.1f) : 0.0f;
-                    uint4 h, mm, l;
-                    split3_pk(v[0], v[1], h.x, mm.x, l.x);
-                    split3_pk(v[2], v[3], h.y, mm.y, l.y);
-                    split3_pk(v[4], v[5], h.z, mm.z, l.z);
-                    split3_pk(v[6], v[7], h.w, mm.w, l.w);
-                    const unsigned ws = mrfs_wrap(xsw + (unsigned)col, (unsigned)XR);
-                    char* px = Xp + ((unsigned)rec * XR16 + 16u * ws);
-                    *reinterpret_cast<uint4*>(px) = h;
-                    *reinterpret_cast<uint4*>(px + PSX16) = mm;
-                    *reinterpret_cast<uint4*>(px + 2u * PSX16) = l;
-                }
+                t2 = t2 < NREC ? t2 : t2 - NREC;
+                const int rec = t2 / TS, col = t2 - rec * TS;
+                const int t = s0 + it * TS + col;
+                const bool s_in = t >= 0 && t < len;
+                float v[8];
+                MI355_UNROLL
+                for (int e = 0; e < 8; ++e) v[e] = s_in ? lrelu_f(sv[e], 0.1f) : 0.0f;
+                uint4 h, mm, l;
+                split3_pk(v[0], v[1], h.x, mm.x, l.x);
+                split3_pk(v[2], v[3], h.y, mm.y, l.y);
+                split3_pk(v[4], v[5], h.z, mm.z, l.z);
+                split3_pk(v[6], v[7], h.w, mm.w, l.w);
+                const unsigned ws = mrfs_wrap(xsw + (unsigned)col, (unsigned)XR);
+                char* px = Xp + ((unsigned)rec * XR16 + 16u * ws);
+                *reinterpret_cast<uint4*>(px) = h;
+                *reinterpret_cast<uint4*>(px + PSX16) = mm;
+                *reinterpret_cast<uint4*>(px + 2u * PSX16) = l;
                 xsw = mrfs_wrap(xsw + TS, (unsigned)XR);
             };
 
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                     const unsigned o = 4u * (unsigned)(co0 * a.x_ld + tc);  // one lane offset; the four rows are uniform base pointers
                     MI355_UNROLL
                     for (int r = 0; r < 4; ++r) v[r] = buf_load_f32(xbuf, o, (unsigned)r * xrow);
+                    SCHED_FENCE();
                 };
                 // residuals in flight: this tile's and the next two (a tile is shorter than a global round trip)
                 float rq[NT][4];
@@ -282,12 +293,14 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                 unsigned x1w = 0, rww = 0;                       // x1 / raw ring slots of column q0 + p TS
                 unsigned xsw = 0;                                // x ring slot of column s0 + u TS (staging)
                 uint4 bfirst[3];
-                MI355_NOUNROLL
-                for (int it = 0; it < NIT; ++it) {
+                // one iteration: staging loads, (ACT: this block's tiles,) staging stores, barrier.  The phases — staging only,
+                // then tiles — are separate loops: a run-time `if (active)` around the tiles would leave the wait-count pass with two
+                // paths of different load counts and it would drain the tiles' prefetches in front of every staging store
+                auto iter = [&](int it, auto ACT) MI355_INLINE_LAMBDA {
                     const int p = it - 2;
                     float sv[8];
                     stage_load(it, sv);
-                    if (p >= 0 && p < N1) {
+                    if constexpr (decltype(ACT)::value) {
                         unsigned ringq = XOFF + (unsigned)q * XR16 + n16;  // from the window's base: the plane offsets fit the immediates
                         OPAQUE_V(ringq);
                         // a block's first tile reads its own first fragments (the columns may have been staged in the iteration
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                             const unsigned sb = mrfs_wrap(xrd + (unsigned)(chh * (16 * NT)), (unsigned)XR), f0 = ringq + 16u * sb;
                             mrfs_rd<G, K>(bfirst, 0, L0, f0, f0 - XR16, WAVE_UNIFORM(XR - (int)sb), lane, PSX16, XR16, d1);
                         }
-                        MI355_NOUNROLL
+                        MI355_UNROLL  // straight-line iteration bodies: the wait-count pass then counts the younger loads / stores exactly
                         for (int i = 0; i < NT; ++i) {
                             const int e0 = q0 + p * TS + chh * (16 * NT) + 16 * i;  // absolute column of lane n = 0
                             f32x4 acc;
@@ -347,7 +360,13 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                     }
                     stage_store(it, sv, xsw);
                     __syncthreads();
-                }
+                };
+                MI355_NOUNROLL
+                for (int it = 0; it < 2; ++it) iter(it, std::false_type{});
+                MI355_NOUNROLL
+                for (int it = 2; it < 2 + N1; ++it) iter(it, std::true_type{});
+                MI355_NOUNROLL
+                for (int it = 2 + N1; it < NIT; ++it) iter(it, std::false_type{});
             } else {
                 // ================================================================== conv2 waves (+ staging of x)
                 auto load_y = [&](int t0, float (&v)[4]) MI355_INLINE_LAMBDA {
@@ -357,6 +376,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                     const unsigned o = 4u * (unsigned)(co0 * a.y_ld + tc);
                     MI355_UNROLL
                     for (int r = 0; r < 4; ++r) v[r] = buf_load_f32(ybuf, o, (unsigned)r * yrow);
+                    SCHED_FENCE();
                 };
                 float yq[NT][4];  // y of this tile and the next two (zeros in the first resblock: nothing to read)
                 MI355_UNROLL
@@ -369,12 +389,11 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                 unsigned rwr = (unsigned)(((W1 - 1) * TS - r2) % RR);       // raw ring slot of column c0
                 unsigned xsw = 0;                                            // x ring slot of column s0 + u TS
                 uint4 bfirst[3];
-                MI355_NOUNROLL
-                for (int it = 0; it < NIT; ++it) {
+                auto iter = [&](int it, auto ACT) MI355_INLINE_LAMBDA {
                     const int m = it - 2 - W1;
                     float sv[8];
                     stage_load(it, sv);
-                    if (m >= 0 && m < N) {
+                    if constexpr (decltype(ACT)::value) {
                         unsigned ringq = X1OFF + (unsigned)q * X1R16 + n16;
                         OPAQUE_V(ringq);
                         const char* rawq = Rw + (unsigned)(co0 >> 2) * RR16;
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                             mrfs_rd<G, K>(bfirst, 0, L0, f0, f0 - X1R16, WAVE_UNIFORM(X1R - (int)sb), lane, PS116, X1R16, d2);
                         }
                         float4 x1n = *reinterpret_cast<const float4*>(rawq + 16u * mrfs_wrap(rwr + (unsigned)(chh * (16 * NT)) + (unsigned)n, (unsigned)RR));
-                        MI355_NOUNROLL
+                        MI355_UNROLL  // straight-line iteration bodies: the wait-count pass then counts the younger loads / stores exactly
                         for (int i = 0; i < NT; ++i) {
                             const int t0 = c0 + m * TS + chh * (16 * NT) + 16 * i;
                             const unsigned off = (unsigned)(chh * (16 * NT) + 16 * i);
@@ -403,19 +422,22 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                             const unsigned sbn = mrfs_wrap(x1r + offn, (unsigned)X1R);
                             if (!(LAB_ABLATE(a) & 1)) mrfs_tile<G, K, AH>(acc, W, L0, ringq, PS116, (unsigned)X1R, sb, d2, lane, bfirst, sbn);
                             const int t = t0 + n;
-                            if (t < a.T && !(LAB_ABLATE(a) & 4)) {
-                                const unsigned o = 4u * (unsigned)(co0 * a.y_ld + t);
-                                MI355_UNROLL
-                                for (int r = 0; r < 4; ++r)
-                                    buf_store_f32(ybuf, o, (unsigned)r * yrow, LAST ? acc[r] * out_mul : acc[r]);
-                            }
+                            // columns past the tensor: the lane's offset is moved out of the buffer's range and the hardware drops the
+                            // store (no branch around the stores: see stage_load)
+                            const unsigned o = (t < a.T && !(LAB_ABLATE(a) & 4)) ? 4u * (unsigned)(co0 * a.y_ld + t) : BUF_OOB;
+                            MI355_UNROLL
+                            for (int r = 0; r < 4; ++r) buf_store_f32(ybuf, o, (unsigned)r * yrow, LAST ? acc[r] * out_mul : acc[r]);
                         }
                         x1r = mrfs_wrap(x1r + TS, (unsigned)X1R);
                         rwr = mrfs_wrap(rwr + TS, (unsigned)RR);
                     }
                     stage_store(it, sv, xsw);
                     __syncthreads();
-                }
+                };
+                MI355_NOUNROLL
+                for (int it = 0; it < 2 + W1; ++it) iter(it, std::false_type{});
+                MI355_NOUNROLL
+                for (int it = 2 + W1; it < NIT; ++it) iter(it, std::true_type{});
             }
         };
 

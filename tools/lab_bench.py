@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mimic3_amd._native as N  # noqa: E402
 
-N.DEFAULT_LIBRARY = os.path.join(ROOT, "mimic3_amd", "csrc", "libmi355vits_lab.so")
+N.DEFAULT_LIBRARY = os.environ.get("MI355VITS_LAB_LIB") or os.path.join(ROOT, "mimic3_amd", "csrc", "libmi355vits_lab.so")  # (a variant build)
 import bench  # noqa: E402
 
 if __name__ == "__main__":
