@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                 const bool s_in = t >= 0 && t < len;
                 float v[8];
                 MI355_UNROLL
-                for (int e = 0; e < 8; ++e) v[e] = s_in ? lrelu_f(sv[e], 0.1f) : 0.0f;
+                for (int e = 0; e < 8; ++e) v[e] = s_in ? fmaxf(sv[e], 0.1f * sv[e]) : 0.0f;  // = leaky-relu(0.1), one compare fewer per element
                 uint4 h, mm, l;
                 split3_pk(v[0], v[1], h.x, mm.x, l.x);
                 split3_pk(v[2], v[3], h.y, mm.y, l.y);
@@ -496,12 +496,24 @@ int mrf_s_segment(int C, int B, int T, int cus) {
     const int min_blocks = 24;  // fill of <= 5 iterations: <= 20 % even at the shortest segment
     const long total_blocks = (long)B * ((T + TS - 1) / TS);
     if (total_blocks < (long)cus * min_blocks) return 0;
-    // segments per row: the multiple of `cus` items closest to the chip from above, rows divided evenly
-    int per_row = (int)((cus + B - 1) / B);
-    if (per_row < 1) per_row = 1;
-    int seg = ((T + per_row - 1) / per_row + TS - 1) / TS * TS;
-    if (seg < min_blocks * TS) seg = min_blocks * TS;
-    return seg;
+    // segments per row: the count that keeps the chip busiest — items / (rounds x CUs) of the persistent loop — times the
+    // share of a sweep that is not pipeline fill (N of N + 5 iterations); ties go to the fewer, longer segments
+    const int row_blocks = (T + TS - 1) / TS;
+    int best_pr = 0;
+    double best = 0.0;
+    for (int pr = 1; pr <= 4 * cus && row_blocks / pr >= min_blocks; ++pr) {
+        const int n = (row_blocks + pr - 1) / pr;  // blocks per segment
+        const int segs = (row_blocks + n - 1) / n;
+        const long items = (long)B * segs;
+        const long rounds = (items + cus - 1) / cus;
+        const double eff = (double)items / (double)(rounds * cus) * (double)n / (double)(n + 5);
+        if (eff > best + 1e-9) {
+            best = eff;
+            best_pr = pr;
+        }
+    }
+    if (best_pr == 0) return 0;
+    return (row_blocks + best_pr - 1) / best_pr * TS;
 }
 
 void launch_mrf_s(MrfArgs a, hipStream_t s) {

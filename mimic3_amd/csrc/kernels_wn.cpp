@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 // LDS: max(3 planes x 192 ch x 104 col x 2 B = 117 KiB, raw 384 x 96 x 4 B = 144 KiB).
 // ------------------------------------------------------------------------------------------------
 constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
+constexpr int WNB_DEFAULT_WAVES = 4;  // waves of the 96-column form: see launch_wn_layer_b3
 
 // NT column tiles per workgroup: 3 (96 columns) when the grid fills the chip, 1 (32 columns) for small grids (one
 // utterance: a third of the dependent MFMA chain per wave, three times the workgroups).  The arithmetic of an output
@@ -451,8 +452,13 @@ constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
 // H2 (MATH_F16X2): operands as two fp16 planes (activations x 2^4 while they are split, weights x 2^13 when packed), three
 // products per multiply-add; the accumulators run scaled by 2^17 (bias and conditioning enter scaled) and are unscaled,
 // exactly, where they leave the matrix cores — the gate and the residual / skip updates see the same values as before.
-template <bool W1, int NT, bool H2 = false>
-__global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
+// MW row tiles (of the 12) per wave: 3 = four waves, one per SIMD with the whole register file each; 1 = twelve waves, three per
+// SIMD with 170 registers each — the same fragments fetched once per workgroup, the same products in the same order per
+// accumulator (bit-identical), but three instruction streams per SIMD to cover each other's L2 / LDS waits in the matrix loops
+// (the four-wave form loses 40 % on a box whose fabric answers slower).
+template <bool W1, int NT, bool H2 = false, int MW = 3>
+__global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
+    constexpr int NWV = 12 / MW, NTH = 64 * NWV;
     static_assert(!(W1 && H2), "one reduced-operand variant at a time");
     constexpr int H = WNB_H, T_B = 32 * NT, NG = WNB_NG;
     constexpr int NP = H2 ? 2 : 3, GW = H2 ? 128 : 192;  // planes per operand; uint4 per weight-fragment group
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     const int PS = NG * 2 * LD;    // uint4 per plane
     const bool two = a.Crs == 2 * H;
 
-    if (!(LAB_ABLATE(a) & 2)) stage_planes<NG, NG, H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, 256);  // 2 column sets x 12 rows: one round trip
+    if (!(LAB_ABLATE(a) & 2)) stage_planes<NG, (MW == 3 ? NG : 4), H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, NTH);  // column sets x row batches: one round trip
     __syncthreads();
 
     // ---- in-layer conv: wave w owns row tiles w, w + 4, w + 8 (rows 32 q .. 32 q + 31 of the 2H), all 3 column tiles
@@ -482,40 +488,42 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     const float* condp = a.cond ? a.cond + (long)b * a.cond_bs : a.b_in;
     const float cond_on = a.cond ? 1.0f : 0.0f;
     {
-        f32x16 acc[3][NT];
-        const uint4* wp[3];
+        f32x16 acc[MW][NT];
+        const uint4* wp[MW];
         MI355_UNROLL
-        for (int i = 0; i < 3; ++i) {
-            const int q = w + 4 * i;
+        for (int i = 0; i < MW; ++i) {
+            const int q = w + NWV * i;
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
-                const float v = (a.b_in[c] + cond_on * condp[c]) * ACC;  // unconditional loads: all 48 in flight together
+                const float v = (a.b_in[c] + cond_on * condp[c]) * ACC;  // unconditional loads: all in flight together
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) acc[i][j][r] = v;
             }
             wp[i] = reinterpret_cast<const uint4*>(a.w_in) + (long)q * a.K * NG * GW + lane;
         }
         if (!(LAB_ABLATE(a) & 1)) {
-            if constexpr (H2) h2_chunk<3, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
-            else b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+            // (twelve waves: 170 registers each — the form with the B fragments single-buffered, same products in the same order)
+            if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+            else if constexpr (MW == 1) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+            else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         }
         __syncthreads();  // every wave is done with the h planes: the raw result takes their place
         MI355_UNROLL
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < MW; ++i)
             MI355_UNROLL
             for (int j = 0; j < NT; ++j)
                 MI355_UNROLL
                 for (int r = 0; r < 16; ++r)
-                    R[(32 * (w + 4 * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r] * UNACC;
+                    R[(32 * (w + NWV * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r] * UNACC;
     }
     __syncthreads();
     // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
-    constexpr int ITEMS = NG * 2 * T_B / 256;  // 9 (96 columns) or 3 (32)
+    constexpr int ITEMS = NG * 2 * T_B / NTH;  // four waves: 9 (96 columns) or 3 (32); twelve: 3 or 1
     float u[ITEMS][8];
     MI355_UNROLL
     for (int it = 0; it < ITEMS; ++it) {
-        const int idx = tid + 256 * it;
+        const int idx = tid + NTH * it;
         const int gh = idx / T_B, col = idx - gh * T_B;
         const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
         MI355_UNROLL
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     constexpr int PSU = NG * 2 * T_B;
     MI355_UNROLL
     for (int it = 0; it < ITEMS; ++it) {
-        const int idx = tid + 256 * it;  // = gh * T_B + col
+        const int idx = tid + NTH * it;  // = gh * T_B + col
         if constexpr (H2) {
             uint4 h4, m4;
             split2_pk(u[it][0] * F16X2_X_SCALE, u[it][1] * F16X2_X_SCALE, h4.x, m4.x);
@@ -555,12 +563,12 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     __syncthreads();
     // ---- res/skip 1x1 conv: Crs / 32 row tiles (12, last layer 6), tile q on wave q % 4
     const int ntr = a.Crs / 32;
-    f32x16 acc[3][NT];
+    f32x16 acc[MW][NT];
     {
-        const uint4* wp[3];
+        const uint4* wp[MW];
         MI355_UNROLL
-        for (int i = 0; i < 3; ++i) {
-            int q = w + 4 * i;
+        for (int i = 0; i < MW; ++i) {
+            int q = w + NWV * i;
             if (q >= ntr) q = ntr - 1;  // beyond the last tile: recompute it, discarded below
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
@@ -571,10 +579,11 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
             wp[i] = reinterpret_cast<const uint4*>(a.w_rs) + (long)q * NG * GW + lane;
         }
         if (!(LAB_ABLATE(a) & 1)) {
-            if (two) {
-                if constexpr (H2) h2_chunk<3, NT, NG, NT>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
-                else b3_chunk<3, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
-            } else {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
+            if (two || MW == 1) {  // (twelve waves, six tiles: waves 6 .. 11 recompute the last tile, discarded below)
+                if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                else if constexpr (MW == 1) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+            } else if constexpr (MW == 3) {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
                 f32x16 a2[2][NT];
                 const uint4* w2[2] = {wp[0], wp[1]};
                 MI355_UNROLL
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
         }
         if constexpr (H2) {  // back to the unscaled domain (exact)
             MI355_UNROLL
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < MW; ++i)
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j)
                     MI355_UNROLL
@@ -603,13 +612,13 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     // lane needs per 32 x 32 tile are loaded unconditionally (clamped column) and one tile ahead of the stores: the
     // memory counter retires in order, so a load issued after a store cannot be waited for without waiting for that
     // store's acknowledgement too — with tile k + 1's loads in front of tile k's stores no wait includes a fresh store.
-    const float* src[3];
-    float* dst[3];
-    long ldr[3];
-    bool valid[3], use_old[3], to_h[3];
+    const float* src[MW];
+    float* dst[MW];
+    long ldr[MW];
+    bool valid[MW], use_old[MW], to_h[MW];
     MI355_UNROLL
-    for (int i = 0; i < 3; ++i) {
-        const int q = w + 4 * i;
+    for (int i = 0; i < MW; ++i) {
+        const int q = w + NWV * i;
         valid[i] = q < ntr;
         const int qc = valid[i] ? q : ntr - 1;
         to_h[i] = two && 32 * qc < H;  // wave-uniform
@@ -647,8 +656,8 @@ __global__ __launch_bounds__(256) void k_wn_layer_b3(WnArgs a) {
     float old[2][16];
     load_tile(0, 0, old[0]);
     MI355_UNROLL
-    for (int k = 0; k < 3 * NT; ++k) {
-        if (k + 1 < 3 * NT) load_tile((k + 1) / NT, (k + 1) % NT, old[(k + 1) & 1]);
+    for (int k = 0; k < MW * NT; ++k) {
+        if (k + 1 < MW * NT) load_tile((k + 1) / NT, (k + 1) % NT, old[(k + 1) & 1]);
         SCHED_FENCE();
         store_tile(k / NT, k % NT, old[k & 1]);
         SCHED_FENCE();
@@ -675,20 +684,31 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     const size_t raw = (size_t)2 * WNB_H * tb * sizeof(float);
     if (raw > shmem) shmem = raw;
     dim3 grid((a.T + tb - 1) / tb, a.B);
-    auto go = [&](auto kfn) {
+    // four waves (one per SIMD, the whole register file each) is the product's form.  The twelve-wave form (three per SIMD; MW = 1)
+    // is bit-identical and measured EQUAL on the MI355X (16 layers 1.77 vs 1.76 ms, profiles/r04_wn_experiments.txt): the matrix
+    // loops do not wait on latencies that more waves could cover, what the layer loses it loses in its serial phases — so it is
+    // compiled into the lab build and the CPU model only (MI355VITS_WN_WAVES=12), as the A/B of that statement
+    const char* nw_s = lab_getenv("MI355VITS_WN_WAVES");
+    const int nw = nw_s ? atoi(nw_s) : WNB_DEFAULT_WAVES;
+    auto go = [&](auto kfn, int threads) {
 #ifndef MI355_EMU
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
 #endif
-        LAUNCH_KERNEL(kfn, grid, dim3(256), shmem, s, a);
+        LAUNCH_KERNEL(kfn, grid, dim3(threads), shmem, s, a);
     };
     if (nt == 1) {
-        if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 1, true>);
-        else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>);
-        else go(k_wn_layer_b3<false, 1>);
+        if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 1, true>, 256);
+        else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>, 256);
+        else go(k_wn_layer_b3<false, 1>, 256);
+#if defined(MI355_LAB) || defined(MI355_EMU)
+    } else if (nw == 12 && a.math != MATH_F16X2) {
+        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3, false, 1>, 768);
+        else go(k_wn_layer_b3<false, 3, false, 1>, 768);
+#endif
     } else {
-        if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 3, true>);
-        else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3>);
-        else go(k_wn_layer_b3<false, 3>);
+        if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 3, true>, 256);
+        else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3>, 256);
+        else go(k_wn_layer_b3<false, 3>, 256);
     }
 }
 

@@ -492,6 +492,22 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
         finally:
             del os.environ["MI355VITS_WN_B3_NT"]
     assert np.array_equal(by_nt["1"], by_nt["3"])
+    # ... and the twelve-wave form of the 96-column tile (one row tile per wave, three waves per SIMD) against the four-wave one
+    by_nw = {}
+    for nw in ("4", "12"):
+        os.environ["MI355VITS_WN_B3_NT"] = "3"
+        os.environ["MI355VITS_WN_WAVES"] = nw
+        try:
+            for mode in ("bf16x3", "bf16w"):
+                eng = Engine(blob, library=emu_lib)
+                eng.set_math(mode)
+                by_nw[nw, mode] = eng.run(ids, np.array([30, 17]), (0.667, 1.0, 0.8), sid, forced_durations=forced, seed=3)["audio"]
+                eng.close()
+        finally:
+            del os.environ["MI355VITS_WN_B3_NT"], os.environ["MI355VITS_WN_WAVES"]
+    assert np.array_equal(by_nw["4", "bf16x3"], by_nt["3"])
+    for mode in ("bf16x3", "bf16w"):
+        assert np.array_equal(by_nw["4", mode], by_nw["12", mode]), mode
 
 
 def test_f16x2_mode_fused_mrf_stages(emu_lib):

@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-export MI355VITS_MRF_SWEEP_SEG=6240
-for ab in 0 2 4 6 1; do
-  MI355VITS_MRF_ABLATE=$ab timeout 300 python tools/lab_bench.py --steps 30 --streams 1 --no-extra --no-cpu-baseline --no-traffic --no-b1 > $O/r04_c.json 2> $O/r04_c.err
-  echo "ablate=$ab $(grep "mrf_s" $O/r04_c.err | awk '{print $1, $4}' | tr '\n' ' ')"
+for nw in 4 12 4 12; do
+  MI355VITS_WN_WAVES=$nw timeout 300 python tools/lab_bench.py --steps 40 --streams 1 --no-extra --no-cpu-baseline --no-traffic > $O/r04_c.json 2> $O/r04_c.err
+  echo "waves=$nw $(grep -o '"ms_per_step": [0-9.]*' $O/r04_c.json | head -1) $(grep "wn_layer" $O/r04_c.err | awk '{print $1, $4}' | tr '\n' ' ')"
 done
