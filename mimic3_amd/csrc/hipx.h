@@ -77,7 +77,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16_f32(float lo, float hi) {
 // hardware transcendental paths (v_exp_f32 / v_rcp_f32, ~1 ulp): used where the result feeds a bounded
 // non-linearity (WaveNet gate), not where exact rounding matters (durations, int16 scaling)
 #define FAST_EXPF(x) __expf(x)
-#define FAST_RCPF(x) __frcp_rn(x)
+#define FAST_RCPF(x) __builtin_amdgcn_rcpf(x)  // v_rcp_f32 (1 ulp); __frcp_rn is the IEEE division sequence: ten instructions
+// (WN_GATE below is the only user of the two)
 // Pin the hand-written software pipeline: hipcc otherwise clusters the ring's prefetch loads into one burst right
 // before their first use (prefetch distance collapses from four k-steps to one).  Nothing moves across this point.
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -160,6 +161,14 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 // LD multiples of 4) interior elements move as 16-byte loads / ds_write_b128.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v >= 0.0f ? v : v * slope; }
+// WaveNet gate tanh(a) * sigmoid(s) with ONE reciprocal: (e^2a - 1) / ((e^2a + 1) (1 + e^-s)); two v_exp_f32, one v_rcp_f32 and
+// five plain VALU per element (round 3: two IEEE reciprocals = 2 x 10 instructions — the gate phase was 19 % of a WaveNet layer,
+// profiles/r04_wn_experiments.txt).  Arguments clamped so that every factor stays finite: e^30 * e^30 < f32 max.
+__device__ __forceinline__ float wn_gate_f(float at, float as) {
+    const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(at, -15.0f), 15.0f));
+    const float es = FAST_EXPF(-fminf(fmaxf(as, -30.0f), 30.0f));
+    return (e2 - 1.0f) * FAST_RCPF((e2 + 1.0f) * (1.0f + es));
+}
 
 template <int NW, int QU>  // QU column groups (64 x 16 B each) per batch: RU * QU 16-byte loads in flight per lane
 __device__ __forceinline__ void stage_tile(const float* __restrict__ xb, long x_ld, int rows, int LD, int ts, int tend,

@@ -92,10 +92,8 @@ __device__ __forceinline__ void epi_gate(const ConvArgs& a, int b, int c, int t,
     if (a.bias) { v0 += a.bias[c]; v1 += a.bias[c + a.H]; }
     if (a.cond) { v0 += a.cond[(long)b * a.cond_bs + c]; v1 += a.cond[(long)b * a.cond_bs + c + a.H]; }
     // tanh(x) = 1 - 2 / (exp(2x) + 1), sigmoid(x) = 1 / (1 + exp(-x)); clamp keeps exp finite
-    const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(v0, -15.0f), 15.0f));
-    const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
-    const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(v1, -30.0f), 30.0f)));
-    a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = th * sg;
+    const float gate = wn_gate_f(v0, v1);
+    a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = gate;
 }
 
 // WaveNet res/skip update (A.9): h = (h + rs[:H]) * mask ; skip += rs[H:]  (last layer: skip += rs)
@@ -243,10 +241,8 @@ __device__ __forceinline__ void epi_gate_tile(const ConvArgs& a, int b, int c0, 
     MI355_UNROLL
     for (int r = 0; r < 16; ++r) {
         const int c = c0 + tile_row(r, brow);
-        const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(v0[r], -15.0f), 15.0f));
-        const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
-        const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(v1[r], -30.0f), 30.0f)));
-        if (c < a.H) a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = th * sg;
+        const float gate = wn_gate_f(v0[r], v1[r]);
+        if (c < a.H) a.y[(long)b * a.y_bs + (long)c * a.y_ld + t] = gate;
     }
 }
 

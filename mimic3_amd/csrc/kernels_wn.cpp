@@ -121,10 +121,7 @@ __global__ __launch_bounds__(64 * NP) MIN_WAVES_PER_SIMD(NP > 1 ? 5 : 1) void k_
         if (!(LAB_ABLATE(a) & 1)) wn_mfma2<CP>(acc0, acc1, wp0, wp1, X + brow * LDX + toff + bcol, LDX, a.K, a.dil);
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) {
-            const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(acc0[r], -15.0f), 15.0f));
-            const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
-            const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(acc1[r], -30.0f), 30.0f)));
-            gate[r] = th * sg;
+            gate[r] = wn_gate_f(acc0[r], acc1[r]);
             const int c = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * brow;
             hres[r] = X[c * LDX + toff + pad + bcol];
         }
@@ -352,10 +349,8 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
     __syncthreads();
     for (int idx = tid; idx < H * 32; idx += NTH) {  // gate in place: U[c][t] = tanh(A[c][t]) * sigmoid(A[H + c][t])
         const float at = X[idx], as = X[H * 32 + idx];
-        const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(at, -15.0f), 15.0f));
-        const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
-        const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(as, -30.0f), 30.0f)));
-        X[idx] = th * sg;
+        const float gate = wn_gate_f(at, as);
+        X[idx] = gate;
     }
     __syncthreads();
     // ---- res/skip 1x1 conv: row tiles q < 6 -> h', q >= 6 -> skip (last layer: 6 tiles, all -> skip)
@@ -442,7 +437,25 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 // LDS: max(3 planes x 192 ch x 104 col x 2 B = 117 KiB, raw 384 x 96 x 4 B = 144 KiB).
 // ------------------------------------------------------------------------------------------------
 constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
-constexpr int WNB_DEFAULT_WAVES = 4;  // waves of the 96-column form: see launch_wn_layer_b3
+constexpr int WNB_DEFAULT_WAVES = 4;
+// phase clocks of one workgroup (lab build, MI355VITS_WN_ABLATE bit 64): shader-clock deltas printed by workgroup (3, 5), wave 0
+#if defined(MI355_LAB) && !defined(MI355_EMU)
+#define WN_TS_DECL() long long wn_ts[7] = {0, 0, 0, 0, 0, 0, 0}
+#define WN_TS(i) do { if (a.ablate & 64) wn_ts[i] = __builtin_readcyclecounter(); } while (0)
+#define WN_TS_END()                                                                                                                  \
+    do {                                                                                                                             \
+        if ((a.ablate & 64) && blockIdx.x == 3 && blockIdx.y == 5 && threadIdx.x == 0) {                                            \
+            __builtin_amdgcn_s_waitcnt(0);                                                                                           \
+            wn_ts[6] = __builtin_readcyclecounter();                                                                                 \
+            printf("wn phases (cycles): stage %lld inconv %lld rawstore %lld gate+planes %lld rs %lld epilogue %lld total %lld\n", wn_ts[1] - wn_ts[0], \
+                   wn_ts[2] - wn_ts[1], wn_ts[3] - wn_ts[2], wn_ts[4] - wn_ts[3], wn_ts[5] - wn_ts[4], wn_ts[6] - wn_ts[5], wn_ts[6] - wn_ts[0]);   \
+        }                                                                                                                            \
+    } while (0)
+#else
+#define WN_TS_DECL() ((void)0)
+#define WN_TS(i) ((void)0)
+#define WN_TS_END() ((void)0)
+#endif  // waves of the 96-column form: see launch_wn_layer_b3
 
 // NT column tiles per workgroup: 3 (96 columns) when the grid fills the chip, 1 (32 columns) for small grids (one
 // utterance: a third of the dependent MFMA chain per wave, three times the workgroups).  The arithmetic of an output
@@ -477,11 +490,14 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
     const int toff = tlo - ts;
     const int LD = a.ldx;          // staged columns of the h tile
+    WN_TS_DECL();
+    WN_TS(0);
     const int PS = NG * 2 * LD;    // uint4 per plane
     const bool two = a.Crs == 2 * H;
 
     if (!(LAB_ABLATE(a) & 2)) stage_planes<NG, (MW == 3 ? NG : 4), H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, NTH);  // column sets x row batches: one round trip
     __syncthreads();
+    WN_TS(1);
 
     // ---- in-layer conv: wave w owns row tiles w, w + 4, w + 8 (rows 32 q .. 32 q + 31 of the 2H), all 3 column tiles
     // (speaker conditioning without a branch per element — a test per load makes hipcc wait for each one in turn)
@@ -509,6 +525,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
             else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         }
         __syncthreads();  // every wave is done with the h planes: the raw result takes their place
+        WN_TS(2);
         MI355_UNROLL
         for (int i = 0; i < MW; ++i)
             MI355_UNROLL
@@ -518,6 +535,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
                     R[(32 * (w + NWV * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r] * UNACC;
     }
     __syncthreads();
+    WN_TS(3);
     // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
     constexpr int ITEMS = NG * 2 * T_B / NTH;  // four waves: 9 (96 columns) or 3 (32); twelve: 3 or 1
     float u[ITEMS][8];
@@ -530,10 +548,8 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
         for (int e = 0; e < 8; ++e) {
             const int c = cbase + 8 * (e >> 2) + (e & 3);
             const float at = R[c * T_B + col], as = R[(H + c) * T_B + col];
-            const float e2 = FAST_EXPF(2.0f * fminf(fmaxf(at, -15.0f), 15.0f));
-            const float th = 1.0f - 2.0f * FAST_RCPF(e2 + 1.0f);
-            const float sg = FAST_RCPF(1.0f + FAST_EXPF(-fminf(fmaxf(as, -30.0f), 30.0f)));
-            u[it][e] = th * sg;
+            const float gate = wn_gate_f(at, as);
+            u[it][e] = gate;
         }
     }
     __syncthreads();  // the raw result has been consumed: u's planes take its place (column pitch T_B)
@@ -561,6 +577,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
         }
     }
     __syncthreads();
+    WN_TS(4);
     // ---- res/skip 1x1 conv: Crs / 32 row tiles (12, last layer 6), tile q on wave q % 4
     const int ntr = a.Crs / 32;
     f32x16 acc[MW][NT];
@@ -607,6 +624,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] *= UNACC;
         }
     }
+    WN_TS(5);
     if ((LAB_ABLATE(a) & 4) && acc[0][0][0] != 1.2345f) return;
     // ---- epilogue: rows < H (two-output layers): h' = (h + rs) * mask; the others: skip (+)= rs.  The 16 old values a
     // lane needs per 32 x 32 tile are loaded unconditionally (clamped column) and one tile ahead of the stores: the
@@ -662,6 +680,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
         store_tile(k / NT, k % NT, old[k & 1]);
         SCHED_FENCE();
     }
+    WN_TS_END();
 }
 
 bool wn_layer_b3_supported(int H, int K, int dil) {
