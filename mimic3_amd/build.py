@@ -17,9 +17,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
-SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
+SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_mrfs1.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
 PER_FILE_FLAGS = {}
 LAB_FILE_FLAGS = {}  # per-file flags of the lab build's side of a running A/B (none at the moment)
+# sources the lab build compiles exactly as the product does (no -DMI355_LAB): k_mrf_p's in-loop ablation tests cost 15 % of its
+# time, and it is now the REFERENCE side of the sweep kernels' A/B (its own ablations are in profiles/r03_mrf_experiments.txt)
+LAB_AS_PRODUCT = {"kernels_mrfp.cpp"}
+# sources of the lab build and the CPU model only: designs that measured EQUAL or worse than what the product runs, kept with their
+# tests as the A/B of that statement (k_mrf_s1: the 32-channel stage as a single-pass sweep, 2.33 vs k_mrf_p's 2.34 ms)
+LAB_ONLY = {"kernels_mrfs1.cpp"}
 HIP_LIB = os.path.join(CSRC, "libmi355vits.so")
 EMU_LIB = os.path.join(EMU, "libmi355vits_emu.so")
 
@@ -61,20 +67,20 @@ def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = 
     hipcc = find_hipcc()
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
             "-I", os.path.join(ROOT, "include")]
-    if lab:
-        base.append("-DMI355_LAB")
     if verbose_resources:
         base.append("-Rpass-analysis=kernel-resource-usage")
     jobs = []
-    for s in SOURCES:
+    srcs = [s for s in SOURCES if lab or s not in LAB_ONLY]
+    for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".cpp", ".o"))
         if force or verbose_resources or _stale(obj, [src] + hdrs):
-            jobs.append(base + PER_FILE_FLAGS.get(s, []) + (LAB_FILE_FLAGS.get(s, []) if lab else []) + ["-c", src, "-o", obj])
+            lab_flags = (["-DMI355_LAB"] if s not in LAB_AS_PRODUCT else []) + LAB_FILE_FLAGS.get(s, []) if lab else []
+            jobs.append(base + PER_FILE_FLAGS.get(s, []) + lab_flags + ["-c", src, "-o", obj])
     if jobs:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(_run, jobs))
-    objs = [os.path.join(objdir, s.replace(".cpp", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, s.replace(".cpp", ".o")) for s in srcs]
     if jobs or _stale(target, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"])
         os.replace(target + ".tmp", target)

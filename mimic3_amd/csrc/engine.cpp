@@ -1164,12 +1164,27 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
                     // large grids: the row sweep (k_mrf_s: fragments register-resident per segment, no halo recompute); small ones:
                     // (row, column block) items (k_mrf_p).  The two agree bit for bit, so the choice may follow the grid.
-                    int seg = mrf_s_supported(ch, nk, m.k, m.d1, m.d2) ? mrf_s_segment(ch, B, (int)T, current_device_cu_count()) : 0;
-                    if (const char* f = lab_getenv("MI355VITS_MRF_SWEEP_SEG")) seg = mrf_s_supported(ch, nk, m.k, m.d1, m.d2) ? atoi(f) : 0;  // lab / tests
+                    // 64 channels: one pass per resblock (k_mrf_s).  32 channels: k_mrf_p — its single-pass sweep (k_mrf_s1) measured
+                    // equal (2.33 vs 2.34 ms) and lives in the lab build / CPU model only (MI355VITS_MRF_SWEEP_SEG32 = segment length)
+                    bool s1 = false;
+                    bool sw_ok = ch != 32 && mrf_s_supported(ch, nk, m.k, m.d1, m.d2);
+                    int seg = !sw_ok ? 0 : mrf_s_segment(ch, B, (int)T, current_device_cu_count());
+                    if (const char* f = lab_getenv("MI355VITS_MRF_SWEEP_SEG")) seg = sw_ok ? atoi(f) : 0;  // lab / tests
+#if defined(MI355_LAB) || defined(MI355_EMU)
+                    if (ch == 32 && mrf_s1_supported(ch, nk, m.k, m.d1, m.d2)) {
+                        const char* f = lab_getenv("MI355VITS_MRF_SWEEP_SEG32");
+                        if (!f) f = lab_getenv("MI355VITS_MRF_SWEEP_SEG");
+                        if (f && atoi(f) > 0) { s1 = true; seg = atoi(f); }
+                    }
+#endif
                     if (seg > 0) {
                         m.seg = seg;
                         ProfScope ps(prof_, i == 1 ? "dec.mrf_s.s1" : (i == 2 ? "dec.mrf_s.s2" : "dec.mrf_s"), flops, 8.0 * B * (double)T * ch);
-                        launch_mrf_s(m, stream_);
+#if defined(MI355_LAB) || defined(MI355_EMU)
+                        if (s1) launch_mrf_s1(m, stream_);
+                        else
+#endif
+                            launch_mrf_s(m, stream_);
                     } else {
                         ProfScope ps(prof_, i == 1 ? "dec.mrf_p.s1" : (i == 2 ? "dec.mrf_p.s2" : "dec.mrf_p"), flops, 8.0 * B * (double)T * ch);
                         launch_mrf_p(m, stream_);

@@ -146,6 +146,11 @@ void launch_mrf_p(MrfArgs a, hipStream_t s);
 bool mrf_s_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 int mrf_s_segment(int C, int B, int T, int cus);
 void launch_mrf_s(MrfArgs a, hipStream_t s);
+// The 32-channel stage as a SINGLE-pass sweep (kernels_mrfs1.cpp; lab build and CPU model only: it measured equal to k_mrf_p): waves
+// specialised by (row tile, conv, resblock group), x staged once, y written once; same bits as k_mrf_p.
+bool mrf_s1_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
+int mrf_s1_segment(int B, int T, int cus);
+void launch_mrf_s1(MrfArgs a, hipStream_t s);
 int current_device_cu_count();  // compute units of the current device (persistent grids), looked up once per device
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, current device)
 void set_max_dynamic_lds(const void* fn, int bytes);

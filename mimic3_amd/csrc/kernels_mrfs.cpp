@@ -11,23 +11,25 @@
 // Here a work item is (row, segment of `seg` columns), and the workgroup sweeps it left to right once per resblock in steps
 // of TS columns with the waves SPECIALISED by conv:
 //
-//      staging  (conv2 waves)  x[s0 + u TS ..)      -> three bf16 planes of lrelu(x) in an LDS ring        iteration u
+//      staging  (all threads)  x[s0 + u TS ..)      -> three bf16 planes of lrelu(x) in an LDS ring        iteration u
 //      conv1    (waves 0-3)    x1[q0 + p TS ..)     -> planes of lrelu(x1) in a second ring, raw x1 (f32)   iteration p + 2
 //      conv2    (waves 4-7)    y [c0 + m TS ..)     <- y + x1 + b2 + conv2(lrelu(x1))   (global, in place)  iteration m + 2 + W1
 //
 // one workgroup barrier per iteration.  conv1 runs r2 columns (+ the pipeline slack) ahead of conv2, staging r1 ahead of conv1:
 // every x1 column is computed exactly once, and each wave keeps the K x C/32 x 3 fragments of ITS conv and ITS 16 output
 // channels in registers for the whole sweep (168 VGPRs at k = 7 and 64 channels).  The rings are addressed modulo their
-// length per lane (one v_sub + v_min_u32 per B fragment), so a sweep is a plain loop: no copies, no halo recompute except the
-// (r1 + r2) columns of pipeline fill at a segment's start.
+// length (a wave-uniform lane mask + one v_cndmask per B fragment, mrfs_rd), so a sweep is a plain loop: no copies, no halo
+// recompute except the (r1 + r2) columns of pipeline fill at a segment's start.  Everything between a load's issue and its
+// use is branch-free and the tile loops are unrolled: see the note at stage_load (hipcc's wait-count pass).
 // The sum over the resblocks lives in y: resblock 0 writes its raw result, 1 adds, the last adds and scales — in exactly
 // k_mrf_p's order of additions (out = ((0 + rb0) + rb1) + rb2, each as `old + (x1 + b2)` feeding the accumulator chain), so the
 // two kernels agree bit for bit and the launcher may choose by grid size.  The price is HBM traffic: x is read once per
-// resblock and y is read / written once more per resblock after the first (4 x the stage's algorithmic bytes) — these
-// stages run at 4 % of the HBM roof, and persistent workgroups at different points of their sweeps spread it evenly.
+// resblock and y is read / written once more per resblock after the first (4 x the stage's algorithmic bytes).  That pays
+// at 64 channels (2.42 -> 1.8 ms per launch at the bench shape) and not at 32 (half the MFMAs per byte and per tile: 2.6 - 2.85 ms
+// against k_mrf_p's 2.31): mrf_s_segment keeps the 32-channel stage on k_mrf_p.  Experiments: profiles/r04_mrf_sweep.txt.
 #include <type_traits>
 
-#include "kernels.h"
+#include "mrfs.h"
 
 namespace m355 {
 
@@ -35,12 +37,6 @@ namespace {
 constexpr size_t MRFS_LDS_LIMIT = 160 * 1024;
 constexpr int MRFS_NT = 3;  // 16-column tiles per wave and iteration
 }  // namespace
-
-// ring offset (any unit) -> [0, ring): valid for c < 2 * ring (unsigned: c - ring wraps around when c < ring)
-__device__ __forceinline__ unsigned mrfs_wrap(unsigned c, unsigned ring) {
-    const unsigned t = c - ring;
-    return c < t ? c : t;
-}
 
 // compile-time ring lengths (columns) and dilations of the "_low" voices' stages, or MrfSDyn = take them from the arguments
 template <int XR_, int X1R_, int RR_, int D10, int D20, int D11, int D21, int D12, int D22>
@@ -50,104 +46,6 @@ struct MrfSShape {
     static constexpr int d2(int j) { return j == 0 ? D20 : (j == 1 ? D21 : D22); }
 };
 using MrfSDyn = MrfSShape<0, 0, 0, 0, 0, 0, 0, 0, 0>;
-
-// One 16-column tile of one conv for this wave's 16 output rows: acc (+)= sum over the C / 32 k-groups and K taps, in
-// k_mrf_p's order: per k-group two accumulator chains (small terms -> as, large terms -> ab), joined (ab + as) after the
-// group's last tap.  W: this wave's fragments [k-group][tap][plane].  ring_q: LDS byte address of (plane 0, k-group 0, this
-// lane's quarter, column slot 0); a k-group is 4 * ring16 bytes further, a plane PS16.  sb16: ring byte offset of the tile's
-// column 0 at tap 0 (wave-uniform, < ring16); n16: this lane's column * 16; d16: dilation * 16.
-// Ring wrap without per-lane arithmetic in the steps.  A tile's lane n reads ring slot (sb + n + s d) mod ring at tap s; the
-// lanes that have passed the ring's end at tap s are n >= ring - sb - s d — the same 16-lane pattern in all four quarters and
-// a function of wave-uniform values only, so the mask is built on the scalar unit and ONE v_cndmask per step picks between
-// the lane's two addresses (base, base - ring); the tap's s d columns ride in the instruction's immediate offset together
-// with the k-group and plane offsets.
-__device__ __forceinline__ unsigned long long mrfs_lane_mask(int th) {  // lanes n >= th of every 16-lane quarter
-#ifdef MI355_EMU
-    th = th < 0 ? 0 : (th > 16 ? 16 : th);
-    const unsigned m16 = (0xffffu << th) & 0xffffu;
-    const unsigned m32 = m16 * 0x10001u;
-#else
-    // on the scalar unit, whatever the compiler would pick for the clamp (it selects v_med3_i32 and drags the rest onto the VALU)
-    unsigned m32;
-    asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, 16\n\ts_lshl_b32 %0, 0xffff, %0\n\ts_and_b32 %0, %0, 0xffff\n\ts_mul_i32 %0, %0, 0x10001"
-        : "=&s"(m32)
-        : "s"(th)
-        : "scc");
-#endif
-    return ((unsigned long long)m32 << 32) | m32;
-}
-__device__ __forceinline__ unsigned mrfs_sel(unsigned a, unsigned b, unsigned long long mask, int lane) {  // mask bit set ? b : a
-#ifdef MI355_EMU
-    return ((mask >> lane) & 1ull) ? b : a;
-#else
-    (void)lane;
-    unsigned r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
-    return r;
-#endif
-}
-
-// the three plane fragments of step st of a tile: lds0 = the LDS window's base; a0 / a1 = this lane's byte offset of (plane 0,
-// k-group 0, its quarter, the tile's column at tap 0) without / with the ring subtracted; wr = ring - sb (columns)
-template <int G, int K>
-__device__ __forceinline__ void mrfs_rd(uint4 (&f)[3], int st, const char* __restrict__ lds0, unsigned a0, unsigned a1, int wr, int lane, unsigned PS16,
-                                        unsigned ring16, int d) {
-    const int g = st / K, s = st % K;
-    const unsigned a = mrfs_sel(a0, a1, mrfs_lane_mask(wr - s * d), lane);
-    const char* p = lds0 + a + ((unsigned)g * 4u * ring16 + 16u * (unsigned)(s * d));
-    MI355_UNROLL
-    for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const uint4*>(p + (unsigned)pl * PS16);
-}
-
-// One 16-column tile of one conv for this wave's 16 output rows: acc (+)= sum over the C / 32 k-groups and K taps, in
-// k_mrf_p's order: per k-group two accumulator chains (small terms -> as, large terms -> ab), joined (ab + as) after the
-// group's last tap.  W: this wave's fragments [k-group][tap][plane].  rq: this lane's byte offset of (plane 0, k-group 0, its
-// quarter, slot 0) + 16 n; sb: ring slot of the tile's column 0 at tap 0 (wave-uniform, < ring); d: the dilation.
-// bfirst: on entry the tile's step-0 fragments (read by the previous tile, or by the caller for a block's first), on exit the
-// NEXT tile's (ring slot sbn), read behind this tile's last step — a tile never starts with an exposed LDS round trip.
-template <int G, int K, int AH>
-__device__ __forceinline__ void mrfs_tile(f32x4& acc, const uint4 (&W)[G][K][3], const char* __restrict__ lds0, unsigned rq, unsigned PS16, unsigned ring,
-                                          unsigned sb, int d, int lane, uint4 (&bfirst)[3], unsigned sbn) {
-    constexpr int NSTEP = G * K, RING = AH + 1;
-    static_assert(AH >= 1 && NSTEP > AH, "the ring holds the running step and AH steps ahead");
-    const unsigned ring16 = 16u * ring;
-    const unsigned a0 = rq + 16u * sb, a1 = a0 - ring16;
-    const int wr = WAVE_UNIFORM((int)ring - (int)sb);
-    uint4 bf[RING][3];
-    MI355_UNROLL
-    for (int pl = 0; pl < 3; ++pl) bf[0][pl] = bfirst[pl];
-    MI355_UNROLL
-    for (int st = 1; st < AH; ++st) mrfs_rd<G, K>(bf[st], st, lds0, a0, a1, wr, lane, PS16, ring16, d);
-    f32x4 ab = acc, as;
-    MI355_UNROLL
-    for (int r = 0; r < 4; ++r) as[r] = 0.0f;
-    MI355_UNROLL
-    for (int st = 0; st < NSTEP; ++st) {
-        const int g = st / K, s = st % K;
-        if (st + AH < NSTEP) mrfs_rd<G, K>(bf[(st + AH) % RING], st + AH, lds0, a0, a1, wr, lane, PS16, ring16, d);
-        if (st == NSTEP - 1) {  // the next tile's first step
-            const unsigned n0 = rq + 16u * sbn;
-            mrfs_rd<G, K>(bfirst, 0, lds0, n0, n0 - ring16, WAVE_UNIFORM((int)ring - (int)sbn), lane, PS16, ring16, d);
-        }
-        SCHED_FENCE();
-        const int c = st % RING;
-        as = MFMA_16x16x32_BF16(W[g][s][2], bf[c][0], as);  // small terms first
-        ab = MFMA_16x16x32_BF16(W[g][s][1], bf[c][0], ab);
-        as = MFMA_16x16x32_BF16(W[g][s][0], bf[c][2], as);
-        ab = MFMA_16x16x32_BF16(W[g][s][0], bf[c][1], ab);
-        as = MFMA_16x16x32_BF16(W[g][s][1], bf[c][1], as);
-        ab = MFMA_16x16x32_BF16(W[g][s][0], bf[c][0], ab);
-        SCHED_FENCE();
-        if (s == K - 1) {  // the k-group is done: join the chains (k_mrf_p: acc = ab + as after every k-group)
-            MI355_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                ab[r] = ab[r] + as[r];
-                as[r] = 0.0f;
-            }
-        }
-    }
-    acc = ab;
-}
 
 template <int C, int K0, int K1, int K2, typename SH>
 __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
@@ -454,7 +352,7 @@ struct GeoS { int TS, XR, X1R, RR; size_t lds; };
 // ring lengths: multiples of 16 columns (a 16-lane fragment read then touches 16 consecutive 16-byte slots modulo the ring:
 // conflict-free), at least the span between a ring's oldest column still read and its newest column written in an iteration
 inline bool geometry_s(int C, int nrb, const int* k, const int* d1, const int* d2, GeoS* g) {
-    if (!(C == 64 || C == 32)) return false;
+    if (C != 64) return false;  // (the 32-channel stage: kernels_mrfs1.cpp)
     const int TS = 16 * MRFS_NT * (4 / (C / 16));
     int r1m = 0, r2m = 0;
     for (int j = 0; j < nrb; ++j) {
@@ -492,6 +390,7 @@ int mrf_s_segment(int C, int B, int T, int cus) {
     // 2.36 -> 3.1 ms (half the matrix work per tile and per byte of y / x traffic: the three passes' 4 x HBM bytes and the
     // per-tile costs outweigh what the sweep saves there) — the 32-channel stage stays on k_mrf_p
     if (C != 64) return 0;
+    if ((long)C * T * 4 >= 0x7fffffffL) return 0;  // a row's bytes must fit the buffer range (32-bit lane offsets): k_mrf_p otherwise
     const int TS = 16 * MRFS_NT * (4 / (C / 16));
     const int min_blocks = 24;  // fill of <= 5 iterations: <= 20 % even at the shortest segment
     const long total_blocks = (long)B * ((T + TS - 1) / TS);
@@ -539,14 +438,10 @@ void launch_mrf_s(MrfArgs a, hipStream_t s) {
     const int k1 = a.nrb > 1 ? a.k[1] : 0, k2 = a.nrb > 2 ? a.k[2] : 0;
     if (!(a.k[0] == 3 && k1 == 5 && k2 == 7)) throw std::runtime_error("mrf_s: unsupported tap counts");
     const bool low = a.d1[0] == 1 && a.d2[0] == 2 && a.d1[1] == 2 && a.d2[1] == 6 && a.d1[2] == 3 && a.d2[2] == 12;  // the "_low" voices
-    if (a.C == 32) {
-        if (low && g.XR == 224 && g.X1R == 272 && g.RR == 240) { go(k_mrf_s<32, 3, 5, 7, MrfSShape<224, 272, 240, 1, 2, 2, 6, 3, 12>>); return; }
-    } else {
-        if (low && g.XR == 128 && g.X1R == 176 && g.RR == 144) { go(k_mrf_s<64, 3, 5, 7, MrfSShape<128, 176, 144, 1, 2, 2, 6, 3, 12>>); return; }
-    }
+    if (a.C != 64) throw std::runtime_error("mrf_s: 64 channels only (32: launch_mrf_s1)");
+    if (low && g.XR == 128 && g.X1R == 176 && g.RR == 144) { go(k_mrf_s<64, 3, 5, 7, MrfSShape<128, 176, 144, 1, 2, 2, 6, 3, 12>>); return; }
 #ifdef MI355_EMU
-    if (a.C == 32) go(k_mrf_s<32, 3, 5, 7, MrfSDyn>);
-    else go(k_mrf_s<64, 3, 5, 7, MrfSDyn>);
+    go(k_mrf_s<64, 3, 5, 7, MrfSDyn>);
 #else
     throw std::runtime_error("mrf_s: unsupported stage shape");
 #endif

@@ -131,11 +131,13 @@ def test_flow_pointwise_convs_slice_kernel_equals_general(lab_lib, monkeypatch):
         assert rel_rms(res["slice"][2][bi, :n], res["general"][2][bi, :n]) < REL_RMS_TOL
 
 
-def test_mrf_row_sweep_equals_block_kernel_bitwise_on_the_device(lab_lib, monkeypatch):
-    """k_mrf_s (row sweep: segments, one pass per resblock, conv-specialised waves, fragments in registers, LDS rings; the default
-    of the 64-channel stage on large grids) vs k_mrf_p (MI355VITS_MRF_SWEEP_SEG=0) on the MI355X at full-size shapes: both MRF
-    stage taps and the waveform BIT FOR BIT — the launcher may pick either by grid size.  Also with the sweep forced onto the
-    32-channel stage (segments of 1,632 columns: a multiple of both stages' steps), ragged rows ending inside a segment."""
+def test_mrf_row_sweeps_equal_block_kernel_bitwise_on_the_device(lab_lib, monkeypatch):
+    """The row-sweep MRF kernels — k_mrf_s (64 channels: one pass per resblock, conv-specialised waves, fragments in registers, LDS
+    rings) and k_mrf_s1 (32 channels: ONE pass for all three resblocks, waves specialised by row tile x conv x resblock group, the
+    partial sum handed from group to group through LDS; lab build only: it measured equal to k_mrf_p) — vs k_mrf_p
+    (MI355VITS_MRF_SWEEP_SEG=0) on the MI355X at full-size shapes: both MRF stage taps and the waveform BIT FOR BIT, so the launcher
+    may pick by grid size.  The product's default (sweep for the 64-channel stage only), both sweeps at a forced short segment (1,632
+    columns: a multiple of both kernels' steps, several items per CU); ragged rows ending inside a segment, a one-phoneme row."""
     cfg = VitsConfig.apope_low()
     w = W.synthetic_weights(cfg, seed=1234)
     blob = W.pack(cfg, w)
@@ -144,7 +146,7 @@ def test_mrf_row_sweep_equals_block_kernel_bitwise_on_the_device(lab_lib, monkey
     lengths = np.array([Tx, Tx, 97, Tx, 64, Tx, 1, 127])
     forced = np.full((B, Tx), 6, np.int32)
     res = {}
-    for tag, env in (("default", None), ("block", "0"), ("sweep_both", "1632")):
+    for tag, env in (("default", None), ("block", "0"), ("short_segments", "1632")):
         if env is None:
             monkeypatch.delenv("MI355VITS_MRF_SWEEP_SEG", raising=False)
         else:
@@ -153,9 +155,9 @@ def test_mrf_row_sweep_equals_block_kernel_bitwise_on_the_device(lab_lib, monkey
         eng.profile_enable(True)
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
         labels = set(eng.profile_report())
-        assert ("dec.mrf_s.s1" in labels) == (tag != "block") and ("dec.mrf_s.s2" in labels) == (tag == "sweep_both"), (tag, labels)
+        assert ("dec.mrf_s.s1" in labels) == (tag != "block") and ("dec.mrf_s.s2" in labels) == (tag == "short_segments"), (tag, labels)
         res[tag] = eng.tap("dec.mrf.1"), eng.tap("dec.mrf.2"), out["audio"].copy()
         eng.close()
-    for tag in ("default", "sweep_both"):
+    for tag in ("default", "short_segments"):
         for k in range(3):
             assert np.array_equal(res[tag][k], res["block"][k]), (tag, k)
