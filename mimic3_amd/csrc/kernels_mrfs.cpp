@@ -33,6 +33,25 @@
 
 namespace m355 {
 
+// phase clocks of one workgroup's waves 0 (conv1) and 4 (conv2), lab build, MI355VITS_MRF_ABLATE bit 128: shader cycles spent in an
+// iteration's tiles, in its staging store and waiting at its barrier, summed over a sweep
+#if defined(MI355_LAB) && !defined(MI355_EMU)
+#define MRFS_CLK_DECL() long long ck_t = 0, ck_s = 0, ck_b = 0, ck_0 = 0, ck_1 = 0, ck_2 = 0, ck_3 = 0
+#define MRFS_CLK(v) do { if (a.ablate & 128) v = __builtin_readcyclecounter(); } while (0)
+#define MRFS_CLK_ACC() do { ck_t += ck_1 - ck_0; ck_s += ck_2 - ck_1; ck_b += ck_3 - ck_2; } while (0)
+#define MRFS_CLK_PRINT(K, its)                                                                                                     \
+    do {                                                                                                                           \
+        if ((a.ablate & 128) && blockIdx.x == 7 && (threadIdx.x == 0 || threadIdx.x == 256))                                       \
+            printf("mrf_s clocks k=%d role %d: %d iterations, per iteration: tiles %lld staging-store %lld barrier %lld\n", K, role, its, \
+                   ck_t / (its), ck_s / (its), ck_b / (its));                                                                       \
+    } while (0)
+#else
+#define MRFS_CLK_DECL() ((void)0)
+#define MRFS_CLK(v) ((void)0)
+#define MRFS_CLK_ACC() ((void)0)
+#define MRFS_CLK_PRINT(K, its) ((void)0)
+#endif
+
 namespace {
 constexpr size_t MRFS_LDS_LIMIT = 160 * 1024;
 constexpr int MRFS_NT = 3;  // 16-column tiles per wave and iteration
@@ -104,6 +123,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
 #else
             constexpr int AH = G == 1 ? 2 : 1;  // measured: 32 channels 2.61 (2) vs 2.75 (1) / 2.76 (3) ms; 64 channels 1.97 (1) vs 2.32 (2: spills at k = 7)
 #endif
+            constexpr bool DEEP = false;  // residual / y prefetch two blocks ahead instead of one: measured no gain (profiles/r04_mrf_sweep.txt)
             const int d1 = SH::d1(j) ? SH::d1(j) : a.d1[j], d2 = SH::d2(j) ? SH::d2(j) : a.d2[j];
             const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
             const int W1 = (2 * r2 + TS - 1) / TS + 1;  // iterations conv1 runs ahead of conv2
@@ -183,10 +203,13 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                     for (int r = 0; r < 4; ++r) v[r] = buf_load_f32(xbuf, o, (unsigned)r * xrow);
                     SCHED_FENCE();
                 };
-                // residuals in flight: this tile's and the next two (a tile is shorter than a global round trip)
-                float rq[NT][4];
+                // residuals in flight per tile position: this block's (rq) and, DEEP, the next block's (rq2) — loaded one / two blocks ahead
+                float rq[NT][4], rq2[NT][4];
                 MI355_UNROLL
-                for (int i = 0; i < NT; ++i) load_x(q0 + chh * (16 * NT) + 16 * i, rq[i]);
+                for (int i = 0; i < NT; ++i) {
+                    load_x(q0 + chh * (16 * NT) + 16 * i, rq[i]);
+                    if constexpr (DEEP) load_x(q0 + TS + chh * (16 * NT) + 16 * i, rq2[i]);
+                }
                 unsigned xrd = (unsigned)((TS - 2 * r1) % XR);  // x ring slot of column q0 - r1 (block 0, tap 0): (p + 1) TS - 2 r1
                 unsigned x1w = 0, rww = 0;                       // x1 / raw ring slots of column q0 + p TS
                 unsigned xsw = 0;                                // x ring slot of column s0 + u TS (staging)
@@ -194,10 +217,12 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                 // one iteration: staging loads, (ACT: this block's tiles,) staging stores, barrier.  The phases — staging only,
                 // then tiles — are separate loops: a run-time `if (active)` around the tiles would leave the wait-count pass with two
                 // paths of different load counts and it would drain the tiles' prefetches in front of every staging store
+                MRFS_CLK_DECL();
                 auto iter = [&](int it, auto ACT) MI355_INLINE_LAMBDA {
                     const int p = it - 2;
                     float sv[8];
                     stage_load(it, sv);
+                    MRFS_CLK(ck_0);
                     if constexpr (decltype(ACT)::value) {
                         unsigned ringq = XOFF + (unsigned)q * XR16 + n16;  // from the window's base: the plane offsets fit the immediates
                         OPAQUE_V(ringq);
@@ -212,12 +237,14 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                             const int e0 = q0 + p * TS + chh * (16 * NT) + 16 * i;  // absolute column of lane n = 0
                             f32x4 acc;
                             MI355_UNROLL
-                            for (int r = 0; r < 4; ++r) acc[r] = rq[0][r] + bia[r];
-                            MI355_UNROLL
-                            for (int u = 0; u + 1 < NT; ++u)
+                            for (int r = 0; r < 4; ++r) acc[r] = rq[i][r] + bia[r];
+                            if constexpr (DEEP) {
                                 MI355_UNROLL
-                                for (int r = 0; r < 4; ++r) rq[u][r] = rq[u + 1][r];
-                            load_x(e0 + TS, rq[NT - 1]);  // the same tile of the next block: NT tiles ahead
+                                for (int r = 0; r < 4; ++r) rq[i][r] = rq2[i][r];
+                                load_x(e0 + 2 * TS, rq2[i]);  // the same tile two blocks on
+                            } else {
+                                load_x(e0 + TS, rq[i]);  // the same tile of the next block
+                            }
                             const unsigned off = (unsigned)(chh * (16 * NT) + 16 * i);
                             const unsigned sb = mrfs_wrap(xrd + off, (unsigned)XR);
                             const unsigned sbn = i + 1 < NT ? mrfs_wrap(xrd + off + 16u, (unsigned)XR) : sb;  // (the last tile re-reads its own: discarded)
@@ -256,8 +283,12 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                         x1w = mrfs_wrap(x1w + TS, (unsigned)X1R);
                         rww = mrfs_wrap(rww + TS, (unsigned)RR);
                     }
+                    MRFS_CLK(ck_1);
                     stage_store(it, sv, xsw);
+                    MRFS_CLK(ck_2);
                     __syncthreads();
+                    MRFS_CLK(ck_3);
+                    if constexpr (decltype(ACT)::value) MRFS_CLK_ACC();
                 };
                 MI355_NOUNROLL
                 for (int it = 0; it < 2; ++it) iter(it, std::false_type{});
@@ -265,6 +296,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                 for (int it = 2; it < 2 + N1; ++it) iter(it, std::true_type{});
                 MI355_NOUNROLL
                 for (int it = 2 + N1; it < NIT; ++it) iter(it, std::false_type{});
+                MRFS_CLK_PRINT(K, N1);
             } else {
                 // ================================================================== conv2 waves (+ staging of x)
                 auto load_y = [&](int t0, float (&v)[4]) MI355_INLINE_LAMBDA {
@@ -276,21 +308,24 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                     for (int r = 0; r < 4; ++r) v[r] = buf_load_f32(ybuf, o, (unsigned)r * yrow);
                     SCHED_FENCE();
                 };
-                float yq[NT][4];  // y of this tile and the next two (zeros in the first resblock: nothing to read)
+                float yq[NT][4], yq2[NT][4];  // y per tile position, one / two (DEEP) blocks ahead (zeros in the first resblock: nothing to read)
                 MI355_UNROLL
                 for (int i = 0; i < NT; ++i) {
                     MI355_UNROLL
-                    for (int r = 0; r < 4; ++r) yq[i][r] = 0.0f;
+                    for (int r = 0; r < 4; ++r) yq[i][r] = yq2[i][r] = 0.0f;
                     load_y(c0 + chh * (16 * NT) + 16 * i, yq[i]);
+                    if constexpr (DEEP) load_y(c0 + TS + chh * (16 * NT) + 16 * i, yq2[i]);
                 }
                 unsigned x1r = (unsigned)(((W1 - 1) * TS - 2 * r2) % X1R);  // x1 ring slot of column c0 - r2 (block 0, tap 0)
                 unsigned rwr = (unsigned)(((W1 - 1) * TS - r2) % RR);       // raw ring slot of column c0
                 unsigned xsw = 0;                                            // x ring slot of column s0 + u TS
                 uint4 bfirst[3];
+                MRFS_CLK_DECL();
                 auto iter = [&](int it, auto ACT) MI355_INLINE_LAMBDA {
                     const int m = it - 2 - W1;
                     float sv[8];
                     stage_load(it, sv);
+                    MRFS_CLK(ck_0);
                     if constexpr (decltype(ACT)::value) {
                         unsigned ringq = X1OFF + (unsigned)q * X1R16 + n16;
                         OPAQUE_V(ringq);
@@ -307,12 +342,14 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                             const float x1a[4] = {x1n.x, x1n.y, x1n.z, x1n.w};
                             f32x4 acc;
                             MI355_UNROLL
-                            for (int r = 0; r < 4; ++r) acc[r] = (FIRST ? 0.0f : yq[0][r]) + (x1a[r] + bia[r]);  // k_mrf_p: out + (x1 + b2)
-                            MI355_UNROLL
-                            for (int u = 0; u + 1 < NT; ++u)
+                            for (int r = 0; r < 4; ++r) acc[r] = (FIRST ? 0.0f : yq[i][r]) + (x1a[r] + bia[r]);  // k_mrf_p: out + (x1 + b2)
+                            if constexpr (DEEP && !FIRST) {
                                 MI355_UNROLL
-                                for (int r = 0; r < 4; ++r) yq[u][r] = yq[u + 1][r];
-                            load_y(t0 + TS, yq[NT - 1]);  // the same tile of the next block: NT tiles ahead
+                                for (int r = 0; r < 4; ++r) yq[i][r] = yq2[i][r];
+                                load_y(t0 + 2 * TS, yq2[i]);  // the same tile two blocks on
+                            } else {
+                                load_y(t0 + TS, yq[i]);
+                            }
                             // the next tile's residual and first fragments (same block only: the next block's may still be in the making)
                             const unsigned offn = i + 1 < NT ? off + 16u : off;
                             x1n = *reinterpret_cast<const float4*>(rawq + 16u * mrfs_wrap(rwr + offn + (unsigned)n, (unsigned)RR));
@@ -329,13 +366,18 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                         x1r = mrfs_wrap(x1r + TS, (unsigned)X1R);
                         rwr = mrfs_wrap(rwr + TS, (unsigned)RR);
                     }
+                    MRFS_CLK(ck_1);
                     stage_store(it, sv, xsw);
+                    MRFS_CLK(ck_2);
                     __syncthreads();
+                    MRFS_CLK(ck_3);
+                    if constexpr (decltype(ACT)::value) MRFS_CLK_ACC();
                 };
                 MI355_NOUNROLL
                 for (int it = 0; it < 2 + W1; ++it) iter(it, std::false_type{});
                 MI355_NOUNROLL
                 for (int it = 2 + W1; it < NIT; ++it) iter(it, std::true_type{});
+                MRFS_CLK_PRINT(K, N);
             }
         };
 
