@@ -140,12 +140,13 @@ def traffic_from_text(txt_path, out_path, B=32, Tx=128, fpi=6):
 def derived(txt_path, min_us=20.0):
     """Per-kernel ratios from a `pmc` text summary: mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024
     SIMDs); wait_any / wait_inst / active / valu = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, SQ_ACTIVE_INST_VALU over
-    SQ_WAVE_CYCLES; valu/mfma = SQ_INSTS_VALU / SQ_INSTS_MFMA; lds_confl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;
+    SQ_WAVE_CYCLES; valu/mfma = SQ_INSTS_VALU / SQ_INSTS_MFMA (SQ_INSTS_VALU counts the MFMAs too: `other/mfma` = the same minus one =
+    plain vector instructions per MFMA); mfma_x = SQ_INSTS_MFMA as issued (compare with the algorithmic count); lds_confl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;
     read_MiB = 2 x FETCH_SIZE KiB / 1024 (gfx950: 64 B tallied per 128-B request), write_MiB = WRITE_SIZE KiB / 1024, per launch."""
     import re
 
     print(f"{'kernel':74s} {'calls':>6s} {'avg_us':>9s} {'mfma_busy':>9s} {'wait_any':>8s} {'wait_inst':>9s} {'active':>7s} {'valu':>6s} "
-          f"{'valu/mfma':>9s} {'lds_confl':>9s} {'read_MiB':>9s} {'write_MiB':>9s}")
+          f"{'valu/mfma':>9s} {'other/mfma':>10s} {'insts_mfma':>11s} {'lds_confl':>9s} {'read_MiB':>9s} {'write_MiB':>9s}")
     for line in open(txt_path):
         m = re.match(r"(.{80})\s+(\d+)\s+([0-9.]+)\s+(.*)", line)
         if not m or "=" not in m.group(4):
@@ -159,7 +160,8 @@ def derived(txt_path, min_us=20.0):
         ratio = lambda a, b: a / b if b and b == b else float("nan")
         print(f"{m.group(1)[:74]:74s} {int(m.group(2)):6d} {avg:9.1f} {ratio(g('SQ_VALU_MFMA_BUSY_CYCLES'), g('GRBM_GUI_ACTIVE') / 8 * 1024):9.3f} "
               f"{ratio(g('SQ_WAIT_ANY'), wc):8.3f} {ratio(g('SQ_WAIT_INST_ANY'), wc):9.3f} {ratio(g('SQ_ACTIVE_INST_ANY'), wc):7.3f} "
-              f"{ratio(g('SQ_ACTIVE_INST_VALU'), wc):6.3f} {ratio(g('SQ_INSTS_VALU'), g('SQ_INSTS_MFMA')):9.1f} "
+              f"{ratio(g('SQ_ACTIVE_INST_VALU'), wc):6.3f} {ratio(g('SQ_INSTS_VALU'), g('SQ_INSTS_MFMA')):9.1f} {ratio(g('SQ_INSTS_VALU'), g('SQ_INSTS_MFMA')) - 1.0:10.2f} "
+              f"{g('SQ_INSTS_MFMA'):11.4g} "
               f"{ratio(g('SQ_LDS_BANK_CONFLICT'), g('SQ_LDS_IDX_ACTIVE')):9.3f} {2 * g('FETCH_SIZE') / 1024:9.1f} {g('WRITE_SIZE') / 1024:9.1f}")
 
 
