@@ -55,6 +55,7 @@ namespace m355 {
 namespace {
 constexpr size_t MRFS_LDS_LIMIT = 160 * 1024;
 constexpr int MRFS_NT = 3;  // 16-column tiles per wave and iteration
+constexpr int MRFS_CONV2_PRIO = 0;
 }  // namespace
 
 // compile-time ring lengths (columns) and dilations of the "_low" voices' stages, or MrfSDyn = take them from the arguments
@@ -95,6 +96,16 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
 
     for (int i = tid; i < a.nrb * 2 * C; i += 512) BS[i] = a.bias[i / (2 * C)][(i / C) & 1][i % C];
     __syncthreads();
+#if !defined(MI355_EMU)
+    // The SIMD's arbiter favours its older wave: waves 0 - 3 (conv1) ran their tiles 15 - 20 % faster than their SIMD partners
+    // 4 - 7 (conv2) and then sat at the barrier while the partner finished alone (phase clocks, profiles/r04_mrf_sweep.txt; with the
+    // roles swapped the slow side swapped too).  A higher user priority for the younger waves evens the two out.
+    if (role == 1) {
+        if (a.vec == 1) __builtin_amdgcn_s_setprio(1);
+        else if (a.vec == 2) __builtin_amdgcn_s_setprio(2);
+        else if (a.vec == 3) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
 
     const int nseg = (a.T + a.seg - 1) / a.seg;
     const int nitems = nseg * a.B;
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
             } else {
                 // ================================================================== conv2 waves (+ staging of x)
                 auto load_y = [&](int t0, float (&v)[4]) MI355_INLINE_LAMBDA {
-                    if (FIRST) return;
+                    if (FIRST || (LAB_ABLATE(a) & 16)) return;
                     const int t = t0 + n;
                     const int tc = t < a.T ? t : a.T - 1;
                     const unsigned o = 4u * (unsigned)(co0 * a.y_ld + tc);
@@ -464,6 +475,8 @@ void launch_mrf_s(MrfArgs a, hipStream_t s) {
     a.ldx = g.XR;
     a.ld1 = g.X1R;
     a.R = g.RR;
+    a.vec = MRFS_CONV2_PRIO;  // s_setprio of the conv2 waves (see the kernel)
+    if (const char* pr = lab_getenv("MI355VITS_MRF_PRIO")) a.vec = atoi(pr);
     const long nitems = (long)((a.T + a.seg - 1) / a.seg) * a.B;
     const int cus = current_device_cu_count();
     dim3 grid((unsigned)(nitems < cus ? nitems : cus));  // persistent: one workgroup per CU

@@ -55,6 +55,18 @@ __device__ __forceinline__ void mrfs_rd(uint4 (&f)[3], int st, const char* __res
     for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const uint4*>(p + (unsigned)pl * PS16);
 }
 
+// the same with the step's lane mask given (mrfs_tile builds a tile's K masks in one batch ahead of its steps: five dependent
+// scalar instructions per mask would otherwise sit in front of every step's fragment reads in the wave's in-order stream)
+template <int G, int K>
+__device__ __forceinline__ void mrfs_rd_m(uint4 (&f)[3], int st, const char* __restrict__ lds0, unsigned a0, unsigned a1, unsigned long long mask, int lane,
+                                          unsigned PS16, unsigned ring16, int d) {
+    const int g = st / K, s = st % K;
+    const unsigned a = mrfs_sel(a0, a1, mask, lane);
+    const char* p = lds0 + a + ((unsigned)g * 4u * ring16 + 16u * (unsigned)(s * d));
+    MI355_UNROLL
+    for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const uint4*>(p + (unsigned)pl * PS16);
+}
+
 // One 16-column tile of one conv for this wave's 16 output rows: acc (+)= sum over the C / 32 k-groups and K taps, in
 // k_mrf_p's order: per k-group two accumulator chains (small terms -> as, large terms -> ab), joined (ab + as) after the
 // group's last tap.  W: this wave's fragments [k-group][tap][plane].  rq: this lane's byte offset of (plane 0, k-group 0, its
@@ -69,18 +81,21 @@ __device__ __forceinline__ void mrfs_tile(f32x4& acc, const uint4 (&W)[G][K][3],
     const unsigned ring16 = 16u * ring;
     const unsigned a0 = rq + 16u * sb, a1 = a0 - ring16;
     const int wr = WAVE_UNIFORM((int)ring - (int)sb);
+    unsigned long long masks[K];
+    MI355_UNROLL
+    for (int s = 0; s < K; ++s) masks[s] = mrfs_lane_mask(wr - s * d);
     uint4 bf[RING][3];
     MI355_UNROLL
     for (int pl = 0; pl < 3; ++pl) bf[0][pl] = bfirst[pl];
     MI355_UNROLL
-    for (int st = 1; st < AH; ++st) mrfs_rd<G, K>(bf[st], st, lds0, a0, a1, wr, lane, PS16, ring16, d);
+    for (int st = 1; st < AH; ++st) mrfs_rd_m<G, K>(bf[st], st, lds0, a0, a1, masks[st % K], lane, PS16, ring16, d);
     f32x4 ab = acc, as;
     MI355_UNROLL
     for (int r = 0; r < 4; ++r) as[r] = 0.0f;
     MI355_UNROLL
     for (int st = 0; st < NSTEP; ++st) {
         const int g = st / K, s = st % K;
-        if (st + AH < NSTEP) mrfs_rd<G, K>(bf[(st + AH) % RING], st + AH, lds0, a0, a1, wr, lane, PS16, ring16, d);
+        if (st + AH < NSTEP) mrfs_rd_m<G, K>(bf[(st + AH) % RING], st + AH, lds0, a0, a1, masks[(st + AH) % K], lane, PS16, ring16, d);
         if (st == NSTEP - 1) {  // the next tile's first step
             const unsigned n0 = rq + 16u * sbn;
             mrfs_rd<G, K>(bfirst, 0, lds0, n0, n0 - ring16, WAVE_UNIFORM((int)ring - (int)sbn), lane, PS16, ring16, d);
