@@ -129,11 +129,10 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
             constexpr int K = decltype(KC)::value, j = decltype(JC)::value;
             constexpr bool FIRST = decltype(FIRSTC)::value, LAST = decltype(LASTC)::value;
             // B fragments ahead of their MFMAs (MRFS_AH overrides for experiments)
-#ifdef MRFS_AH
-            constexpr int AH = MRFS_AH;
-#else
-            constexpr int AH = G == 1 ? 2 : 1;  // measured: 32 channels 2.61 (2) vs 2.75 (1) / 2.76 (3) ms; 64 channels 1.97 (1) vs 2.32 (2: spills at k = 7)
+#ifndef MRFS_AH_SMALL
+#define MRFS_AH_SMALL 1
 #endif
+            constexpr int AH = G == 1 ? 2 : (G * K * 12 <= 120 ? MRFS_AH_SMALL : 1);  // (k = 7 at 64 channels: no registers beyond one step ahead)
             constexpr bool DEEP = false;  // residual / y prefetch two blocks ahead instead of one: measured no gain (profiles/r04_mrf_sweep.txt)
             const int d1 = SH::d1(j) ? SH::d1(j) : a.d1[j], d2 = SH::d2(j) ? SH::d2(j) : a.d2[j];
             const int r1 = (K - 1) / 2 * d1, r2 = (K - 1) / 2 * d2;
