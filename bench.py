@@ -31,7 +31,8 @@ The JSON line also carries
                    120 sentences through mimic3_amd.streaming on one session, default math and bf16 weights), the f32-MFMA /
                    bf16-weights / f16x2 math modes; they run after the headline's handles are closed (open idle handles alias
                    HIP streams onto shared hardware queues: tools/floor_diag2.py).
-  "device"       — shader / memory / fabric clocks, socket power and cap, partition modes of the HIP device from sysfs, sampled
+  "device"       — (after an untimed pre-heat of the same steps until the shader clock is steady: "device.preheat")
+                   shader / memory / fabric clocks, socket power and cap, partition modes of the HIP device from sysfs, sampled
                    every 10 ms over the timed loop and over the per-kernel table; one-line summaries of it, of the batch-1
                    latency, the batch-256 leg and the streaming leg sit in "config" (the driver's record keeps that object).
 """
@@ -420,6 +421,30 @@ def main():
     dev_before = mon.snapshot()
     # in single-process mode K "steps" = K batches per device = K * n_gpus engine calls
     calls = args.steps * (n_gpus if single else 1)
+    # pre-heat: a device that idled through model load starts at its idle clock state and takes a few hundred ms of load to
+    # reach the loaded one; W = 5 warm-up steps are 50 ms.  The same steps, untimed, until the shader clock has been steady
+    # for 0.2 s (or 1.5 s at most; 0.5 s when the clock cannot be read) — recorded in "device.preheat", never part of `value`
+    preheat = {"seconds": 0.0, "steps": 0}
+    t_ph = time.perf_counter()
+    hist = []
+    while True:
+        wl.run_steps(max(1, args.streams) * (n_gpus if single else 1))
+        preheat["steps"] += max(1, args.streams)
+        el_ph = time.perf_counter() - t_ph
+        clk = mon.snapshot().get("sclk_mhz") if mon.dir else None
+        hist.append((el_ph, clk))
+        if clk is None:
+            if el_ph >= 0.5:
+                break
+            continue
+        recent = [c for t, c in hist if t >= el_ph - 0.2 and c]
+        if el_ph >= 0.3 and recent and min(recent) >= 0.97 * max(c for _, c in hist if c):
+            break
+        if el_ph >= 1.5:
+            break
+    preheat["seconds"] = time.perf_counter() - t_ph
+    preheat["sclk_mhz_first_last"] = [hist[0][1], hist[-1][1]]
+    barrier()
     mon.start()  # (sampling starts with the warm-up steps; it reads two sysfs files every 10 ms)
     elapsed, out = timed(wl, calls, args.warmup * (n_gpus if single else 1))
     dev_window = mon.stop()
@@ -459,7 +484,7 @@ def main():
         "rtf": elapsed / args.steps / (samples_per_step / SAMPLE_RATE),
         "x_realtime": (samples_per_step / SAMPLE_RATE) / (elapsed / args.steps),
         "timed_region_s": elapsed,
-        "device": {"before": dev_before, "timed_window": dev_window},
+        "device": {"before": dev_before, "preheat": preheat, "timed_window": dev_window},
     }
     result["config"]["device"] = DeviceMonitor.brief(dev_before, dev_window)
 
