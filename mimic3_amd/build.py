@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
-SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_mrfs1.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
+SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_mrfs1.cpp", "kernels_rbc.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
 PER_FILE_FLAGS = {}
 LAB_FILE_FLAGS = {}  # per-file flags of the lab build's side of a running A/B (none at the moment)
 # sources the lab build compiles exactly as the product does (no -DMI355_LAB): k_mrf_p's in-loop ablation tests cost 15 % of its

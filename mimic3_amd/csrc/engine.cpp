@@ -363,6 +363,7 @@ Engine::Engine(const Engine& lane0) : cfg_(lane0.cfg_), device_(lane0.device_) {
         b3_min_work_ = lane0.b3_min_work_;
         wn_b3_ = lane0.wn_b3_;
         no_mrf_p_ = lane0.no_mrf_p_;
+        no_rbc_ = lane0.no_rbc_;
         no_fused_dds_ = lane0.no_fused_dds_;
         no_dds_stack_ = lane0.no_dds_stack_;
         no_dds_stack_b3_ = lane0.no_dds_stack_b3_;
@@ -397,6 +398,7 @@ void Engine::open_device(int device) {
     b3_min_work_ = bw ? atoi(bw) : 256;
     wn_b3_ = lab_getenv("MI355VITS_WN_B3") != nullptr;
     no_mrf_p_ = lab_getenv("MI355VITS_NO_MRF_P") != nullptr;
+    no_rbc_ = lab_getenv("MI355VITS_NO_RBC") != nullptr;
     no_fused_dds_ = lab_getenv("MI355VITS_NO_FUSED_DDS") != nullptr;
     no_dds_stack_ = lab_getenv("MI355VITS_NO_DDS_STACK") != nullptr;
     no_dds_stack_b3_ = lab_getenv("MI355VITS_NO_DDS_STACK_B3") != nullptr;
@@ -611,6 +613,11 @@ bool Engine::enc_gemm(const ConvW& w, const ConvArgs& a) const {
            a.ksplit == enc_conv_b3_slices(w.Cin) && (a.ksplit == 1 || a.part);  // a split conv only where the caller adds up the slices
 }
 
+// a filled-in conv of the decoder that k_rb_conv takes (MATH_BF16X3 only: the other modes keep their kernels)
+bool Engine::rbc_ok(const ConvW& w, const ConvArgs& a) const {
+    return phase_b_ && !force_generic_ && !no_rbc_ && math_ == MATH_BF16X3 && w.packed_p != NO_OFF && rb_conv_supported(a);
+}
+
 void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     // frames-sized tensors: the kernel is a function of the layer, not of the batch's padding.  Phoneme-sized ones (the text
     // encoder) stay on the f32 kernels except the wide FFN conv (192 -> 768, k3: K Cin >= 512 and >= 4 row blocks), whose
@@ -630,6 +637,12 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     if (a.epi == EPI_RESSKIP) ch_io += w.Cout;  // h and skip are read-modify-write
     const double bytes = 4.0 * a.B * (double)a.T * ch_io + 4.0 * (double)w.Cout * w.Cin * w.K;
     ProfScope ps(prof_, label, flops, bytes);
+    if (rbc_ok(w, a)) {  // 128-channel resblock convs: every input channel resident, one launch per conv (k_rb_conv)
+        a.w = P(w.packed_p);
+        a.math = MATH_BF16X3;
+        launch_rb_conv(a, stream_);
+        return;
+    }
     if (enc_gemm(w, a)) {  // phoneme-sized dense convs: one 192-channel slice per workgroup, staged once (k_enc_b3)
         a.wb3 = P(w.packed_b3s);
         a.math = pmath();
@@ -1191,8 +1204,18 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     }
                     n_fused = nk;
                 }
+                // 128 channels in MATH_BF16X3: conv by conv on k_rb_conv (every input channel resident in LDS, kernels_rbc.cpp)
+                bool rbc_stage = !n_fused && math_ == MATH_BF16X3 && !no_rbc_;
+                for (int j = 0; j < nk && rbc_stage; ++j)
+                    for (int q = 0; q < 2; ++q) {
+                        const ConvW& w = cw(S("dec.rb.%d.c.%d", i * nk + j, q));
+                        ConvArgs probe;
+                        probe.Cin = w.Cin; probe.Cout = w.Cout; probe.K = w.K; probe.dil = q == 0 ? m.d1[j] : m.d2[j];
+                        probe.pad = (w.K - 1) / 2 * probe.dil; probe.res = d_bufA_; probe.in_len = slen; probe.T = (int)T;
+                        rbc_stage = rbc_stage && rbc_ok(w, probe);
+                    }
                 // the longest prefix of resblocks whose tiles fit LDS together (128 channels: only the narrow ones)
-                int p = n_fused ? 0 : nk;
+                int p = (n_fused || rbc_stage) ? 0 : nk;
                 while (p > 0 && !(mrf_fused_supported(ch, p, m.k, m.d1, m.d2) && cw(S("dec.rb.%d.c.%d", i * nk, 0)).packed4 != NO_OFF)) --p;
                 if (p > 0) {
                     double flops = 0;

@@ -155,6 +155,7 @@ class Engine {
 
     // launch helpers
     void conv(const char* label, const ConvW& w, ConvArgs a);
+    bool rbc_ok(const ConvW& w, const ConvArgs& a) const;    // this conv runs on k_rb_conv (128-channel resblock conv, MATH_BF16X3)
     bool enc_gemm(const ConvW& w, const ConvArgs& a) const;  // this conv runs on k_enc_b3 (phoneme-sized, split-bf16)
     void tap(const char* name, const float* dev, std::initializer_list<int64_t> dims);
     void text_encoder(int B, int Tx);
@@ -186,6 +187,7 @@ class Engine {
     int pmath() const { return phase_b_ ? kmath() : tmath(); }  // math of the launch helpers shared by both phases
     bool no_f16x2_convs_ = false;  // MI355VITS_F16X2_NO_CONVS=1: in MATH_F16X2 keep the staged convs / upsamplers on bf16x3
     bool enc_b3_ = true;           // the encoder's wide FFN conv on the split-bf16 staged kernel (MI355VITS_NO_ENC_B3=1: f32 kernel)
+    bool no_rbc_ = false;        // MI355VITS_NO_RBC=1: the 128-channel stage on k_mrf_fused + the staged conv (A/B against k_rb_conv)
     bool no_mrf_p_ = false;      // MI355VITS_NO_MRF_P=1: keep the on-the-fly split MRF kernel (A/B against k_mrf_p)
     bool wn_b3_ = false;         // MATH_BF16X3: WaveNet layers as two staged split-bf16 convs instead of the fused f32 layer
     int math_ = MATH_BF16X3;     // which matrix-core path the dense convs take (include/mi355vits.h: MI355VITS_MATH_*)

@@ -39,6 +39,9 @@ constexpr unsigned BUF_OOB = 0x80000000u;  // a lane offset past the buffer's ra
 static inline void buf_store_f32(const BufRsrc& r, unsigned voff, unsigned soff, float v) {
     if (voff < BUF_OOB) *reinterpret_cast<float*>(r.p + voff + soff) = v;
 }
+static inline uint4 buf_load_u4(const BufRsrc& r, unsigned voff, unsigned soff) {  // 16 bytes (weight fragments)
+    return *reinterpret_cast<const uint4*>(r.p + voff + soff);
+}
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -104,6 +107,12 @@ __device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned voff, unsigned
 constexpr unsigned BUF_OOB = 0x80000000u;
 __device__ __forceinline__ void buf_store_f32(BufRsrc r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+// buffer_load_dwordx4: a 16-byte fragment per lane, the fragment's offset in an SGPR (streamed weight fragments: no address VALU)
+__device__ __forceinline__ uint4 buf_load_u4(BufRsrc r, unsigned voff, unsigned soff) {
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 // register budget: ask the compiler to keep the kernel within 512 / n registers per lane
 #define MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))

@@ -151,6 +151,10 @@ void launch_mrf_s(MrfArgs a, hipStream_t s);
 bool mrf_s1_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 int mrf_s1_segment(int B, int T, int cus);
 void launch_mrf_s1(MrfArgs a, hipStream_t s);
+// One dense conv of a 128-channel ResBlock2 (HiFi-GAN stage 0) in MATH_BF16X3 with all input channels resident in LDS (kernels_rbc.cpp):
+// y (+)= (res + bias + conv(lrelu(x * mask))) * out_scale; a.w = pack_conv_weights_p16 fragments; K / dilation pairs of the "_low" voices.
+bool rb_conv_supported(const ConvArgs& a);
+void launch_rb_conv(ConvArgs a, hipStream_t s);
 int current_device_cu_count();  // compute units of the current device (persistent grids), looked up once per device
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, current device)
 void set_max_dynamic_lds(const void* fn, int bytes);

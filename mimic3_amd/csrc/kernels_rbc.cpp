@@ -1,0 +1,354 @@
+// kernels_rbc.cpp — one dense Conv1d of a 128-channel ResBlock2 (stage 0 of the HiFi-GAN decoder) in MATH_BF16X3:
+//
+//      y[b, co, t] (+)= (res[b, co, t] + bias[co] + sum_ci sum_k W[co, ci, k] * lrelu(x[b, ci, t - pad + k dil] * mask)) * out_scale
+//
+// Why this stage has its own kernel.  At 128 channels neither MRF kernel's idea fits: a conv's weight fragments are 96 KiB per tap
+// (k_mrf_p / k_mrf_s keep them in registers: 688 KiB at seven taps against a 512 KiB register file), and a resblock's two
+// activation tiles with their halos (k = 7, dilations 3 and 12: 72 + 90 columns) leave no room in LDS for output columns.  So
+// the stage runs conv by conv, as it always did — but the staged split kernel it ran on (k_conv1d_b3: 32-channel chunks, stage /
+// barrier / compute / barrier per chunk, 0.34 of the matrix-core roof) pays two barriers and one exposed staging round trip per
+// 32 input channels.  Here a work item is (row, 128 output columns) with ALL 128 input channels resident:
+//
+//   * LDS holds the item's input as three bf16 planes (x = h + m + l exactly, hipx.h) of lrelu(x), zero outside the row:
+//     [plane][16 records of 8 channels][N + halo columns] x 16 B = 768 B per column, at most 208 columns = 156 KiB;
+//   * eight waves = the eight 16-row tiles of output channels; a wave walks k-groups x taps ("steps") and, per step, its eight
+//     16-column tiles: one weight fragment (3 x 16 B per lane, streamed from L2 four steps ahead, buffer addressing) feeds
+//     48 v_mfma_f32_16x16x32_bf16, the activation fragments come from LDS one tile pair ahead (conflict-free ds_read_b128);
+//   * the planes are TWO half-buffers (k-groups 0, 1 | 2, 3).  While the matrix cores work through one half, the other half is
+//     refilled: phase 0 (k-groups 0, 1) stages the item's own k-groups 2, 3, phase 1 stages k-groups 0, 1 of the workgroup's NEXT
+//     item — loads issued one round (eight per thread) per step at the top of the phase, leaky-relu + split + LDS stores dealt
+//     out between the MFMAs of later steps (sched_group_barrier).  No staging phase with idle matrix cores, two barriers per item;
+//   * the residual of a tile is prefetched during phase 1; the epilogue is bias + residual + scale (+ old y) and 64-byte row
+//     stores (lanes past the tensor switched off by the buffer range check: no branch between a load's issue and its use,
+//     kernels_mrfs.cpp).
+// The sum order of an output element — k-group, tap, six products small terms first — does not depend on the item width, so the
+// 32-column form used for small grids (one utterance) gives the same bits as the 128-column form.
+// Weights: pack_conv_weights_p16 fragments (the k_mrf_p order: [row tile][tap][k-group][plane][lane]).
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace m355 {
+
+namespace {
+constexpr size_t RBC_LDS_LIMIT = 160 * 1024;
+constexpr int RBC_C = 128, RBC_G = RBC_C / 32, RBC_REC = RBC_C / 8;
+constexpr int RBC_WR = 4;  // weight-fragment ring: the running step and three ahead (the step count is a multiple of 4)
+}  // namespace
+
+template <int K, int DIL, int NCT>
+struct RbcGeo {
+    static constexpr int N = 16 * NCT, PAD = (K - 1) / 2 * DIL, LD = N + 2 * PAD, LDP = (LD + 15) & ~15;
+    static constexpr unsigned REC16 = 16u * LDP, PS16 = RBC_REC * REC16;  // bytes per record row / per plane
+    static constexpr int HALF = (RBC_REC / 2) * LD;                        // (record, column) pairs of one half-buffer
+    static constexpr int ROUNDS = (HALF + 511) / 512;                      // eight-load rounds per thread and half
+    static constexpr size_t LDS = 3 * (size_t)PS16;
+};
+
+template <int K, int DIL, int NCT>
+__global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
+    using GE = RbcGeo<K, DIL, NCT>;
+    constexpr int G = RBC_G, N = GE::N, PAD = GE::PAD, LD = GE::LD, LDP = GE::LDP, S = G * K, SH = S / 2;
+    constexpr int ROUNDS = GE::ROUNDS, HALF = GE::HALF, NP = NCT / 2, WR = RBC_WR;
+    constexpr unsigned REC16 = GE::REC16, PS16 = GE::PS16;
+    constexpr int SD = (SH - ROUNDS) < 4 ? (SH - ROUNDS) : 4;  // steps between a staging round's loads and its stores
+    static_assert(NCT % 2 == 0 && S % WR == 0 && SD >= 2 && GE::LDS <= RBC_LDS_LIMIT, "shape");
+    DYN_SMEM(float, smem);
+    char* L0 = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, mt = WAVE_UNIFORM(tid >> 6);
+    const int q = lane >> 4, n = lane & 15;
+    const int co0 = 32 * (mt >> 1) + 8 * q + 4 * (mt & 1);  // this lane's four output channels (pack_conv_weights_p16's row order)
+    const BufRsrc wbuf = buf_rsrc(a.w);
+    const unsigned wl = 16u * (unsigned)lane;
+    const unsigned wmt = (unsigned)mt * (unsigned)(K * G * 3 * 64 * 16);
+    // (plane p, record q, column n): one base register per plane, so that every fragment read is base + a 16-bit immediate
+    unsigned lq[3];
+    MI355_UNROLL
+    for (int p = 0; p < 3; ++p) {
+        lq[p] = (unsigned)p * PS16 + (unsigned)(q * LDP + n) * 16u;
+        OPAQUE_V(lq[p]);
+    }
+    float bia[4];
+    MI355_UNROLL
+    for (int r = 0; r < 4; ++r) bia[r] = a.bias ? a.bias[co0 + r] : 0.0f;
+    const int nblk = (a.T + N - 1) / N;
+    const int nitems = nblk * a.B;
+    const unsigned xrow = 4u * (unsigned)a.x_ld, yrow = 4u * (unsigned)a.y_ld, rrow = 4u * (unsigned)a.res_ld;
+
+    struct Item { int b, t0, len, last; };
+    // a row's length through the scalar cache (s_load_dword: the constant address space tells hipcc that the table is read-only;
+    // as a plain global load it costs the item loop a vmcnt(0) — every prefetch drained — and one exposed round trip per item)
+    auto row_len = [&](int b) MI355_INLINE_LAMBDA {
+#ifdef MI355_EMU
+        return a.in_len[b];
+#else
+        typedef const int __attribute__((address_space(4))) * cptr_t;
+        return ((cptr_t)(a.in_len))[b];
+#endif
+    };
+    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+        Item o;
+        o.b = WAVE_UNIFORM(it / nblk);
+        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
+        int len = row_len(o.b);
+        if (len > a.T) len = a.T;
+        o.len = len;
+        o.last = o.len > 0 ? o.len - 1 : 0;
+        return o;
+    };
+
+    // ---- staging of one half-buffer (records 8 half .. 8 half + 7) of an item, round by round: a thread takes (record, column)
+    // pairs tid + 512 round (past the end: the last pair again — same bytes to the same slot, no branch): eight 4-byte loads = the
+    // record's eight channels at that column (256 contiguous bytes per wave and row), clamped into the row and masked afterwards
+    auto stage_load = [&](const Item& im, const BufRsrc& xb, int half, int round, float (&sv)[8]) MI355_INLINE_LAMBDA {
+        int t2 = tid;
+        OPAQUE_V(t2);  // everything derived from it is recomputed per round (hoisted, the offsets of all rounds occupy registers)
+        int idx = t2 + 512 * round;
+        if (512 * (round + 1) > HALF) idx = idx < HALF ? idx : HALF - 1;
+        const int rec = idx / LD, col = idx - rec * LD;
+        const int t = im.t0 - PAD + col;
+        const int tc = t < 0 ? 0 : (t > im.last ? im.last : t);
+        const unsigned o = 4u * (unsigned)(8 * (8 * half + rec) * a.x_ld + tc);
+        MI355_UNROLL
+        for (int e = 0; e < 8; ++e) sv[e] = buf_load_f32(xb, o, (unsigned)e * xrow);
+    };
+    // one quarter of a round's leaky-relu + split (pieces 0 .. 3 = channel pairs), the three 16-byte stores behind the last piece
+    struct StagePos { unsigned addr; bool in; };
+    auto stage_pos = [&](const Item& im, int half, int round) MI355_INLINE_LAMBDA {  // where a round's record goes, and whether it is inside the row
+        int t2 = tid;
+        OPAQUE_V(t2);
+        int idx = t2 + 512 * round;
+        if (512 * (round + 1) > HALF) idx = idx < HALF ? idx : HALF - 1;
+        const int rec = idx / LD, col = idx - rec * LD;
+        const int t = im.t0 - PAD + col;
+        StagePos sp;
+        sp.in = t >= 0 && t < im.len;
+        sp.addr = (unsigned)(8 * half + rec) * REC16 + 16u * (unsigned)col;
+        return sp;
+    };
+    auto stage_piece = [&](int piece, const float (&sv)[8], uint4 (&ph)[3], const StagePos& sp) MI355_INLINE_LAMBDA {
+        const float v0 = sp.in ? lrelu_f(sv[2 * piece], a.in_slope) : 0.0f, v1 = sp.in ? lrelu_f(sv[2 * piece + 1], a.in_slope) : 0.0f;
+        unsigned h, m, l;
+        split3_sc(v0, v1, h, m, l);
+        if (piece == 0) { ph[0].x = h; ph[1].x = m; ph[2].x = l; }
+        if (piece == 1) { ph[0].y = h; ph[1].y = m; ph[2].y = l; }
+        if (piece == 2) { ph[0].z = h; ph[1].z = m; ph[2].z = l; }
+        if (piece == 3) {
+            ph[0].w = h; ph[1].w = m; ph[2].w = l;
+            char* px = L0 + sp.addr;
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(px + (unsigned)p * PS16) = ph[p];
+        }
+    };
+    auto w_load = [&](int s, uint4 (&w)[3]) MI355_INLINE_LAMBDA {  // fragments of step s = (k-group s / K, tap s % K)
+        const int g = s / K, k = s % K;
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) w[p] = buf_load_u4(wbuf, wl, wmt + (unsigned)(((k * G + g) * 3 + p) * 64 * 16));
+    };
+    auto b_read = [&](int s, int j, uint4 (&bf)[3]) MI355_INLINE_LAMBDA {  // activation fragments of tile j at step s
+        const int g = s / K, k = s % K;
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p)
+            bf[p] = *reinterpret_cast<const uint4*>(L0 + lq[p] + (unsigned)((4 * g) * LDP + 16 * j + k * DIL) * 16u);
+    };
+
+    if ((int)blockIdx.x >= nitems) return;
+    // ---- prologue: half 0 of the first item, the first steps' weight fragments
+    {
+        const Item im = decode(blockIdx.x);
+        const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
+        float sv[ROUNDS][8];
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) stage_load(im, xb, 0, r, sv[r]);
+        SCHED_FENCE();
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) {
+            uint4 ph[3];
+            const StagePos sp = stage_pos(im, 0, r);
+            MI355_UNROLL
+            for (int pc = 0; pc < 4; ++pc) stage_piece(pc, sv[r], ph, sp);
+        }
+    }
+    uint4 Wr[WR][3];
+    MI355_UNROLL
+    for (int s = 0; s < WR - 1; ++s) w_load(s, Wr[s]);
+    __syncthreads();
+
+    MI355_NOUNROLL
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const Item im = decode(it);
+        const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;  // (no next item: this one's half 0 again, unread)
+        const Item imn = decode(itn);
+        const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs), xbn = buf_rsrc(a.x + (long)imn.b * a.x_bs);
+        const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
+        const BufRsrc rbuf = buf_rsrc(a.res + (long)im.b * a.res_bs);
+        f32x4 acc[NCT];
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) acc[j][r] = 0.0f;
+        float rq[NCT][4];  // residuals (phase 1)
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) rq[j][r] = 0.0f;
+        auto load_res = [&](int j) MI355_INLINE_LAMBDA {
+            const int t = im.t0 + 16 * j + n;
+            const int tc = t < a.T ? t : a.T - 1;
+            const unsigned o = 4u * (unsigned)(co0 * a.res_ld + tc);
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) rq[j][r] = buf_load_f32(rbuf, o, (unsigned)r * rrow);
+        };
+
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            // this phase computes on half h and refills half 1 - h: the item's own second half, or the next item's first
+            const Item& ims = h == 0 ? im : imn;
+            const BufRsrc& xbs = h == 0 ? xb : xbn;
+            const int hs = 1 - h;
+            float sv[ROUNDS][8];
+            uint4 ph[3];
+            uint4 Bf[2][2][3];
+            b_read(h * SH, 0, Bf[0][0]);
+            b_read(h * SH, 1, Bf[0][1]);
+            MI355_UNROLL
+            for (int sl = 0; sl < SH; ++sl) {
+                const int s = h * SH + sl;
+                // (1) this step's loads: the weight fragments three steps on, one staging round, (phase 1) residual tiles
+                w_load((s + WR - 1) % S, Wr[(s + WR - 1) % WR]);
+                if (sl < ROUNDS) stage_load(ims, xbs, hs, sl, sv[sl]);
+                if (h == 1) {
+                    MI355_UNROLL
+                    for (int j = 0; j < NCT; ++j)
+                        if (j * (SH - 1) / NCT == sl) load_res(j);
+                }
+                const int sr = sl - SD;  // round stored in this step
+                StagePos sp = {0u, false};
+                if (sr >= 0 && sr < ROUNDS) sp = stage_pos(ims, hs, sr);
+                SCHED_FENCE();
+                // (2) the tile pairs; between their MFMAs the staging round whose loads were issued SD steps ago
+                MI355_UNROLL
+                for (int jp = 0; jp < NP; ++jp) {
+                    const int cur = (NP % 2 == 0) ? (jp & 1) : ((s * NP + jp) & 1);
+                    if (jp + 1 < NP) {
+                        b_read(s, 2 * jp + 2, Bf[cur ^ 1][0]);
+                        b_read(s, 2 * jp + 3, Bf[cur ^ 1][1]);
+                    } else if (sl + 1 < SH) {
+                        b_read(s + 1, 0, Bf[cur ^ 1][0]);
+                        b_read(s + 1, 1, Bf[cur ^ 1][1]);
+                    }
+                    SCHED_FENCE();
+                    {
+                        const uint4(&W)[3] = Wr[s % WR];
+                        f32x4 c0 = acc[2 * jp], c1 = acc[2 * jp + 1];
+                        const uint4(&B0)[3] = Bf[cur][0];
+                        const uint4(&B1)[3] = Bf[cur][1];
+                        c0 = MFMA_16x16x32_BF16(W[2], B0[0], c0);  // small terms first
+                        c1 = MFMA_16x16x32_BF16(W[2], B1[0], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[2], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[2], c1);
+                        c0 = MFMA_16x16x32_BF16(W[1], B0[1], c0);
+                        c1 = MFMA_16x16x32_BF16(W[1], B1[1], c1);
+                        c0 = MFMA_16x16x32_BF16(W[1], B0[0], c0);
+                        c1 = MFMA_16x16x32_BF16(W[1], B1[0], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[1], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[1], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[0], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[0], c1);
+                        acc[2 * jp] = c0;
+                        acc[2 * jp + 1] = c1;
+                    }
+                    if (sr >= 0 && sr < ROUNDS) {
+                        if (NP >= 4) {
+                            if (jp < 4) stage_piece(jp, sv[sr], ph, sp);
+                        } else {  // fewer pairs than pieces: the pieces share the pairs
+                            MI355_UNROLL
+                            for (int pc = 0; pc < 4; ++pc)
+                                if (pc * NP / 4 == jp) stage_piece(pc, sv[sr], ph, sp);
+                        }
+                        MI355_UNROLL
+                        for (int u = 0; u < 12; ++u) {
+                            SCHED_GROUP(0x8, 1);  // one MFMA ...
+                            SCHED_GROUP(0x2, 3);  // ... then up to three VALU of the staging piece
+                        }
+                    }
+                    SCHED_FENCE();
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: (res + (acc + bias)) * scale (+ old y); columns past the tensor dropped by the range check.  The old
+        // values of an accumulating conv are loaded for all tiles before the first store (a load behind a store cannot be
+        // waited for without waiting for the store's acknowledgement: the memory counter retires in order)
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) acc[j][r] = (rq[j][r] + (acc[j][r] + bia[r])) * a.out_scale;
+        if (a.accumulate) {
+            MI355_UNROLL
+            for (int j = 0; j < NCT; ++j) {
+                const int t = im.t0 + 16 * j + n;
+                const int tc = t < a.T ? t : a.T - 1;
+                const unsigned oc = 4u * (unsigned)(co0 * a.y_ld + tc);
+                MI355_UNROLL
+                for (int r = 0; r < 4; ++r) rq[j][r] = buf_load_f32(ybuf, oc, (unsigned)r * yrow);
+            }
+            MI355_UNROLL
+            for (int j = 0; j < NCT; ++j)
+                MI355_UNROLL
+                for (int r = 0; r < 4; ++r) acc[j][r] += rq[j][r];
+        }
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j) {
+            const int t = im.t0 + 16 * j + n;
+            const unsigned o = t < a.T ? 4u * (unsigned)(co0 * a.y_ld + t) : BUF_OOB;
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) buf_store_f32(ybuf, o, (unsigned)r * yrow, acc[j][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace {
+inline bool rbc_shape(int K, int dil) {  // the "_low" voices' stage-0 convs (instantiated tap / dilation pairs)
+    return (K == 3 && (dil == 1 || dil == 2)) || (K == 5 && (dil == 2 || dil == 6)) || (K == 7 && (dil == 3 || dil == 12));
+}
+}  // namespace
+
+bool rb_conv_supported(const ConvArgs& a) {
+    return a.Cin == RBC_C && a.Cout == RBC_C && rbc_shape(a.K, a.dil) && a.epi == EPI_STD && a.res && a.in_len && !a.cond && !a.relu && !a.res_sub && !a.mask_before_res &&
+           !a.out_len && !a.shuf_s && a.Tin < 0 && a.pad == (a.K - 1) / 2 * a.dil && a.ksplit == 1 && (long)RBC_C * a.T * 4 < 0x7fffffffL;
+}
+
+// a.w = the conv's pack_conv_weights_p16 fragments.  wide = 128-column items (grids that fill the chip), else 32-column items:
+// the same bits either way
+void launch_rb_conv(ConvArgs a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    if (!rb_conv_supported(a)) throw std::runtime_error("rb_conv: unsupported shape");
+    const int cus = current_device_cu_count();
+    bool wide = (long)a.B * ((a.T + 127) / 128) >= cus;
+    if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;  // lab / tests
+    auto go = [&](auto kfn, size_t lds, int ncols) {
+        const long nitems = (long)((a.T + ncols - 1) / ncols) * a.B;
+        dim3 grid((unsigned)(nitems < cus ? nitems : cus));  // persistent: one workgroup per CU
+        set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
+        LAUNCH_KERNEL(kfn, grid, dim3(512), lds, s, a);
+    };
+#define RBC_CASE(KK, DD)                                                             \
+    if (a.K == KK && a.dil == DD) {                                                  \
+        if (wide) go(k_rb_conv<KK, DD, 8>, RbcGeo<KK, DD, 8>::LDS, 128);             \
+        else go(k_rb_conv<KK, DD, 2>, RbcGeo<KK, DD, 2>::LDS, 32);                   \
+        return;                                                                      \
+    }
+    RBC_CASE(3, 1)
+    RBC_CASE(3, 2)
+    RBC_CASE(5, 2)
+    RBC_CASE(5, 6)
+    RBC_CASE(7, 3)
+    RBC_CASE(7, 12)
+#undef RBC_CASE
+    throw std::runtime_error("rb_conv: unsupported shape");
+}
+
+}  // namespace m355

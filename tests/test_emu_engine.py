@@ -736,6 +736,44 @@ def test_mrf_row_sweep_is_bitwise_the_block_kernel(emu_lib, dils, seg, monkeypat
     assert np.array_equal(outs["p"]["audio"], outs["s"]["audio"])
 
 
+def test_resblock_conv_128_channels_resident_input(emu_lib, monkeypatch):
+    """k_rb_conv (kernels_rbc.cpp): the six convs of the 128-channel MRF stage, each with all its input channels resident in LDS
+    as two half-buffers (one refilled while the matrix cores work through the other) — against the kernels it replaces
+    (k_mrf_fused for the narrow resblocks + the staged conv for k = 7: another order of summation, so within tolerance) and,
+    through check_parity, against the oracle at every decoder tap; 128- and 32-column work items BIT FOR BIT (the sum order of an
+    output element does not depend on the item width); ragged batch (row 1 ends inside an item, row 2 one frame short), 384
+    columns per row = 3 items of 128 columns (the last one of row 1 entirely masked), 9 items on the CPU model's 8 "CUs"."""
+    cfg = VitsConfig.tiny_wide(initial_channel=256)
+    w = W.synthetic_weights(cfg, seed=91, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 24
+    forced = np.full((3, Tx), 4, np.int32)
+    ids = np.random.default_rng(8).integers(1, cfg.num_symbols, (3, Tx))
+    lengths = np.array([Tx, Tx - 9, Tx - 1])
+    outs, taps = {}, {}
+    for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math("bf16x3")
+        eng.profile_enable(True)
+        outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=91, weights=w, engine=eng)
+        labels = set(eng.profile_report())
+        assert ("dec.mrf_fused.s0" in labels) == (tag == "old"), labels
+        assert "dec.rb.s0" in labels, labels
+        taps[tag] = eng.tap("dec.mrf.0")
+        eng.close()
+    assert np.array_equal(taps["wide"], taps["narrow"])
+    assert np.array_equal(outs["wide"]["audio"], outs["narrow"]["audio"])
+    for bi in range(3):
+        L = int(outs["old"]["lengths"][bi])
+        L0 = L * taps["old"].shape[2] // outs["old"]["audio"].shape[1]  # the row's own columns in stage 0 (past them: unmasked leftovers)
+        assert rel_rms(taps["wide"][bi, :, :L0], taps["old"][bi, :, :L0]) < 2e-6
+        assert rel_rms(outs["wide"]["audio"][bi, :L], outs["old"]["audio"][bi, :L]) < 2e-5
+
+
 ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (2, 96, 192, 130, 1), (1, 96, 40, 65, 3), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
              (1, 384, 100, 33, 3)]
 

@@ -161,3 +161,39 @@ def test_mrf_row_sweeps_equal_block_kernel_bitwise_on_the_device(lab_lib, monkey
     for tag in ("default", "short_segments"):
         for k in range(3):
             assert np.array_equal(res[tag][k], res["block"][k]), (tag, k)
+
+
+def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
+    """k_rb_conv (the 128-channel MRF stage conv by conv, all input channels resident in LDS, kernels_rbc.cpp) on the MI355X at the
+    full-size shapes: the stage-0 tap and the waveform against the kernels it replaces (MI355VITS_NO_RBC=1: k_mrf_fused + the staged
+    conv — another order of summation, so within tolerance on each row's own columns), and its 128- and 32-column work items BIT FOR
+    BIT (the launcher picks by grid size; a row's bits must not depend on what it is batched with).  Ragged rows ending inside an
+    item, a one-phoneme row."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    blob = W.pack(cfg, w)
+    B, Tx = 8, 128
+    ids = np.random.default_rng(8).integers(1, 50, (B, Tx))
+    lengths = np.array([Tx, Tx, 97, Tx, 64, Tx, 1, 127])
+    forced = np.full((B, Tx), 6, np.int32)
+    res = {}
+    for tag, env in (("default", {}), ("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(blob, library=lab_lib, device=0)
+        eng.profile_enable(True)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
+        labels = set(eng.profile_report())
+        assert ("dec.mrf_fused.s0" in labels) == (tag == "old"), (tag, labels)
+        res[tag] = eng.tap("dec.mrf.0"), out["audio"].copy(), out["lengths"].copy()
+        eng.close()
+    for tag in ("default", "narrow"):
+        assert np.array_equal(res[tag][0], res["wide"][0]), tag
+        assert np.array_equal(res[tag][1], res["wide"][1]), tag
+    hop = res["old"][1].shape[1] // res["old"][0].shape[2]
+    for bi in range(B):
+        n = int(res["old"][2][bi])
+        assert rel_rms(res["wide"][0][bi, :, : n // hop], res["old"][0][bi, :, : n // hop]) < 2e-6, bi
+        assert rel_rms(res["wide"][1][bi, :n], res["old"][1][bi, :n]) < REL_RMS_TOL, bi
