@@ -236,6 +236,12 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             pack_conv_weights_p16(w.data(), Cout, Cin, K, pp.data());
             c.packed_p = stage(reinterpret_cast<const float*>(pp.data()), pp.size());
         }
+        if (key.rfind("dec.ups.", 0) == 0 && epi == EPI_STD && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && K == 2) {
+            // polyphase upsamplers 128 -> 64 / 64 -> 32: fragments of 16-row tiles in natural row order (k_ups_pl)
+            std::vector<uint32_t> pp(p16_packed_words(Cout, Cin, K));
+            pack_conv_weights_p16n(w.data(), Cout, Cin, K, pp.data());
+            c.packed_p = stage(reinterpret_cast<const float*>(pp.data()), pp.size());
+        }
         if (Cin % 32 == 0 && (epi == EPI_GATE ? (Cout / 2) % 32 == 0 : true)) {
             // ... and for the staged split-bf16 kernel (every dense conv with a multiple of 32 input channels)
             const int pe = epi == EPI_GATE ? EPI_GATE : EPI_STD;
@@ -637,6 +643,12 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     if (a.epi == EPI_RESSKIP) ch_io += w.Cout;  // h and skip are read-modify-write
     const double bytes = 4.0 * a.B * (double)a.T * ch_io + 4.0 * (double)w.Cout * w.Cin * w.K;
     ProfScope ps(prof_, label, flops, bytes);
+    if (a.shuf_s && phase_b_ && !force_generic_ && !no_rbc_ && math_ == MATH_BF16X3 && w.packed_p != NO_OFF && ups_pl_supported(a)) {
+        a.w = P(w.packed_p);  // polyphase upsamplers 128 -> 64, 64 -> 32: every input channel resident (k_ups_pl)
+        a.math = MATH_BF16X3;
+        launch_ups_pl(a, stream_);
+        return;
+    }
     if (rbc_ok(w, a)) {  // 128-channel resblock convs: every input channel resident, one launch per conv (k_rb_conv)
         a.w = P(w.packed_p);
         a.math = MATH_BF16X3;

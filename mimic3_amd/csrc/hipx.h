@@ -39,6 +39,12 @@ constexpr unsigned BUF_OOB = 0x80000000u;  // a lane offset past the buffer's ra
 static inline void buf_store_f32(const BufRsrc& r, unsigned voff, unsigned soff, float v) {
     if (voff < BUF_OOB) *reinterpret_cast<float*>(r.p + voff + soff) = v;
 }
+static inline void buf_store_f4(const BufRsrc& r, unsigned voff, unsigned soff, float a, float b, float c, float d) {
+    if (voff < BUF_OOB) { float* p = reinterpret_cast<float*>(r.p + voff + soff); p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+}
+static inline void buf_store_f2(const BufRsrc& r, unsigned voff, unsigned soff, float a, float b) {
+    if (voff < BUF_OOB) { float* p = reinterpret_cast<float*>(r.p + voff + soff); p[0] = a; p[1] = b; }
+}
 static inline uint4 buf_load_u4(const BufRsrc& r, unsigned voff, unsigned soff) {  // 16 bytes (weight fragments)
     return *reinterpret_cast<const uint4*>(r.p + voff + soff);
 }
@@ -107,6 +113,17 @@ __device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned voff, unsigned
 constexpr unsigned BUF_OOB = 0x80000000u;
 __device__ __forceinline__ void buf_store_f32(BufRsrc r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+// 16- / 8-byte stores of consecutive floats (out-of-range lanes dropped as above)
+__device__ __forceinline__ void buf_store_f4(BufRsrc r, unsigned voff, unsigned soff, float a, float b, float c, float d) {
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    const v4u_t v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_f2(BufRsrc r, unsigned voff, unsigned soff, float a, float b) {
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    const v2u_t v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 // buffer_load_dwordx4: a 16-byte fragment per lane, the fragment's offset in an SGPR (streamed weight fragments: no address VALU)
 __device__ __forceinline__ uint4 buf_load_u4(BufRsrc r, unsigned voff, unsigned soff) {

@@ -155,6 +155,11 @@ void launch_mrf_s1(MrfArgs a, hipStream_t s);
 // y (+)= (res + bias + conv(lrelu(x * mask))) * out_scale; a.w = pack_conv_weights_p16 fragments; K / dilation pairs of the "_low" voices.
 bool rb_conv_supported(const ConvArgs& a);
 void launch_rb_conv(ConvArgs a, hipStream_t s);
+// The polyphase upsamplers 128 -> 64 (x 8) and 64 -> 32 (x 4) in the same form (k_ups_pl): a = the ConvArgs of the polyphase conv
+// (shuf_*, Tin, T = Tin + 1), a.w = pack_conv_weights_p16n fragments of the [stride * Cout, Cin, 2] polyphase filter.
+void pack_conv_weights_p16n(const float* w, int Cout, int Cin, int K, uint32_t* out);
+bool ups_pl_supported(const ConvArgs& a);
+void launch_ups_pl(ConvArgs a, hipStream_t s);
 int current_device_cu_count();  // compute units of the current device (persistent grids), looked up once per device
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel, current device)
 void set_max_dynamic_lds(const void* fn, int bytes);

@@ -309,6 +309,282 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The polyphase upsamplers 128 -> 64 (x 8) and 64 -> 32 (x 4) in the same form.  ConvTranspose1d(k = 2 s, stride s)
+// of lrelu(x) = a two-tap stride-1 conv with s * Cout "phase rows" (kernels.h: shuf_*; row m = c s + phase): output position i,
+// row m = w'[m, :, 0] . x[:, i - 1] + w'[m, :, 1] . x[:, i], landing at y[c][i s + phase - s / 2].  A work item is (row, N output
+// positions) with all CIN input channels resident as planes (N + 1 columns); the phase rows run in blocks of 128 (8 waves x one
+// 16-row tile; 128 -> 64: four blocks per item, 64 -> 32: one), every block through the two half-buffers' k-groups.  The halves
+// are refilled as in k_rb_conv, except that a half's loads are issued one phase before its stores (a phase is only two or four
+// steps here): half 1 of an item is stored during its first phase (loaded during the previous item's last one), half 0 of the
+// NEXT item during its last phase (loaded during the one before).  Weights in natural row order (pack_conv_weights_p16n), so a
+// wave's 16 rows are two channels x 8 phases (four channels x 4): lanes q = 0, 1 (r = 0..3) write adjacent 16 bytes and a store
+// instruction covers whole 512-byte runs of y.
+template <int I, int NN, typename F>
+__device__ __forceinline__ void rbc_static_for(F&& f) {
+    if constexpr (I < NN) {
+        f(std::integral_constant<int, I>{});
+        rbc_static_for<I + 1, NN>(f);
+    }
+}
+// staging rounds of a phase of SH steps: round r belongs to step r SH / ROUNDS; first / one-past-last round of step sl
+constexpr int rbc_round_lo(int sl, int SH, int ROUNDS) {
+    int r = 0;
+    while (r < ROUNDS && r * SH / ROUNDS < sl) ++r;
+    return r;
+}
+constexpr int rbc_round_hi(int sl, int SH, int ROUNDS) {
+    int r = 0;
+    while (r < ROUNDS && r * SH / ROUNDS <= sl) ++r;
+    return r;
+}
+
+template <int CIN, int STR, int NCT>
+struct UpsGeo {
+    static constexpr int G = CIN / 32, REC = CIN / 8, N = 16 * NCT, LD = N + 1, LDP = (LD + 15) & ~15;
+    static constexpr int M = STR * (CIN / 2), RB = M / 128;
+    static constexpr unsigned REC16 = 16u * LDP, PS16 = REC * REC16;
+    static constexpr int HALF = (REC / 2) * LD, ROUNDS = (HALF + 511) / 512;
+    static constexpr size_t LDS = 3 * (size_t)PS16;
+};
+
+template <int CIN, int STR, int NCT>
+__global__ __launch_bounds__(512) void k_ups_pl(ConvArgs a) {
+    using GE = UpsGeo<CIN, STR, NCT>;
+    constexpr int G = GE::G, REC = GE::REC, N = GE::N, LD = GE::LD, LDP = GE::LDP, RB = GE::RB, K = 2;
+    constexpr int S = G * K, SH = S / 2, NPH = 2 * RB, ROUNDS = GE::ROUNDS, HALF = GE::HALF, NP = NCT / 2, WR = RBC_WR;
+    constexpr unsigned REC16 = GE::REC16, PS16 = GE::PS16;
+    static_assert(NCT % 2 == 0 && (RB * S) % WR == 0 && G % 2 == 0 && GE::M % 128 == 0 && (STR == 4 || STR == 8) && GE::LDS <= RBC_LDS_LIMIT, "shape");
+    DYN_SMEM(float, smem);
+    char* L0 = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, mt = WAVE_UNIFORM(tid >> 6);
+    const int q = lane >> 4, n = lane & 15;
+    const BufRsrc wbuf = buf_rsrc(a.w);
+    const unsigned wl = 16u * (unsigned)lane;
+    unsigned lq[3];
+    MI355_UNROLL
+    for (int p = 0; p < 3; ++p) {
+        lq[p] = (unsigned)p * PS16 + (unsigned)(q * LDP + n) * 16u;
+        OPAQUE_V(lq[p]);
+    }
+    const int nblk = (a.T + N - 1) / N;  // a.T = output positions = Tin + 1
+    const int nitems = nblk * a.B;
+    const unsigned xrow = 4u * (unsigned)a.x_ld;
+
+    struct Item { int b, t0, len, last; };
+    auto row_len = [&](int b) MI355_INLINE_LAMBDA {
+#ifdef MI355_EMU
+        return a.in_len[b];
+#else
+        typedef const int __attribute__((address_space(4))) * cptr_t;
+        return ((cptr_t)(a.in_len))[b];
+#endif
+    };
+    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+        Item o;
+        o.b = WAVE_UNIFORM(it / nblk);
+        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
+        int len = row_len(o.b);
+        if (len > a.Tin) len = a.Tin;
+        o.len = len;
+        o.last = o.len > 0 ? o.len - 1 : 0;
+        return o;
+    };
+    auto stage_load = [&](const Item& im, const BufRsrc& xb, int half, int round, float (&sv)[8]) MI355_INLINE_LAMBDA {
+        int t2 = tid;
+        OPAQUE_V(t2);
+        int idx = t2 + 512 * round;
+        if (512 * (round + 1) > HALF) idx = idx < HALF ? idx : HALF - 1;
+        const int rec = idx / LD, col = idx - rec * LD;
+        const int t = im.t0 - 1 + col;
+        const int tc = t < 0 ? 0 : (t > im.last ? im.last : t);
+        const unsigned o = 4u * (unsigned)(8 * ((REC / 2) * half + rec) * a.x_ld + tc);
+        MI355_UNROLL
+        for (int e = 0; e < 8; ++e) sv[e] = buf_load_f32(xb, o, (unsigned)e * xrow);
+    };
+    struct StagePos { unsigned addr; bool in; };
+    auto stage_pos = [&](const Item& im, int half, int round) MI355_INLINE_LAMBDA {
+        int t2 = tid;
+        OPAQUE_V(t2);
+        int idx = t2 + 512 * round;
+        if (512 * (round + 1) > HALF) idx = idx < HALF ? idx : HALF - 1;
+        const int rec = idx / LD, col = idx - rec * LD;
+        const int t = im.t0 - 1 + col;
+        StagePos sp;
+        sp.in = t >= 0 && t < im.len;
+        sp.addr = (unsigned)((REC / 2) * half + rec) * REC16 + 16u * (unsigned)col;
+        return sp;
+    };
+    auto stage_piece = [&](int piece, const float (&sv)[8], uint4 (&ph)[3], const StagePos& sp) MI355_INLINE_LAMBDA {
+        const float v0 = sp.in ? lrelu_f(sv[2 * piece], a.in_slope) : 0.0f, v1 = sp.in ? lrelu_f(sv[2 * piece + 1], a.in_slope) : 0.0f;
+        unsigned h, m, l;
+        split3_sc(v0, v1, h, m, l);
+        if (piece == 0) { ph[0].x = h; ph[1].x = m; ph[2].x = l; }
+        if (piece == 1) { ph[0].y = h; ph[1].y = m; ph[2].y = l; }
+        if (piece == 2) { ph[0].z = h; ph[1].z = m; ph[2].z = l; }
+        if (piece == 3) {
+            ph[0].w = h; ph[1].w = m; ph[2].w = l;
+            char* px = L0 + sp.addr;
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(px + (unsigned)p * PS16) = ph[p];
+        }
+    };
+    // step u of an item = (row block u / S, k-group (u % S) / K, tap u % K)
+    auto w_load = [&](int u, uint4 (&w)[3]) MI355_INLINE_LAMBDA {
+        const int rb = u / S, g = (u % S) / K, k = u % K;
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p)
+            w[p] = buf_load_u4(wbuf, wl, (unsigned)(rb * 8 * K * G * 3 * 1024) + (unsigned)mt * (unsigned)(K * G * 3 * 1024) + (unsigned)(((k * G + g) * 3 + p) * 1024));
+    };
+    auto b_read = [&](int u, int j, uint4 (&bf)[3]) MI355_INLINE_LAMBDA {
+        const int g = (u % S) / K, k = u % K;
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const uint4*>(L0 + lq[p] + (unsigned)((4 * g) * LDP + 16 * j + k) * 16u);
+    };
+
+    if ((int)blockIdx.x >= nitems) return;
+    float sv[ROUNDS][8];  // the half being staged: loaded one phase ahead of its stores
+    {
+        // prologue: half 0 of the first item (loaded and stored), the loads of its half 1, the first steps' weight fragments
+        const Item im = decode(blockIdx.x);
+        const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) stage_load(im, xb, 0, r, sv[r]);
+        SCHED_FENCE();
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) {
+            uint4 ph[3];
+            const StagePos sp = stage_pos(im, 0, r);
+            MI355_UNROLL
+            for (int pc = 0; pc < 4; ++pc) stage_piece(pc, sv[r], ph, sp);
+        }
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) stage_load(im, xb, 1, r, sv[r]);
+    }
+    uint4 Wr[WR][3];
+    MI355_UNROLL
+    for (int u = 0; u < WR - 1; ++u) w_load(u, Wr[u]);
+    __syncthreads();
+
+    MI355_NOUNROLL
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const Item im = decode(it);
+        const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;
+        const Item imn = decode(itn);
+        const BufRsrc xbn = buf_rsrc(a.x + (long)imn.b * a.x_bs);
+        const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
+        f32x4 acc[NCT];
+        rbc_static_for<0, NPH>([&](auto PHI) MI355_INLINE_LAMBDA {
+            constexpr int phi = decltype(PHI)::value;
+            constexpr int rb = phi / 2, h = phi & 1;
+            if constexpr (h == 0) {
+                MI355_UNROLL
+                for (int j = 0; j < NCT; ++j)
+                    MI355_UNROLL
+                    for (int r = 0; r < 4; ++r) acc[j][r] = 0.0f;
+            }
+            // what this phase stores (loaded one phase earlier) and what it loads (stored one phase later)
+            constexpr bool st1 = phi == 0, st0 = phi == NPH - 1;          // half 1 of this item | half 0 of the next
+            constexpr bool ld0 = phi == NPH - 2, ld1 = phi == NPH - 1;    // half 0 of the next item | half 1 of the next
+            uint4 ph[3];
+            uint4 Bf[2][2][3];
+            b_read(phi * SH, 0, Bf[0][0]);
+            b_read(phi * SH, 1, Bf[0][1]);
+            rbc_static_for<0, SH>([&](auto SL) MI355_INLINE_LAMBDA {
+                constexpr int sl = decltype(SL)::value;
+                constexpr int u = phi * SH + sl;
+                constexpr int r0 = rbc_round_lo(sl, SH, ROUNDS), r1 = rbc_round_hi(sl, SH, ROUNDS), nr = r1 - r0;  // this step's rounds
+                static_assert(nr <= NP, "a round needs a tile pair of its own");
+                w_load((u + WR - 1) % (RB * S), Wr[(u + WR - 1) % WR]);
+                if constexpr (ld0 && !st1) {  // (one row block: the loads follow their registers' stores, below)
+                    rbc_static_for<r0, r1>([&](auto R) MI355_INLINE_LAMBDA { stage_load(imn, xbn, 0, decltype(R)::value, sv[decltype(R)::value]); });
+                }
+                SCHED_FENCE();
+                rbc_static_for<0, NP>([&](auto JP) MI355_INLINE_LAMBDA {
+                    constexpr int jp = decltype(JP)::value;
+                    constexpr int cur = (NP % 2 == 0) ? (jp & 1) : ((u * NP + jp) & 1);
+                    if constexpr (jp + 1 < NP) {
+                        b_read(u, 2 * jp + 2, Bf[cur ^ 1][0]);
+                        b_read(u, 2 * jp + 3, Bf[cur ^ 1][1]);
+                    } else if constexpr (sl + 1 < SH) {
+                        b_read(u + 1, 0, Bf[cur ^ 1][0]);
+                        b_read(u + 1, 1, Bf[cur ^ 1][1]);
+                    }
+                    SCHED_FENCE();
+                    {
+                        const uint4(&W)[3] = Wr[u % WR];
+                        f32x4 c0 = acc[2 * jp], c1 = acc[2 * jp + 1];
+                        const uint4(&B0)[3] = Bf[cur][0];
+                        const uint4(&B1)[3] = Bf[cur][1];
+                        c0 = MFMA_16x16x32_BF16(W[2], B0[0], c0);  // small terms first
+                        c1 = MFMA_16x16x32_BF16(W[2], B1[0], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[2], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[2], c1);
+                        c0 = MFMA_16x16x32_BF16(W[1], B0[1], c0);
+                        c1 = MFMA_16x16x32_BF16(W[1], B1[1], c1);
+                        c0 = MFMA_16x16x32_BF16(W[1], B0[0], c0);
+                        c1 = MFMA_16x16x32_BF16(W[1], B1[0], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[1], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[1], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[0], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[0], c1);
+                        acc[2 * jp] = c0;
+                        acc[2 * jp + 1] = c1;
+                    }
+                    if constexpr ((st1 || st0) && nr > 0) {
+                        // this step's rounds share its tile pairs: round r0 + x on pairs [x NP / nr, (x + 1) NP / nr), four pieces each
+                        constexpr int x = jp * nr / NP, p0 = (x * NP + nr - 1) / nr, p1 = ((x + 1) * NP + nr - 1) / nr, np = p1 - p0;
+                        constexpr int r = r0 + x;
+                        const StagePos sp = stage_pos(st1 ? im : imn, st1 ? 1 : 0, r);
+                        rbc_static_for<0, 4>([&](auto PC) MI355_INLINE_LAMBDA {
+                            constexpr int pc = decltype(PC)::value;
+                            if constexpr (pc * np / 4 == jp - p0) stage_piece(pc, sv[r], ph, sp);
+                        });
+                        MI355_UNROLL
+                        for (int xx = 0; xx < 12; ++xx) {
+                            SCHED_GROUP(0x8, 1);
+                            SCHED_GROUP(0x2, 3);
+                        }
+                    }
+                    SCHED_FENCE();
+                });
+                // the registers of the rounds stored in this step take the next half's loads
+                if constexpr (ld1 || (ld0 && st1)) {
+                    rbc_static_for<r0, r1>([&](auto R) MI355_INLINE_LAMBDA { stage_load(imn, xbn, ld1 ? 1 : 0, decltype(R)::value, sv[decltype(R)::value]); });
+                    SCHED_FENCE();
+                }
+            });
+            // barriers: behind a phase that stored a half (its readers come next), and in front of the phase that overwrites half 0
+            // with the next item's columns (every wave must be done with this item's last pass over half 0)
+            if constexpr (st1 || st0 || phi == NPH - 2) __syncthreads();
+            if constexpr (h == 1) {
+                // ---- epilogue of row block rb: bias, then the phases of a channel side by side
+                const int m0 = 128 * rb + 16 * mt + 4 * q;  // this lane's four phase rows
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + m0);
+                const float bia[4] = {bv.x, bv.y, bv.z, bv.w};
+                MI355_UNROLL
+                for (int j = 0; j < NCT; ++j) {
+                    const int i = im.t0 + 16 * j + n;
+                    float v[4];
+                    MI355_UNROLL
+                    for (int r = 0; r < 4; ++r) v[r] = acc[j][r] + bia[r];
+                    if (STR == 8) {
+                        const int c = m0 >> 3, n0 = 8 * i + (m0 & 7) - 4;
+                        const unsigned o = (i < a.T && n0 >= 0 && n0 + 3 < a.shuf_T) ? 4u * (unsigned)(c * a.y_ld + n0) : BUF_OOB;
+                        buf_store_f4(ybuf, o, 0u, v[0], v[1], v[2], v[3]);
+                    } else {
+                        const int c = m0 >> 2, n0 = 4 * i - 2;
+                        const unsigned o0 = (i < a.T && i >= 1) ? 4u * (unsigned)(c * a.y_ld + n0) : BUF_OOB;
+                        const unsigned o1 = (i < a.T && n0 + 3 < a.shuf_T) ? 4u * (unsigned)(c * a.y_ld + n0 + 2) : BUF_OOB;
+                        buf_store_f2(ybuf, o0, 0u, v[0], v[1]);
+                        buf_store_f2(ybuf, o1, 0u, v[2], v[3]);
+                    }
+                }
+            }
+        });
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 inline bool rbc_shape(int K, int dil) {  // the "_low" voices' stage-0 convs (instantiated tap / dilation pairs)
@@ -349,6 +625,86 @@ void launch_rb_conv(ConvArgs a, hipStream_t s) {
     RBC_CASE(7, 12)
 #undef RBC_CASE
     throw std::runtime_error("rb_conv: unsupported shape");
+}
+
+
+// natural row order (row tile t = rows 16 t .. 16 t + 15): [row tile][tap][k-group][plane][lane][8 bf16], lane = (quarter q, row l & 15)
+// holds the input channels 32 g + 8 q + 0..7; w = h + m + l exactly, each term rounded to nearest on the host
+void pack_conv_weights_p16n(const float* w, int Cout, int Cin, int K, uint32_t* out) {
+    auto rne = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    };
+    auto tof = [](uint32_t b) {
+        const uint32_t u = b << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    const int G = Cin / 32;
+    for (int t = 0; t < Cout / 16; ++t)
+        for (int k = 0; k < K; ++k)
+            for (int g = 0; g < G; ++g)
+                for (int l = 0; l < 64; ++l) {
+                    const int q = l >> 4, co = 16 * t + (l & 15);
+                    uint32_t plane[3][8];
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = w[((size_t)co * Cin + 32 * g + 8 * q + e) * K + k];
+                        const uint32_t h = rne(v);
+                        const float r1 = v - tof(h);
+                        const uint32_t mm = rne(r1);
+                        const float r2 = r1 - tof(mm);
+                        plane[0][e] = h; plane[1][e] = mm; plane[2][e] = rne(r2);
+                    }
+                    for (int p = 0; p < 3; ++p) {
+                        uint32_t* o = out + (((((size_t)t * K + k) * G + g) * 3 + p) * 64 + l) * 4;
+                        for (int jj = 0; jj < 4; ++jj) o[jj] = plane[p][2 * jj] | (plane[p][2 * jj + 1] << 16);
+                    }
+                }
+}
+
+// 128 -> 64 (x 8): 0.35 -> 0.26 ms per launch at the bench shape.  64 -> 32 (x 4) measured EQUAL to the staged polyphase kernel
+// (0.39 vs 0.38 - 0.42 ms: 1.2 GB of HBM traffic per launch against 0.15 ms of matrix work, and a half's loads are only one short
+// phase ahead of their use); that form stays in the lab build and the CPU model (MI355VITS_UPS_PL64=1) as the A/B of this statement.
+bool ups_pl_supported(const ConvArgs& a) {
+    bool s4 = false;
+#if defined(MI355_LAB) || defined(MI355_EMU)
+    s4 = a.Cin == 64 && a.shuf_s == 4 && lab_getenv("MI355VITS_UPS_PL64") != nullptr;
+#endif
+    const bool s8 = a.Cin == 128 && a.shuf_s == 8;
+    return (s8 || s4) && a.K == 2 && a.dil == 1 && a.pad == 1 && a.Cout == a.shuf_s * (a.Cin / 2) && a.shuf_cout == a.Cin / 2 && a.shuf_p == a.shuf_s / 2 &&
+           a.epi == EPI_STD && a.bias && a.in_len && a.Tin >= 0 && a.T == a.Tin + 1 && a.shuf_T == a.Tin * a.shuf_s && !a.res && !a.cond && !a.relu &&
+           !a.accumulate && a.out_scale == 1.0f && !a.out_len && a.ksplit == 1 && a.y_ld % 4 == 0 && a.y_bs % 4 == 0 &&
+           reinterpret_cast<uintptr_t>(a.y) % 16 == 0 && (long)a.Cin * a.Tin * 4 < 0x7fffffffL && (long)(a.Cin / 2) * a.shuf_T * 4 < 0x7fffffffL;
+}
+
+// a.w = the polyphase filter's pack_conv_weights_p16n fragments
+void launch_ups_pl(ConvArgs a, hipStream_t s) {
+    if (a.T <= 0 || a.B <= 0) return;
+    if (!ups_pl_supported(a)) throw std::runtime_error("ups_pl: unsupported shape");
+    const int cus = current_device_cu_count();
+    auto go = [&](auto kfn, size_t lds, int ncols) {
+        const long nitems = (long)((a.T + ncols - 1) / ncols) * a.B;
+        dim3 grid((unsigned)(nitems < cus ? nitems : cus));
+        set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
+        LAUNCH_KERNEL(kfn, grid, dim3(512), lds, s, a);
+    };
+    if (a.Cin == 128) {
+        bool wide = (long)a.B * ((a.T + 127) / 128) >= cus;
+        if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;  // lab / tests
+        if (wide) go(k_ups_pl<128, 8, 8>, UpsGeo<128, 8, 8>::LDS, 128);
+        else go(k_ups_pl<128, 8, 2>, UpsGeo<128, 8, 2>::LDS, 32);
+    } else {
+#if defined(MI355_LAB) || defined(MI355_EMU)
+        bool wide = (long)a.B * ((a.T + 255) / 256) >= cus;
+        if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;
+        if (wide) go(k_ups_pl<64, 4, 16>, UpsGeo<64, 4, 16>::LDS, 256);
+        else go(k_ups_pl<64, 4, 4>, UpsGeo<64, 4, 4>::LDS, 64);
+#endif
+    }
 }
 
 }  // namespace m355

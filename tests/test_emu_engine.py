@@ -774,6 +774,47 @@ def test_resblock_conv_128_channels_resident_input(emu_lib, monkeypatch):
         assert rel_rms(outs["wide"]["audio"][bi, :L], outs["old"]["audio"][bi, :L]) < 2e-5
 
 
+def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
+    """k_ups_pl (kernels_rbc.cpp): the upsamplers 128 -> 64 (x 8, k 16) and 64 -> 32 (x 4, k 8) as two-tap polyphase convs with all
+    input channels resident in LDS (half-buffers loaded one phase ahead of their stores, phase rows in blocks of 128, 16- / 8-byte
+    phase-interleaved stores) — through check_parity against the oracle at the upsampler taps, against the staged polyphase kernel
+    it replaces (MI355VITS_NO_RBC=1) within tolerance, and wide vs narrow work items BIT FOR BIT; ragged rows, first / last output
+    position (the half-valid phases at both ends of a row), several items per row."""
+    cfg = VitsConfig.tiny_wide(initial_channel=256)
+    cfg.upsample_rates = (2, 8, 4)
+    cfg.upsample_kernel_sizes = (4, 16, 8)
+    cfg.hop_length = 64
+    w = W.synthetic_weights(cfg, seed=93, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 12
+    forced = np.full((2, Tx), 4, np.int32)
+    ids = np.random.default_rng(9).integers(1, cfg.num_symbols, (2, Tx))
+    lengths = np.array([Tx, Tx - 5])
+    outs, taps = {}, {}
+    monkeypatch.setenv("MI355VITS_UPS_PL64", "1")  # the 64 -> 32 upsampler in this form too (CPU model / lab build: it measured equal)
+    for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math("bf16x3")
+        eng.profile_enable(True)
+        outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=93, weights=w, engine=eng)
+        taps[tag] = {k: eng.tap(k) for k in ("dec.ups.1", "dec.ups.2")}
+        eng.close()
+    for k in taps["wide"]:
+        assert np.array_equal(taps["wide"][k], taps["narrow"][k]), k
+        assert not np.array_equal(taps["wide"][k], taps["old"][k]), k  # (another kernel did run: another order of summation)
+    assert np.array_equal(outs["wide"]["audio"], outs["narrow"]["audio"])
+    for bi in range(2):
+        L = int(outs["old"]["lengths"][bi])
+        for k in taps["wide"]:
+            Lk = L * taps["old"][k].shape[2] // outs["old"]["audio"].shape[1]
+            assert rel_rms(taps["wide"][k][bi, :, :Lk], taps["old"][k][bi, :, :Lk]) < 2e-6, k
+        assert rel_rms(outs["wide"]["audio"][bi, :L], outs["old"]["audio"][bi, :L]) < 2e-5
+
+
 ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (2, 96, 192, 130, 1), (1, 96, 40, 65, 3), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),
              (1, 384, 100, 33, 3)]
 

@@ -164,8 +164,8 @@ def test_mrf_row_sweeps_equal_block_kernel_bitwise_on_the_device(lab_lib, monkey
 
 
 def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
-    """k_rb_conv (the 128-channel MRF stage conv by conv, all input channels resident in LDS, kernels_rbc.cpp) on the MI355X at the
-    full-size shapes: the stage-0 tap and the waveform against the kernels it replaces (MI355VITS_NO_RBC=1: k_mrf_fused + the staged
+    """k_rb_conv (the 128-channel MRF stage conv by conv, all input channels resident in LDS, kernels_rbc.cpp) and k_ups_pl (the
+    upsamplers 128 -> 64 and 64 -> 32 in the same form) on the MI355X at the full-size shapes: the stage-0 tap and the waveform against the kernels it replaces (MI355VITS_NO_RBC=1: k_mrf_fused + the staged
     conv — another order of summation, so within tolerance on each row's own columns), and its 128- and 32-column work items BIT FOR
     BIT (the launcher picks by grid size; a row's bits must not depend on what it is batched with).  Ragged rows ending inside an
     item, a one-phoneme row."""
@@ -180,6 +180,7 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
     for tag, env in (("default", {}), ("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
         for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
             monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("MI355VITS_UPS_PL64", "1")  # the 64 -> 32 upsampler in the same form too (lab build only: it measured equal)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = Engine(blob, library=lab_lib, device=0)
@@ -187,13 +188,14 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
         labels = set(eng.profile_report())
         assert ("dec.mrf_fused.s0" in labels) == (tag == "old"), (tag, labels)
-        res[tag] = eng.tap("dec.mrf.0"), out["audio"].copy(), out["lengths"].copy()
+        res[tag] = eng.tap("dec.mrf.0"), out["audio"].copy(), out["lengths"].copy(), eng.tap("dec.ups.1"), eng.tap("dec.ups.2")
         eng.close()
     for tag in ("default", "narrow"):
-        assert np.array_equal(res[tag][0], res["wide"][0]), tag
-        assert np.array_equal(res[tag][1], res["wide"][1]), tag
-    hop = res["old"][1].shape[1] // res["old"][0].shape[2]
+        for k in (0, 1, 3, 4):
+            assert np.array_equal(res[tag][k], res["wide"][k]), (tag, k)
     for bi in range(B):
         n = int(res["old"][2][bi])
-        assert rel_rms(res["wide"][0][bi, :, : n // hop], res["old"][0][bi, :, : n // hop]) < 2e-6, bi
+        for k in (0, 3, 4):  # the stage-0 MRF output and the two upsamplers that run in the same form (k_ups_pl)
+            hop = res["old"][1].shape[1] // res["old"][k].shape[2]
+            assert rel_rms(res["wide"][k][bi, :, : n // hop], res["old"][k][bi, :, : n // hop]) < 2e-6, (bi, k)
         assert rel_rms(res["wide"][1][bi, :n], res["old"][1][bi, :n]) < REL_RMS_TOL, bi
