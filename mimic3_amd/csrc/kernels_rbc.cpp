@@ -585,6 +585,226 @@ __global__ __launch_bounds__(512) void k_ups_pl(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The 64 -> 32 upsampler (x 4, k = 8): 1.2 GB of HBM traffic per launch at the bench shape against 0.15 ms of matrix work — a
+// memory-bound kernel, and in the half-buffer form above it ran no faster than the staged kernel (0.39 ms): every workgroup ends
+// its item with 32 stores per lane, all CUs at once, and the loads of the next phase sit behind them in the in-order memory
+// counter.  What this shape offers instead: its four steps' weight fragments are 48 registers — RESIDENT, no weight stream —, so
+// the loop can be tile-major: a tile pair runs all four steps and is stored at once while the next pair computes (stores spread
+// evenly over the item), and with only 384 bytes per column the input fits twice: item i + 1's planes are written to the other
+// buffer while item i computes (loads issued one whole item earlier still: two items ahead of their use), one barrier per item.
+// Items are 127 output positions = 128 input columns: exactly two staging rounds for the 512 threads.
+template <int NCT>
+struct Ups64Geo {
+    static constexpr int CIN = 64, G = 2, REC = 8, STR = 4, K = 2, S = G * K;
+    static constexpr int NPOS = 16 * NCT - 1, LD = 16 * NCT, LDP = LD;        // positions per item; staged columns = pitch
+    static constexpr unsigned REC16 = 16u * LDP, PS16 = REC * REC16, BUF = 3 * PS16;
+    static constexpr int FULL = REC * LD, ROUNDS = (FULL + 511) / 512;
+    static constexpr size_t LDS = 2 * (size_t)BUF;
+};
+
+template <int NCT>
+__global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
+    using GE = Ups64Geo<NCT>;
+    constexpr int G = GE::G, K = GE::K, S = GE::S, NPOS = GE::NPOS, LD = GE::LD, LDP = GE::LDP, ROUNDS = GE::ROUNDS, FULL = GE::FULL, NP = NCT / 2;
+    constexpr unsigned REC16 = GE::REC16, PS16 = GE::PS16, BUF = GE::BUF;
+    constexpr int NSLOT = NP * S;  // (tile pair, step) slots of an item
+    static_assert(NCT % 2 == 0 && GE::LDS <= RBC_LDS_LIMIT && ROUNDS * 4 <= NSLOT, "shape");
+    DYN_SMEM(float, smem);
+    char* L0 = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, mt = WAVE_UNIFORM(tid >> 6);
+    const int q = lane >> 4, n = lane & 15;
+    const BufRsrc wbuf = buf_rsrc(a.w);
+    const int nblk = (a.T + NPOS - 1) / NPOS;
+    const int nitems = nblk * a.B;
+    const unsigned xrow = 4u * (unsigned)a.x_ld;
+    if ((int)blockIdx.x >= nitems) return;
+
+    struct Item { int b, t0, len, last; };
+    auto row_len = [&](int b) MI355_INLINE_LAMBDA {
+#ifdef MI355_EMU
+        return a.in_len[b];
+#else
+        typedef const int __attribute__((address_space(4))) * cptr_t;
+        return ((cptr_t)(a.in_len))[b];
+#endif
+    };
+    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+        Item o;
+        o.b = WAVE_UNIFORM(it / nblk);
+        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * NPOS);
+        int len = row_len(o.b);
+        if (len > a.Tin) len = a.Tin;
+        o.len = len;
+        o.last = o.len > 0 ? o.len - 1 : 0;
+        return o;
+    };
+    auto clampi = [&](int it) MI355_INLINE_LAMBDA { return it < nitems ? it : nitems - 1; };  // (past the last item: it again, unread)
+    auto stage_load = [&](const Item& im, int round, float (&sv)[8]) MI355_INLINE_LAMBDA {
+        const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
+        int t2 = tid;
+        OPAQUE_V(t2);
+        int idx = t2 + 512 * round;
+        if (512 * (round + 1) > FULL) idx = idx < FULL ? idx : FULL - 1;
+        const int rec = idx / LD, col = idx - rec * LD;
+        const int t = im.t0 - 1 + col;
+        const int tc = t < 0 ? 0 : (t > im.last ? im.last : t);
+        const unsigned o = 4u * (unsigned)(8 * rec * a.x_ld + tc);
+        MI355_UNROLL
+        for (int e = 0; e < 8; ++e) sv[e] = buf_load_f32(xb, o, (unsigned)e * xrow);
+    };
+    struct StagePos { unsigned addr; bool in; };
+    auto stage_pos = [&](const Item& im, unsigned buf, int round) MI355_INLINE_LAMBDA {
+        int t2 = tid;
+        OPAQUE_V(t2);
+        int idx = t2 + 512 * round;
+        if (512 * (round + 1) > FULL) idx = idx < FULL ? idx : FULL - 1;
+        const int rec = idx / LD, col = idx - rec * LD;
+        const int t = im.t0 - 1 + col;
+        StagePos sp;
+        sp.in = t >= 0 && t < im.len;
+        sp.addr = buf + (unsigned)rec * REC16 + 16u * (unsigned)col;
+        return sp;
+    };
+    auto stage_piece = [&](int piece, const float (&sv)[8], uint4 (&ph)[3], const StagePos& sp) MI355_INLINE_LAMBDA {
+        const float v0 = sp.in ? lrelu_f(sv[2 * piece], a.in_slope) : 0.0f, v1 = sp.in ? lrelu_f(sv[2 * piece + 1], a.in_slope) : 0.0f;
+        unsigned h, m, l;
+        split3_sc(v0, v1, h, m, l);
+        if (piece == 0) { ph[0].x = h; ph[1].x = m; ph[2].x = l; }
+        if (piece == 1) { ph[0].y = h; ph[1].y = m; ph[2].y = l; }
+        if (piece == 2) { ph[0].z = h; ph[1].z = m; ph[2].z = l; }
+        if (piece == 3) {
+            ph[0].w = h; ph[1].w = m; ph[2].w = l;
+            char* px = L0 + sp.addr;
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(px + (unsigned)p * PS16) = ph[p];
+        }
+    };
+
+    // the four steps' fragments of this wave's row tile: resident (step u = k-group u / K, tap u % K)
+    uint4 Wr[S][3];
+    MI355_UNROLL
+    for (int u = 0; u < S; ++u)
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p)
+            Wr[u][p] = buf_load_u4(wbuf, 16u * (unsigned)lane, (unsigned)mt * (unsigned)(K * G * 3 * 1024) + (unsigned)((((u % K) * G + u / K) * 3 + p) * 1024));
+    const int m0 = 16 * mt + 4 * q;  // this lane's channel (m0 >> 2), phases 0..3
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + m0);
+    const float bia[4] = {bv.x, bv.y, bv.z, bv.w};
+
+    // prologue: the first item's planes into buffer 0, the second item's loads in flight
+    float sv[ROUNDS][8];
+    {
+        const Item im = decode(blockIdx.x);
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) stage_load(im, r, sv[r]);
+        SCHED_FENCE();
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) {
+            uint4 ph[3];
+            const StagePos sp = stage_pos(im, 0u, r);
+            MI355_UNROLL
+            for (int pc = 0; pc < 4; ++pc) stage_piece(pc, sv[r], ph, sp);
+        }
+        const Item im1 = decode(clampi(blockIdx.x + gridDim.x));
+        MI355_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) stage_load(im1, r, sv[r]);
+    }
+    __syncthreads();
+
+    unsigned cur = 0;  // byte offset of the buffer this item computes from
+    MI355_NOUNROLL
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const Item im = decode(it);
+        const Item im1 = decode(clampi(it + (int)gridDim.x)), im2 = decode(clampi(it + 2 * (int)gridDim.x));
+        const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
+        const unsigned other = cur == 0u ? BUF : 0u;  // the buffer item i + 1 is staged into
+        unsigned lq[3];
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) {
+            lq[p] = cur + (unsigned)p * PS16 + (unsigned)(q * LDP + n) * 16u;
+            OPAQUE_V(lq[p]);
+        }
+        auto b_read = [&](int u, int j, uint4 (&bf)[3]) MI355_INLINE_LAMBDA {
+            const int g = u / K, k = u % K;
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const uint4*>(L0 + lq[p] + (unsigned)((4 * g) * LDP + 16 * j + k) * 16u);
+        };
+        uint4 ph[3];
+        StagePos sp = {0u, false};
+        uint4 Bf[2][2][3];
+        b_read(0, 0, Bf[0][0]);
+        b_read(0, 1, Bf[0][1]);
+        rbc_static_for<0, NP>([&](auto JP) MI355_INLINE_LAMBDA {
+            constexpr int jp = decltype(JP)::value;
+            f32x4 c0, c1;
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) c0[r] = c1[r] = 0.0f;
+            rbc_static_for<0, S>([&](auto U) MI355_INLINE_LAMBDA {
+                constexpr int u = decltype(U)::value;
+                constexpr int slot = jp * S + u, cb = slot & 1;
+                // staging of item i + 1 into the other buffer: round slot / 4, piece slot % 4 (slots 0 .. 4 ROUNDS - 1); behind a
+                // round's last piece its registers take the loads of item i + 2
+                constexpr int sr = slot / 4, pc = slot % 4;
+                if constexpr (sr < ROUNDS && pc == 0) sp = stage_pos(im1, other, sr);
+                if constexpr (u + 1 < S) {
+                    b_read(u + 1, 2 * jp, Bf[cb ^ 1][0]);
+                    b_read(u + 1, 2 * jp + 1, Bf[cb ^ 1][1]);
+                } else if constexpr (jp + 1 < NP) {
+                    b_read(0, 2 * jp + 2, Bf[cb ^ 1][0]);
+                    b_read(0, 2 * jp + 3, Bf[cb ^ 1][1]);
+                }
+                SCHED_FENCE();
+                {
+                    const uint4(&W)[3] = Wr[u];
+                    const uint4(&B0)[3] = Bf[cb][0];
+                    const uint4(&B1)[3] = Bf[cb][1];
+                    c0 = MFMA_16x16x32_BF16(W[2], B0[0], c0);  // small terms first
+                    c1 = MFMA_16x16x32_BF16(W[2], B1[0], c1);
+                    c0 = MFMA_16x16x32_BF16(W[0], B0[2], c0);
+                    c1 = MFMA_16x16x32_BF16(W[0], B1[2], c1);
+                    c0 = MFMA_16x16x32_BF16(W[1], B0[1], c0);
+                    c1 = MFMA_16x16x32_BF16(W[1], B1[1], c1);
+                    c0 = MFMA_16x16x32_BF16(W[1], B0[0], c0);
+                    c1 = MFMA_16x16x32_BF16(W[1], B1[0], c1);
+                    c0 = MFMA_16x16x32_BF16(W[0], B0[1], c0);
+                    c1 = MFMA_16x16x32_BF16(W[0], B1[1], c1);
+                    c0 = MFMA_16x16x32_BF16(W[0], B0[0], c0);
+                    c1 = MFMA_16x16x32_BF16(W[0], B1[0], c1);
+                }
+                if constexpr (sr < ROUNDS) {
+                    stage_piece(pc, sv[sr], ph, sp);
+                    MI355_UNROLL
+                    for (int x = 0; x < 12; ++x) {
+                        SCHED_GROUP(0x8, 1);
+                        SCHED_GROUP(0x2, 3);
+                    }
+                    if constexpr (pc == 3) {
+                        SCHED_FENCE();
+                        stage_load(im2, sr, sv[sr]);
+                    }
+                }
+                SCHED_FENCE();
+            });
+            // this pair is complete: bias, the four phases of a channel as two 8-byte stores per tile (n = 4 i - 2 + phase)
+            MI355_UNROLL
+            for (int e = 0; e < 2; ++e) {
+                const f32x4& c = e == 0 ? c0 : c1;
+                const int il = 16 * (2 * jp + e) + n;  // position inside the item
+                const int i = im.t0 + il;
+                const bool on = il < NPOS && i < a.T;
+                const int ch = m0 >> 2, n0 = 4 * i - 2;
+                const unsigned o0 = (on && i >= 1) ? 4u * (unsigned)(ch * a.y_ld + n0) : BUF_OOB;
+                const unsigned o1 = (on && n0 + 3 < a.shuf_T) ? 4u * (unsigned)(ch * a.y_ld + n0 + 2) : BUF_OOB;
+                buf_store_f2(ybuf, o0, 0u, c[0] + bia[0], c[1] + bia[1]);
+                buf_store_f2(ybuf, o1, 0u, c[2] + bia[2], c[3] + bia[3]);
+            }
+        });
+        __syncthreads();
+        cur = other;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 inline bool rbc_shape(int K, int dil) {  // the "_low" voices' stage-0 convs (instantiated tap / dilation pairs)
@@ -666,14 +886,9 @@ void pack_conv_weights_p16n(const float* w, int Cout, int Cin, int K, uint32_t* 
                 }
 }
 
-// 128 -> 64 (x 8): 0.35 -> 0.26 ms per launch at the bench shape.  64 -> 32 (x 4) measured EQUAL to the staged polyphase kernel
-// (0.39 vs 0.38 - 0.42 ms: 1.2 GB of HBM traffic per launch against 0.15 ms of matrix work, and a half's loads are only one short
-// phase ahead of their use); that form stays in the lab build and the CPU model (MI355VITS_UPS_PL64=1) as the A/B of this statement.
 bool ups_pl_supported(const ConvArgs& a) {
-    bool s4 = false;
-#if defined(MI355_LAB) || defined(MI355_EMU)
-    s4 = a.Cin == 64 && a.shuf_s == 4 && lab_getenv("MI355VITS_UPS_PL64") != nullptr;
-#endif
+    bool s4 = a.Cin == 64 && a.shuf_s == 4;
+    if (lab_getenv("MI355VITS_NO_UPS64")) s4 = false;  // lab / tests: the 64 -> 32 upsampler on the staged polyphase kernel
     const bool s8 = a.Cin == 128 && a.shuf_s == 8;
     return (s8 || s4) && a.K == 2 && a.dil == 1 && a.pad == 1 && a.Cout == a.shuf_s * (a.Cin / 2) && a.shuf_cout == a.Cin / 2 && a.shuf_p == a.shuf_s / 2 &&
            a.epi == EPI_STD && a.bias && a.in_len && a.Tin >= 0 && a.T == a.Tin + 1 && a.shuf_T == a.Tin * a.shuf_s && !a.res && !a.cond && !a.relu &&
@@ -698,12 +913,11 @@ void launch_ups_pl(ConvArgs a, hipStream_t s) {
         if (wide) go(k_ups_pl<128, 8, 8>, UpsGeo<128, 8, 8>::LDS, 128);
         else go(k_ups_pl<128, 8, 2>, UpsGeo<128, 8, 2>::LDS, 32);
     } else {
-#if defined(MI355_LAB) || defined(MI355_EMU)
-        bool wide = (long)a.B * ((a.T + 255) / 256) >= cus;
+        const long n127 = (long)a.B * ((a.T + 126) / 127);
+        bool wide = n127 >= cus;
         if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;
-        if (wide) go(k_ups_pl<64, 4, 16>, UpsGeo<64, 4, 16>::LDS, 256);
-        else go(k_ups_pl<64, 4, 4>, UpsGeo<64, 4, 4>::LDS, 64);
-#endif
+        if (wide) go(k_ups64<8>, Ups64Geo<8>::LDS, 127);
+        else go(k_ups64<2>, Ups64Geo<2>::LDS, 31);
     }
 }
 

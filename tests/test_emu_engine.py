@@ -775,9 +775,9 @@ def test_resblock_conv_128_channels_resident_input(emu_lib, monkeypatch):
 
 
 def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
-    """k_ups_pl (kernels_rbc.cpp): the upsamplers 128 -> 64 (x 8, k 16) and 64 -> 32 (x 4, k 8) as two-tap polyphase convs with all
-    input channels resident in LDS (half-buffers loaded one phase ahead of their stores, phase rows in blocks of 128, 16- / 8-byte
-    phase-interleaved stores) — through check_parity against the oracle at the upsampler taps, against the staged polyphase kernel
+    """k_ups_pl / k_ups64 (kernels_rbc.cpp): the upsamplers 128 -> 64 (x 8, k 16) and 64 -> 32 (x 4, k 8) as two-tap polyphase convs
+    with all input channels resident in LDS (128 -> 64: half-buffers loaded one phase ahead of their stores, phase rows in blocks of
+    128; 64 -> 32: resident weights, tile-major, two whole buffers, items of 127 positions; 16- / 8-byte phase-interleaved stores) — through check_parity against the oracle at the upsampler taps, against the staged polyphase kernel
     it replaces (MI355VITS_NO_RBC=1) within tolerance, and wide vs narrow work items BIT FOR BIT; ragged rows, first / last output
     position (the half-valid phases at both ends of a row), several items per row."""
     cfg = VitsConfig.tiny_wide(initial_channel=256)
@@ -791,7 +791,6 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
     ids = np.random.default_rng(9).integers(1, cfg.num_symbols, (2, Tx))
     lengths = np.array([Tx, Tx - 5])
     outs, taps = {}, {}
-    monkeypatch.setenv("MI355VITS_UPS_PL64", "1")  # the 64 -> 32 upsampler in this form too (CPU model / lab build: it measured equal)
     for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
         for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
             monkeypatch.delenv(k, raising=False)

@@ -180,7 +180,6 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
     for tag, env in (("default", {}), ("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
         for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
             monkeypatch.delenv(k, raising=False)
-        monkeypatch.setenv("MI355VITS_UPS_PL64", "1")  # the 64 -> 32 upsampler in the same form too (lab build only: it measured equal)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = Engine(blob, library=lab_lib, device=0)
