@@ -236,7 +236,7 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             pack_conv_weights_p16(w.data(), Cout, Cin, K, pp.data());
             c.packed_p = stage(reinterpret_cast<const float*>(pp.data()), pp.size());
         }
-        if (key.rfind("dec.ups.", 0) == 0 && epi == EPI_STD && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && K == 2) {
+        if (key.rfind("dec.ups.", 0) == 0 && epi == EPI_STD && (Cin == 64 || Cin == 128 || Cin == 256) && Cout % 128 == 0 && K == 2) {
             // polyphase upsamplers 128 -> 64 / 64 -> 32: fragments of 16-row tiles in natural row order (k_ups_pl)
             std::vector<uint32_t> pp(p16_packed_words(Cout, Cin, K));
             pack_conv_weights_p16n(w.data(), Cout, Cin, K, pp.data());

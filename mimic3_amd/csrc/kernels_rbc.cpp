@@ -889,7 +889,7 @@ void pack_conv_weights_p16n(const float* w, int Cout, int Cin, int K, uint32_t* 
 bool ups_pl_supported(const ConvArgs& a) {
     bool s4 = a.Cin == 64 && a.shuf_s == 4;
     if (lab_getenv("MI355VITS_NO_UPS64")) s4 = false;  // lab / tests: the 64 -> 32 upsampler on the staged polyphase kernel
-    const bool s8 = a.Cin == 128 && a.shuf_s == 8;
+    const bool s8 = (a.Cin == 128 || a.Cin == 256) && a.shuf_s == 8;
     return (s8 || s4) && a.K == 2 && a.dil == 1 && a.pad == 1 && a.Cout == a.shuf_s * (a.Cin / 2) && a.shuf_cout == a.Cin / 2 && a.shuf_p == a.shuf_s / 2 &&
            a.epi == EPI_STD && a.bias && a.in_len && a.Tin >= 0 && a.T == a.Tin + 1 && a.shuf_T == a.Tin * a.shuf_s && !a.res && !a.cond && !a.relu &&
            !a.accumulate && a.out_scale == 1.0f && !a.out_len && a.ksplit == 1 && a.y_ld % 4 == 0 && a.y_bs % 4 == 0 &&
@@ -907,7 +907,12 @@ void launch_ups_pl(ConvArgs a, hipStream_t s) {
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(512), lds, s, a);
     };
-    if (a.Cin == 128) {
+    if (a.Cin == 256) {  // 256 -> 128: eight row blocks over 64-column items (32 records of planes: 123 KiB)
+        bool wide = (long)a.B * ((a.T + 63) / 64) >= cus;
+        if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;  // lab / tests
+        if (wide) go(k_ups_pl<256, 8, 4>, UpsGeo<256, 8, 4>::LDS, 64);
+        else go(k_ups_pl<256, 8, 2>, UpsGeo<256, 8, 2>::LDS, 32);
+    } else if (a.Cin == 128) {
         bool wide = (long)a.B * ((a.T + 127) / 128) >= cus;
         if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;  // lab / tests
         if (wide) go(k_ups_pl<128, 8, 8>, UpsGeo<128, 8, 8>::LDS, 128);

@@ -781,13 +781,13 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
     it replaces (MI355VITS_NO_RBC=1) within tolerance, and wide vs narrow work items BIT FOR BIT; ragged rows, first / last output
     position (the half-valid phases at both ends of a row), several items per row."""
     cfg = VitsConfig.tiny_wide(initial_channel=256)
-    cfg.upsample_rates = (2, 8, 4)
-    cfg.upsample_kernel_sizes = (4, 16, 8)
-    cfg.hop_length = 64
+    cfg.upsample_rates = (8, 8, 4)  # the "_low" voices' decoder: 256 -> 128 -> 64 -> 32 channels
+    cfg.upsample_kernel_sizes = (16, 16, 8)
+    cfg.hop_length = 256
     w = W.synthetic_weights(cfg, seed=93, frames_per_id=2.0)
     blob = W.pack(cfg, w)
     Tx = 12
-    forced = np.full((2, Tx), 4, np.int32)
+    forced = np.full((2, Tx), 2, np.int32)
     ids = np.random.default_rng(9).integers(1, cfg.num_symbols, (2, Tx))
     lengths = np.array([Tx, Tx - 5])
     outs, taps = {}, {}
@@ -800,7 +800,7 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
         eng.set_math("bf16x3")
         eng.profile_enable(True)
         outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=93, weights=w, engine=eng)
-        taps[tag] = {k: eng.tap(k) for k in ("dec.ups.1", "dec.ups.2")}
+        taps[tag] = {k: eng.tap(k) for k in ("dec.ups.0", "dec.ups.1", "dec.ups.2")}
         eng.close()
     for k in taps["wide"]:
         assert np.array_equal(taps["wide"][k], taps["narrow"][k]), k

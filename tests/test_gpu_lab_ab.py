@@ -164,8 +164,8 @@ def test_mrf_row_sweeps_equal_block_kernel_bitwise_on_the_device(lab_lib, monkey
 
 
 def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
-    """k_rb_conv (the 128-channel MRF stage conv by conv, all input channels resident in LDS, kernels_rbc.cpp) and k_ups_pl (the
-    upsamplers 128 -> 64 and 64 -> 32 in the same form) on the MI355X at the full-size shapes: the stage-0 tap and the waveform against the kernels it replaces (MI355VITS_NO_RBC=1: k_mrf_fused + the staged
+    """k_rb_conv (the 128-channel MRF stage conv by conv, all input channels resident in LDS, kernels_rbc.cpp) and k_ups_pl / k_ups64 (the three
+    upsamplers in the same form) on the MI355X at the full-size shapes: the stage-0 tap and the waveform against the kernels it replaces (MI355VITS_NO_RBC=1: k_mrf_fused + the staged
     conv — another order of summation, so within tolerance on each row's own columns), and its 128- and 32-column work items BIT FOR
     BIT (the launcher picks by grid size; a row's bits must not depend on what it is batched with).  Ragged rows ending inside an
     item, a one-phoneme row."""
@@ -187,14 +187,14 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
         labels = set(eng.profile_report())
         assert ("dec.mrf_fused.s0" in labels) == (tag == "old"), (tag, labels)
-        res[tag] = eng.tap("dec.mrf.0"), out["audio"].copy(), out["lengths"].copy(), eng.tap("dec.ups.1"), eng.tap("dec.ups.2")
+        res[tag] = eng.tap("dec.mrf.0"), out["audio"].copy(), out["lengths"].copy(), eng.tap("dec.ups.1"), eng.tap("dec.ups.2"), eng.tap("dec.ups.0")
         eng.close()
     for tag in ("default", "narrow"):
-        for k in (0, 1, 3, 4):
+        for k in (0, 1, 3, 4, 5):
             assert np.array_equal(res[tag][k], res["wide"][k]), (tag, k)
     for bi in range(B):
         n = int(res["old"][2][bi])
-        for k in (0, 3, 4):  # the stage-0 MRF output and the two upsamplers that run in the same form (k_ups_pl)
+        for k in (0, 3, 4, 5):  # the stage-0 MRF output and the three upsamplers (k_ups_pl, k_ups64)
             hop = res["old"][1].shape[1] // res["old"][k].shape[2]
             assert rel_rms(res["wide"][k][bi, :, : n // hop], res["old"][k][bi, :, : n // hop]) < 2e-6, (bi, k)
         assert rel_rms(res["wide"][1][bi, :n], res["old"][1][bi, :n]) < REL_RMS_TOL, bi
