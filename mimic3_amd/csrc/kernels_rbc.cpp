@@ -1,4 +1,5 @@
-// kernels_rbc.cpp — one dense Conv1d of a 128-channel ResBlock2 (stage 0 of the HiFi-GAN decoder) in MATH_BF16X3:
+// kernels_rbc.cpp — the decoder's convs whose whole input fits LDS, in MATH_BF16X3: k_rb_conv (below), k_ups_pl and k_ups64 (the
+// polyphase upsamplers, further down).  k_rb_conv = one dense Conv1d of a 128-channel ResBlock2 (stage 0 of the HiFi-GAN decoder):
 //
 //      y[b, co, t] (+)= (res[b, co, t] + bias[co] + sum_ci sum_k W[co, ci, k] * lrelu(x[b, ci, t - pad + k dil] * mask)) * out_scale
 //
@@ -310,16 +311,17 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// The polyphase upsamplers 128 -> 64 (x 8) and 64 -> 32 (x 4) in the same form.  ConvTranspose1d(k = 2 s, stride s)
+// The polyphase upsamplers 256 -> 128 and 128 -> 64 (x 8, k = 16) in the same form.  ConvTranspose1d(k = 2 s, stride s)
 // of lrelu(x) = a two-tap stride-1 conv with s * Cout "phase rows" (kernels.h: shuf_*; row m = c s + phase): output position i,
 // row m = w'[m, :, 0] . x[:, i - 1] + w'[m, :, 1] . x[:, i], landing at y[c][i s + phase - s / 2].  A work item is (row, N output
-// positions) with all CIN input channels resident as planes (N + 1 columns); the phase rows run in blocks of 128 (8 waves x one
-// 16-row tile; 128 -> 64: four blocks per item, 64 -> 32: one), every block through the two half-buffers' k-groups.  The halves
-// are refilled as in k_rb_conv, except that a half's loads are issued one phase before its stores (a phase is only two or four
-// steps here): half 1 of an item is stored during its first phase (loaded during the previous item's last one), half 0 of the
-// NEXT item during its last phase (loaded during the one before).  Weights in natural row order (pack_conv_weights_p16n), so a
-// wave's 16 rows are two channels x 8 phases (four channels x 4): lanes q = 0, 1 (r = 0..3) write adjacent 16 bytes and a store
-// instruction covers whole 512-byte runs of y.
+// positions) with all CIN input channels resident as planes (N + 1 columns; 128 channels: N = 128, 256 channels: N = 64); the
+// phase rows run in blocks of 128 (8 waves x one 16-row tile; four / eight blocks per item), every block through the two
+// half-buffers' k-groups.  The halves are refilled as in k_rb_conv, except that a half's loads are issued one phase before its
+// stores (a phase is only four or eight steps here): half 1 of an item is stored during its first phase (loaded during the
+// previous item's last one), half 0 of the NEXT item during its last phase (loaded during the one before), with a barrier in
+// front of that phase as well — every wave must be done with the item's last pass over half 0.  Weights in natural row order
+// (pack_conv_weights_p16n), so a wave's 16 rows are two channels x 8 phases: lanes q = 0, 1 (r = 0..3) write adjacent 16 bytes and a
+// store instruction covers whole 512-byte runs of y.  (The 64 -> 32 upsampler, x 4, has its own kernel below: k_ups64.)
 template <int I, int NN, typename F>
 __device__ __forceinline__ void rbc_static_for(F&& f) {
     if constexpr (I < NN) {
