@@ -45,7 +45,8 @@ static inline void buf_store_f4(const BufRsrc& r, unsigned voff, unsigned soff, 
 static inline void buf_store_f2(const BufRsrc& r, unsigned voff, unsigned soff, float a, float b) {
     if (voff < BUF_OOB) { float* p = reinterpret_cast<float*>(r.p + voff + soff); p[0] = a; p[1] = b; }
 }
-static inline uint4 buf_load_u4(const BufRsrc& r, unsigned voff, unsigned soff) {  // 16 bytes (weight fragments)
+static inline uint4 buf_load_u4(const BufRsrc& r, unsigned voff, unsigned soff) {  // 16 bytes (weight fragments, column groups)
+    if (voff >= 0x80000000u) return uint4{0u, 0u, 0u, 0u};
     return *reinterpret_cast<const uint4*>(r.p + voff + soff);
 }
 #else
