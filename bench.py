@@ -7,10 +7,12 @@ own timed region, mimic3_tts/voice.py:229-232).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --gpus N --single-process        # one process, N devices (the unchanged mimic3-server's shape)
 
-A "step" is one pass of the hot path over one batch of synthetic phoneme ids.  Workload (weak scaling):
-every GPU synthesises ``--batch`` (default 32) independent utterances of 128 phoneme ids, durations forced
-to 6 frames/id -> 768 latent frames = 196,608 samples = 8.916 s per utterance (SURVEY.md §8d "unit S");
-8 GPUs x 32 = the batch-256 configuration of BASELINE.json.
+A "step" is one pass of the hot path over the job's batch of synthetic phoneme ids.  Workload: BASELINE.json's
+batch of 256 independent utterances of 128 phoneme ids, durations forced to 6 frames/id -> 768 latent frames =
+196,608 samples = 8.916 s per utterance (SURVEY.md §8d "unit S"), sharded by utterance over the GPUs: all 256 on the
+one GPU at ``--gpus 1`` (the configuration the metric names; ``value`` IS the batch-256 number), 256 / N per GPU at
+``--gpus N`` (32 each on eight: BASELINE configs[3]) — strong scaling of a fixed job, no collective on the data path.
+``--batch B`` fixes the per-GPU batch instead (weak scaling; ``--batch 32`` = rounds 1-4's headline shape).
 
 Timed region = what the reference times around ``run`` + int16: phoneme ids start in host memory (1 KiB per
 utterance), the int16 result ENDS in host memory (pinned buffers recycled by the library, D2H inside the
@@ -27,7 +29,10 @@ The JSON line also carries
   "host_ms_per_step" — one handle driven sequentially: call wall time vs device time
   "cpu_baseline" — the PyTorch-CPU oracle (onnxruntime is not installed here) timed on this host's cores on
                    a bounded sample of the same workload (rank 0, N = 1 only), with the engine checked against it
-  "extra"        — vctk_low b32 (configs[2]), the whole batch-256 configuration on ONE GPU, long-form streaming (configs[4]:
+  first level    — the metric's other configurations as NUMBERS: latency_b1_ms / b1_x_realtime / b1_launches (configs[1]), b256_ms,
+                   b32_ms / b32_samples_per_s (the 32-row shard of the eight-GPU run on this one device), longform_first_audio_ms /
+                   longform_total_ms (configs[4]), probe_* (the box probe: L2-hit stream GB/s, L2-hit latency, HBM copy GB/s)
+  "extra"        — vctk_low b32 (configs[2]), the 32-row shard on ONE GPU with its kernel table, long-form streaming (configs[4]:
                    120 sentences through mimic3_amd.streaming on one session, default math and bf16 weights), the f32-MFMA /
                    bf16-weights / f16x2 math modes; they run after the headline's handles are closed (open idle handles alias
                    HIP streams onto shared hardware queues: tools/floor_diag2.py).
@@ -337,7 +342,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of about 3 s)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="utterances per GPU per step.  Default: BASELINE's batch 256 divided over the GPUs (256 on one GPU — the "
+                         "configuration the metric names —, 32 each on eight: strong scaling of a fixed job); given explicitly, every "
+                         "GPU gets that many whatever --gpus is (weak scaling)")
     ap.add_argument("--tx", type=int, default=128)
     ap.add_argument("--frames-per-id", type=int, default=6)
     ap.add_argument("--voice", choices=["apope_low", "vctk_low"], default="apope_low",
@@ -356,6 +364,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the device-only and vctk_low legs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes that measure roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU-baseline sample")
+    ap.add_argument("--no-preheat", action="store_true",
+                    help="skip the untimed pre-heat steps in front of the warm-up (rounds 1-3 and the driver's BENCH_r01-r03 were "
+                         "measured without them; the JSON says which protocol ran: device.preheat)")
     args = ap.parse_args()
 
     import torch
@@ -387,9 +398,17 @@ def main():
     weights = W.synthetic_weights(cfg, seed=1234)
     devices = list(range(args.gpus)) if single else [local_rank]
     n_gpus = args.gpus if single else world
-    B, Tx, fpi = args.batch, args.tx, args.frames_per_id
+    # BASELINE.json: "... batch=1 and batch=256"; configs[3]: "batch=256 sharded across 8 x MI355X".  One step = one pass over the
+    # job's 256 utterances: all of them on the one GPU at --gpus 1, 256 / N per GPU at --gpus N (strong scaling of the fixed job)
+    strong = args.batch is None
+    if strong and 256 % n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} does not divide BASELINE's batch of 256: pass --batch (utterances per GPU)")
+    B, Tx, fpi = (256 // n_gpus if strong else args.batch), args.tx, args.frames_per_id
+    # handles in flight per GPU: a 256-row batch fills the chip for 68 ms and takes 27 GB of workspace per handle — two overlap the
+    # text side of one batch with the decoder of the other just as well as three
+    n_streams = max(1, args.streams) if B < 128 else min(2, max(1, args.streams))
     # single-process: every step of every device is one batch of B utterances; the job's step = n_gpus batches
-    wl = Workload(cfg, weights, devices, args.streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
+    wl = Workload(cfg, weights, devices, n_streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
                   math=args.math)
     eng = wl.engines[0]
     math = wl.math
@@ -424,12 +443,19 @@ def main():
     # pre-heat: a device that idled through model load starts at its idle clock state and takes a few hundred ms of load to
     # reach the loaded one; W = 5 warm-up steps are 50 ms.  The same steps, untimed, until the shader clock has been steady
     # for 0.2 s (or 1.5 s at most; 0.5 s when the clock cannot be read) — recorded in "device.preheat", never part of `value`
-    preheat = {"seconds": 0.0, "steps": 0}
+    preheat = {"seconds": 0.0, "steps": 0, "enabled": not args.no_preheat}
     t_ph = time.perf_counter()
     hist = []
-    while True:
-        wl.run_steps(max(1, args.streams) * (n_gpus if single else 1))
-        preheat["steps"] += max(1, args.streams)
+    box_probe = None
+    if rank == 0:
+        try:  # ~10 ms: what this lease's chip gives the kernels' access patterns (include/mi355vits.h mi355vits_probe_device)
+            from mimic3_amd._native import default_library
+            box_probe = default_library().probe_device(local_rank)
+        except Exception as ex:  # noqa: BLE001 - diagnostics only
+            box_probe = {"error": str(ex)[:100]}
+    while not args.no_preheat:
+        wl.run_steps(n_streams * (n_gpus if single else 1))
+        preheat["steps"] += n_streams
         el_ph = time.perf_counter() - t_ph
         clk = mon.snapshot().get("sclk_mhz") if mon.dir else None
         hist.append((el_ph, clk))
@@ -443,7 +469,7 @@ def main():
         if el_ph >= 1.5:
             break
     preheat["seconds"] = time.perf_counter() - t_ph
-    preheat["sclk_mhz_first_last"] = [hist[0][1], hist[-1][1]]
+    preheat["sclk_mhz_first_last"] = [hist[0][1], hist[-1][1]] if hist else None
     barrier()
     mon.start()  # (sampling starts with the warm-up steps; it reads two sysfs files every 10 ms)
     elapsed, out = timed(wl, calls, args.warmup * (n_gpus if single else 1))
@@ -463,7 +489,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32" if math == "f32" else (
             "f32 in / out / accumulate; dense-conv operands as 2 x fp16 terms (22 significant bits, 3 f16-MFMA products per multiply-add), "
@@ -473,11 +499,12 @@ def main():
         "math": math,
         "data": f"synthetic (seeded random-init weights of the {args.voice} shapes, seeded phoneme ids)",
         "config": {
-            "workload": (f"{'en_UK/apope_low' if args.voice == 'apope_low' else 'en_US/vctk_low'}, {B} utt/GPU x {Tx} ids x {fpi} frames/id = "
-                         f"{Tx * fpi * cfg.hop_length} samples each: the per-GPU shard of BASELINE batch {B * 8} on 8 GPUs")[:127],
-            "global_batch": B * n_gpus, "phonemes": Tx, "frames": Tx * fpi,
+            "workload": (f"{'en_UK/apope_low' if args.voice == 'apope_low' else 'en_US/vctk_low'} batch {B * n_gpus}"
+                         + (" (BASELINE's batch=256)" if B * n_gpus == 256 else "") + f" on {n_gpus} GPU(s): {B} utt/GPU x {Tx} ids x {fpi} "
+                         f"frames/id = {Tx * fpi * cfg.hop_length} samples each")[:127],
+            "global_batch": B * n_gpus, "per_gpu_batch": B, "phonemes": Tx, "frames": Tx * fpi,
             "parallelism": f"batch-shard x{n_gpus}" + (" (one process, one host thread per engine handle)" if single else ""),
-            "streams_per_gpu": max(1, args.streams),
+            "streams_per_gpu": n_streams,
             "scales": [0.667, 1.0, 0.8],
             "timed_region": "host-to-host: ids H2D + run + int16 + D2H of int16 into recycled pinned buffers",
         },
@@ -487,6 +514,13 @@ def main():
         "device": {"before": dev_before, "preheat": preheat, "timed_window": dev_window},
     }
     result["config"]["device"] = DeviceMonitor.brief(dev_before, dev_window)
+    if B * n_gpus == 256:
+        result["b256_ms"] = ms_per_step  # one pass over BASELINE's batch of 256 (this run's step)
+    if box_probe:
+        result["box_probe"] = box_probe
+        for k in ("l2_stream_GBps", "l2_hit_latency_ns", "hbm_copy_GBps", "l2_stream_beside_copy_GBps", "table_24MB_stream_GBps", "latency_32MB_ns", "latency_1GiB_ns"):
+            if k in box_probe:
+                result["probe_" + k] = box_probe[k]
 
     if rank == 0:
         print(f"headline: {value:.4g} samples/s, {ms_per_step:.3f} ms/step over {elapsed:.2f} s (host-to-host)", file=sys.stderr)
@@ -502,7 +536,7 @@ def main():
             devs.append(eng.last_run_ms())
         w_ms, d_ms = float(np.median(walls[2:])) * 1e3, float(np.median(devs[2:]))
         result["host_ms_per_step"] = {"one_handle_call_ms": w_ms, "device_ms": d_ms, "host_side_ms": max(0.0, w_ms - d_ms),
-                                      "handles_in_flight": max(1, args.streams),
+                                      "handles_in_flight": n_streams,
                                       "note": "median of 10 sequential calls on one handle; host_side = call wall - device time "
                                               "between the call's first and last event"}
 
@@ -556,7 +590,12 @@ def main():
         if not args.no_roofline:
             result["latency_b1"]["launches"] = sum(r["launches_per_step"] for r in rows1)
             result["latency_b1"]["kernel_ms"] = tot1 / 3
-        # the metric's batch-1 half where the driver's record keeps it (it keeps `config`, strings up to 128 characters)
+        # the metric's batch-1 half as first-level numbers (and, as before, as a string where the driver's record keeps `config`)
+        result["latency_b1_ms"] = med * 1e3
+        result["b1_x_realtime"] = (n1 / SAMPLE_RATE) / med
+        if "launches" in result["latency_b1"]:
+            result["b1_launches"] = result["latency_b1"]["launches"]
+            result["b1_kernel_ms"] = result["latency_b1"]["kernel_ms"]
         result["config"]["batch1"] = ("%.3f ms host-to-host = %.0f x real time (180 ids -> 991 frames = 11.5 s), %s launches, kernels %s ms" % (
             med * 1e3, (n1 / SAMPLE_RATE) / med, result["latency_b1"].get("launches", "?"),
             ("%.3f" % result["latency_b1"]["kernel_ms"]) if "kernel_ms" in result["latency_b1"] else "?"))[:127]
@@ -615,28 +654,36 @@ def main():
             print_table("vctk_low b32, per-kernel (HIP events):", tablev[:12])
         result["extra"] = {"vctk_low_b32": extra}
         vw.close()
-        # ---- BASELINE.json `metric`: "... batch=1 and batch=256": the whole batch-256 configuration on ONE device (configs[3]
-        # shards it 8 x 32; it also fits one MI355X: about 27 GB of workspace per handle)
-        bigw = Workload(cfg, weights, devices, min(2, max(1, args.streams)), 256, Tx, fpi, 0, 1, multispeaker_sid=cfg.is_multispeaker,
-                        math=args.math)
-        bigw.size_workspaces()
-        bsteps = max(8, args.steps // 16)
-        el_g, out_g = timed(bigw, bsteps, 2)
+        # ---- the other end of configs[3]'s curve on this one device: the 32-row shard a GPU gets when the batch of 256 is spread over
+        # eight (headline at --gpus 1: all 256 rows here), or — when --batch made the shard the headline — the whole 256 on one GPU
+        ob = 32 if B != 32 else 256
+        ow = Workload(cfg, weights, devices, max(1, args.streams) if ob < 128 else min(2, max(1, args.streams)), ob, Tx, fpi, 0, 1,
+                      multispeaker_sid=cfg.is_multispeaker, math=args.math)
+        ow.size_workspaces()
+        osteps = max(60, args.steps) if ob == 32 else max(8, args.steps // 16)
+        el_g, out_g = timed(ow, osteps, 10 if ob == 32 else 2)
         spb = int(out_g["lengths"].sum())
-        big = {"workload": f"en_UK/apope_low, 256 utterances x {Tx} phoneme ids on ONE GPU, forced {fpi} frames/id; host-to-host",
-               "value": spb * bsteps / el_g, "unit": "samples/s", "steps": bsteps, "ms_per_step": el_g / bsteps * 1e3,
-               "x_realtime": (spb / SAMPLE_RATE) / (el_g / bsteps), "math": math, "global_batch": 256}
+        oleg = {"workload": f"en_UK/apope_low, {ob} utterances x {Tx} phoneme ids on ONE GPU, forced {fpi} frames/id; host-to-host",
+                "value": spb * osteps / el_g, "unit": "samples/s", "steps": osteps, "ms_per_step": el_g / osteps * 1e3,
+                "x_realtime": (spb / SAMPLE_RATE) / (el_g / osteps), "math": math, "global_batch": ob}
         if not args.no_roofline:
-            repg, tableg, totg = kernel_table(bigw.engines[0], lambda i: bigw.step(i, device_only=True), 2)
-            big["roofline"] = roofline_of(repg, tableg, totg, 2, [256, Tx, fpi], args.voice, math)
-        result["extra"]["apope_low_b256_1gpu"] = big
-        result["config"]["batch256_1gpu"] = ("%.4g samples/s = %.2f ms per 256 utterances on ONE GPU (%.0f x real time), %d steps" % (
-            big["value"], big["ms_per_step"], big["x_realtime"], bsteps))[:127]
-        bigw.close()
+            repg, tableg, totg = kernel_table(ow.engines[0], lambda i: ow.step(i, device_only=True), 3 if ob == 32 else 2)
+            oleg["roofline"] = roofline_of(repg, tableg, totg, 3 if ob == 32 else 2, [ob, Tx, fpi], args.voice, math)
+            oleg["kernels_ms_per_step"] = {r["kernel"]: round(r["ms_per_step"], 4) for r in tableg[:16]}
+        result["extra"]["apope_low_b%d_1gpu" % ob] = oleg
+        result["b%d_ms" % ob] = oleg["ms_per_step"]
+        result["b%d_samples_per_s" % ob] = oleg["value"]
+        result["config"]["batch%d_1gpu" % ob] = ("%.4g samples/s = %.2f ms per %d utterances on ONE GPU (%.0f x real time), %d steps" % (
+            oleg["value"], oleg["ms_per_step"], ob, oleg["x_realtime"], osteps))[:127]
+        ow.close()
         # ---- BASELINE.json configs[4]: long-form text streamed sentence by sentence, default math and bf16 weights
         lf = {"default": longform_stream(cfg, weights, args.math), "bf16w": longform_stream(cfg, weights, "bf16w")}
         lf["lengths_equal_across_modes"] = lf["default"].pop("det_lengths") == lf["bf16w"].pop("det_lengths")
         result["extra"]["longform_stream"] = lf
+        result["longform_first_audio_ms"] = lf["default"]["first_audio_ms"]
+        result["longform_total_ms"] = lf["default"]["total_ms"]
+        result["longform_bf16w_first_audio_ms"] = lf["bf16w"]["first_audio_ms"]
+        result["longform_bf16w_total_ms"] = lf["bf16w"]["total_ms"]
         result["config"]["longform_stream"] = (
             "120 sentences %.0f s audio: first audio %.1f ms, all in %.0f ms = %.0f x RT; bf16w %.1f / %.0f ms; chunks==calls %s, lengths== %s" % (
                 lf["default"]["audio_s"], lf["default"]["first_audio_ms"], lf["default"]["total_ms"], lf["default"]["x_realtime"],

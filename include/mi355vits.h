@@ -203,8 +203,11 @@ long mi355vits_list_taps(mi355vits_handle h, char* buf, size_t cap);
 /* Kernel unit-test hook: one Conv1d through a chosen implementation on host buffers.
  * impl: 0 = generic VALU kernel, 1 = fp32-MFMA kernel, 2 = split-bf16 staged kernel (MI355VITS_MATH_BF16X3; needs
  * Cin % 32 == 0 and T > 512), 3 = the text encoder's slice kernel (MI355VITS_MATH_BF16X3; Cin % 192 == 0, K in {1, 3}, dilation
- * 1; Cin > 192: the raw sums of the 192-channel slices added up, no bias / residual).  See tests/test_gpu_parity.py,
- * tests/test_emu_engine.py. */
+ * 1; Cin > 192: the raw sums of the 192-channel slices added up, no bias / residual), 4 = the 128-channel resblock conv with
+ * every input channel resident in LDS (MI355VITS_MATH_BF16X3; Cin = Cout = 128, (K, dilation) in {(3,1), (3,2), (5,2), (5,6),
+ * (7,3), (7,12)}, needs res and in_len).  mi355vits_test_conv_transpose1d: impl 0 = generic, 1 = f32-MFMA polyphase, 2 = the
+ * staged split-bf16 polyphase kernels, 3 = the resident-input polyphase kernels (256 -> 128 and 128 -> 64 with stride 8 / K 16,
+ * 64 -> 32 with stride 4 / K 8).  See tests/test_gpu_parity.py, tests/test_emu_engine.py. */
 typedef struct mi355vits_conv_test {
     int32_t impl, B, Cin, Cout, T, K, dilation;
     const float* x;       /* [B,Cin,T] */
@@ -231,6 +234,14 @@ int mi355vits_bench_conv1d(int device, int B, int Cin, int Cout, int T, int K, i
 /* MFMA fragment-layout self test: returns 0 when the 32x32x2 and 16x16x4 f32 MFMA lane maps
  * assumed by the kernels hold on this device; max abs error in *err. */
 int mi355vits_test_mfma_layout(int device, float* err);
+/* Box probe (bench.py: the numbers ride in the JSON line so that a slow lease can be told from a slow kernel; ~30 ms, 1 GiB of
+ * scratch): out[0] = GB/s all CUs together reach streaming ONE 2.6 MB table out of the L2 with 16-byte buffer loads (the
+ * weight-fragment pattern of the WaveNet / resident-input kernels), out[1] = ns per dependent vector load over 2 MB (L2 hits),
+ * out[2] = GB/s (read + written) of a 256 MiB HBM copy, out[3] = compute units, out[4] = the table stream of out[0] again while
+ * every workgroup also copies its slice of 256 MiB through the same L2 (8 bytes of table per byte of copy: what the cache sees of a
+ * weight-streaming kernel), out[5] = GB/s streaming a 24 MB table (fits the memory-side cache, not an XCD's L2), out[6] / out[7] =
+ * ns per dependent load over 32 MB (memory-side cache) / 1 GiB (HBM, mostly TLB misses). */
+int mi355vits_probe_device(int device, double out[8]);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "mi355vits_get_config", "mi355vits_run", "mi355vits_fetch", "mi355vits_free_result",
     "mi355vits_last_error", "mi355vits_profile_enable", "mi355vits_profile_reset",
     "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_list_taps",
-    "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout", "mi355vits_bench_conv1d",
+    "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout", "mi355vits_bench_conv1d", "mi355vits_probe_device",
 )
 
 
@@ -141,6 +141,7 @@ class NativeLibrary:
             ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
         L.mi355vits_test_mfma_layout.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.mi355vits_bench_conv1d.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_float)]
+        L.mi355vits_probe_device.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
 
     def version(self) -> str:
         return self.lib.mi355vits_version().decode()
@@ -199,6 +200,16 @@ class NativeLibrary:
         if rc != 0:
             raise NativeError(rc, self.create_error())
         return float(ms.value)
+
+    def probe_device(self, device=0) -> dict:
+        """The box probe: what this lease's chip gives the kernels' access patterns (include/mi355vits.h)."""
+        out = (ctypes.c_double * 8)()
+        rc = self.lib.mi355vits_probe_device(device, out)
+        if rc != 0:
+            raise RuntimeError(f"mi355vits_probe_device failed: rc={rc}")
+        return {"l2_stream_GBps": round(out[0], 1), "l2_hit_latency_ns": round(out[1], 1), "hbm_copy_GBps": round(out[2], 1), "cus": int(out[3]),
+                "l2_stream_beside_copy_GBps": round(out[4], 1), "table_24MB_stream_GBps": round(out[5], 1),
+                "latency_32MB_ns": round(out[6], 1), "latency_1GiB_ns": round(out[7], 1)}
 
     def test_mfma_layout(self, device=0) -> float:
         err = ctypes.c_float(-1.0)

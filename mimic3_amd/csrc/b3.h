@@ -59,6 +59,68 @@ __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NA], const uint4* con
     }
 }
 
+// b3_chunk with the WEIGHT fragments RA - 1 groups ahead instead of one (a ring of RA buffers, NG % RA == 0 so that the ring
+// position of a group is the same in every tap): a group of the 3 x 3-tile WaveNet loop is 54 MFMAs = 0.85 us, and one group of
+// prefetch covers an L2 hit but not a fragment that the layer's activation stream has pushed out of the XCD's L2 (refetched from
+// the memory-side cache / HBM: ~1 - 2 us) — on the boxes where that happens often every weight-streaming kernel runs 20 - 50 %
+// slower (BENCH_r03 / r04, profiles/r05_*).  The activation fragments (LDS) stay one group ahead.  Same products in the same order
+// per accumulator as b3_chunk: bit-identical.
+template <int MT, int NT, int NG, int NA, bool W1, int RA>
+__device__ __forceinline__ void b3_chunk_ra(f32x16 (&acc)[MT][NA], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS, int LD,
+                                            int K, int groups_per_tap, int dil) {
+    static_assert(RA >= 2 && NG % RA == 0 && RA - 1 <= NG, "ring of RA weight-fragment buffers");
+    uint4 ra[RA][MT][3];
+    uint4 rb[2][NT][3];
+    constexpr int NPA = W1 ? 1 : 3;
+    constexpr int D = RA - 1;  // groups ahead
+    // linear group index n = k * NG + g of the K * NG groups; past the last one: the last again (every load unconditional)
+    const int ntot = K * NG;
+    auto load_a = [&](int n, uint4 (&dst)[MT][3]) MI355_INLINE_LAMBDA {
+        const int nc = n < ntot ? n : ntot - 1;
+        const int k = nc / NG, g = nc - k * NG;
+        const long woff = ((long)k * groups_per_tap + g) * 192;
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i)
+            MI355_UNROLL
+            for (int p = 0; p < NPA; ++p) dst[i][p] = wp[i][woff + p * 64];
+    };
+    MI355_UNROLL
+    for (int d = 0; d < D; ++d) load_a(d, ra[d]);
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j)
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) rb[0][j][p] = xq[p * PS + j * 32];
+    for (int k = 0; k < K; ++k) {
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            const bool wrap = g + 1 == NG;
+            const int xoff = wrap ? (last_tap ? k * dil + g * 2 * LD : (k + 1) * dil) : k * dil + (g + 1) * 2 * LD;
+            load_a(k * NG + g + D, ra[(g + D) % RA]);
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j)
+                MI355_UNROLL
+                for (int p = 0; p < 3; ++p) rb[nxt][j][p] = xq[p * PS + xoff + j * 32];
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int i = 0; i < MT; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j) {
+                    f32x16 c = acc[i][j];
+                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[g % RA][i][2], rb[cur][j][0], c);  // small terms first
+                    c = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[cur][j][2], c);
+                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[g % RA][i][1], rb[cur][j][1], c);
+                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[g % RA][i][1], rb[cur][j][0], c);
+                    c = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[cur][j][1], c);
+                    c = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[cur][j][0], c);
+                    acc[i][j] = c;
+                }
+            SCHED_FENCE();
+        }
+    }
+}
+
 // MATH_F16X2 form of b3_chunk: two fp16 planes per operand (hipx.h: split2), three products on v_mfma_f32_32x32x16_f16.
 // A group of weight fragments is 128 uint4 (two planes x 64 lanes); the activation planes are [2][group][half][column].
 template <int MT, int NT, int NG, int NA = NT>

@@ -271,6 +271,16 @@ int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t) {
                 }
                 return;
             }
+        } else if (t->impl == 4) {  // the 128-channel resblock conv with every input channel resident (k_rb_conv / k_rb_conv_pw)
+            if (!rb_conv_supported(a)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the resident-input kernel");
+            std::vector<uint32_t> pp(p16_packed_words(t->Cout, t->Cin, t->K));
+            pack_conv_weights_p16(t->w, t->Cout, t->Cin, t->K, pp.data());
+            DevBuf dpp(pp.size() * 4);
+            HIP_CHECK(hipMemcpy(dpp.p, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
+            a.w = dpp.as<float>();
+            a.math = MATH_BF16X3;
+            launch_rb_conv(a, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
         } else if (t->impl == 1 || t->impl == 2) {
             if (!conv1d_mfma_supported(t->Cin, t->Cout, t->K, t->dilation)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the MFMA kernel");
             packed.resize(mfma_packed_floats(t->Cout, t->Cin, t->K));
@@ -310,7 +320,32 @@ int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Co
         const size_t nx = (size_t)B * Cin * Tin, ny = (size_t)B * Cout * Tin * stride, nw = (size_t)Cin * Cout * K;
         DevBuf dx(nx * 4), dy(ny * 4), dw(nw * 4), db(Cout * 4);
         HIP_CHECK(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
-        if (impl == 1 || impl == 2) {
+        if (impl == 3) {
+            // the resident-input polyphase kernels (k_ups_pl: 256 -> 128, 128 -> 64; k_ups64: 64 -> 32), MATH_BF16X3; a valid length per
+            // row is part of their contract (the engine always has one): every row at full length here
+            const int taps = convt_taps(K, stride);
+            std::vector<float> wv((size_t)stride * Cout * Cin * taps), bv((size_t)stride * Cout);
+            convt_to_polyphase(w, bias, Cin, Cout, K, stride, wv.data(), bv.data());
+            std::vector<uint32_t> pp(p16_packed_words(stride * Cout, Cin, taps));
+            pack_conv_weights_p16n(wv.data(), stride * Cout, Cin, taps, pp.data());
+            std::vector<int> lens((size_t)B, Tin);
+            DevBuf dpp(pp.size() * 4), dbias(bv.size() * 4), dlen((size_t)B * 4);
+            HIP_CHECK(hipMemcpy(dpp.p, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dbias.p, bv.data(), bv.size() * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dlen.p, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+            ConvArgs u;
+            u.x = dx.as<float>(); u.x_bs = (long)Cin * Tin; u.x_ld = Tin;
+            u.y = dy.as<float>(); u.y_bs = (long)Cout * Tin * stride; u.y_ld = Tin * stride;
+            u.w = dpp.as<float>(); u.bias = dbias.as<float>(); u.in_len = dlen.as<int>();
+            u.Cin = Cin; u.Cout = stride * Cout; u.K = taps; u.dil = 1;
+            u.in_slope = in_slope; u.pad = taps - 1; u.Tin = Tin;
+            u.shuf_s = stride; u.shuf_p = (K - stride) / 2; u.shuf_cout = Cout; u.shuf_T = Tin * stride;
+            u.B = B; u.T = Tin + taps - 1;
+            u.math = MATH_BF16X3;
+            if (!ups_pl_supported(u)) throw EngineError(MI355VITS_ERR_INVALID, "shape not supported by the resident-input polyphase kernels");
+            launch_ups_pl(u, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        } else if (impl == 1 || impl == 2) {
             // polyphase filters on the MFMA conv kernel (the path Engine uses); impl 2: the split-bf16 staged kernels
             // (MATH_BF16X3; 64-channel chunks run the persistent producer / consumer form)
             const int taps = convt_taps(K, stride);
@@ -409,6 +444,56 @@ int mi355vits_bench_conv1d(int device, int B, int Cin, int Cout, int T, int K, i
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         *ms_per_launch = ms / reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    });
+}
+
+int mi355vits_probe_device(int device, double out[8]) {
+    return guarded(nullptr, [&] {
+        if (!out) throw EngineError(MI355VITS_ERR_INVALID, "bad arguments");
+        HIP_CHECK(hipSetDevice(device));
+        const int cus = current_device_cu_count();
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        auto timed = [&](auto&& launch, int warm, int reps) {
+            for (int i = 0; i < warm; ++i) launch();
+            HIP_CHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < reps; ++i) launch();
+            HIP_CHECK(hipEventRecord(e1, nullptr));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            return (double)ms / reps;
+        };
+        // one zero-filled GiB serves everything: [0, 2.6 MB) the L2 table, [0, 24 MB) the big table, the halves as copy source / destination
+        const size_t gib = (size_t)1 << 30;
+        DevBuf mem(gib), sink((size_t)cus * 4 + 16);
+        HIP_CHECK(hipMemset(mem.p, 0, gib));
+        const int n16 = 256 * 8 * 80;  // 163,840 x 16 B = 2.62 MB
+        const int reps_in = 8;
+        const double ms_stream = timed([&] { launch_probe_l2_stream(mem.p, n16, reps_in, sink.as<unsigned>(), cus, nullptr); }, 1, 3);
+        out[0] = (double)cus * reps_in * n16 * 16.0 / (ms_stream * 1e-3) / 1e9;
+        const int steps = 2000;
+        auto chase = [&](unsigned nlines, int warm) {
+            const double ms = timed([&] { launch_probe_l2_latency(mem.as<unsigned>(), steps, nlines, sink.as<unsigned>(), cus, nullptr); }, warm, 2);
+            return ms * 1e6 / steps;
+        };
+        out[1] = chase(1u << 15, 2);   // 2 MB: after two passes every XCD's L2 holds what its waves touch
+        out[6] = chase(1u << 19, 2);   // 32 MB: past an L2, inside the memory-side cache
+        out[7] = chase(1u << 24, 1);   // 1 GiB: HBM (and the TLB's reach)
+        const long ncopy16 = (256L << 20) / 16;
+        char* base = static_cast<char*>(mem.p);
+        const double ms_copy = timed([&] { launch_probe_copy(base, base + gib / 2, ncopy16, cus * 16, nullptr); }, 1, 3);
+        out[2] = 2.0 * ncopy16 * 16.0 / (ms_copy * 1e-3) / 1e9;
+        out[3] = (double)cus;
+        const long slice16 = ncopy16 / cus;
+        const double ms_mixed = timed([&] { launch_probe_l2_mixed(mem.p, n16, reps_in, base + gib / 4, base + gib / 2, slice16, sink.as<unsigned>(), cus, nullptr); }, 1, 3);
+        out[4] = (double)cus * reps_in * n16 * 16.0 / (ms_mixed * 1e-3) / 1e9;
+        const int big16 = n16 * 9;
+        const double ms_big = timed([&] { launch_probe_l2_stream(mem.p, big16, 1, sink.as<unsigned>(), cus, nullptr); }, 1, 3);
+        out[5] = (double)cus * big16 * 16.0 / (ms_big * 1e-3) / 1e9;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     });

@@ -303,5 +303,10 @@ void launch_speaker_cond(const float* emb_g, const long long* sid, const float* 
 // misc
 void launch_fill(float* p, float v, size_t n, hipStream_t s);
 void launch_mfma_selftest(float* out /*[32*32 + 16*16 + 16*16]*/, hipStream_t s);
+// box probe (mi355vits_probe_device): L2-hit 16-byte stream of one table by every CU, L2-hit dependent-load chain, HBM copy
+void launch_probe_l2_stream(const void* tbl, int n16, int reps, unsigned* sink, int grid, hipStream_t s);
+void launch_probe_l2_latency(const unsigned* chain, int steps, unsigned nlines, unsigned* out, int grid, hipStream_t s);
+void launch_probe_copy(const void* src, void* dst, long n16, int grid, hipStream_t s);
+void launch_probe_l2_mixed(const void* tbl, int n16, int reps, const void* src, void* dst, long slice16, unsigned* sink, int grid, hipStream_t s);
 
 }  // namespace m355

@@ -1951,12 +1951,150 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh_vec(const float* __restr
     }
 }
 
+// Round 5: the same conv with (nearly) every byte of x requested ONCE.  k_conv_post_tanh_vec gives a lane eight consecutive samples and
+// has it read x[t - 4 .. t + 11] as four 16-byte loads per channel: lanes 32 bytes apart, so every wave-load touches 32 64-byte
+// segments at half use and a channel costs 128 segment accesses for 33 segments of data — and its lane-dependent `inner` test sits
+// between the loads and their use, so hipcc drains the memory counter (vmcnt(0)) once per channel: 3.6 TB/s.  Here a wave owns NT
+// tiles; per channel and tile a lane loads ONE float4 (a wave-load = 1 KiB contiguous) and gets the three samples either side from
+// its neighbours through DPP wave shifts (v_mov_b32 wave_shr:1 / wave_shl:1 — one VALU each, no LDS).  Lanes 0 and 63 only SUPPLY
+// halo: a tile produces the 248 samples of lanes 1 .. 62 and consecutive tiles overlap by two float4 (3 % of the loads instead of a
+// second, sparse halo load per tile and channel).  All loads are unconditional buffer loads (row offset in an SGPR; "before the
+// row" is a negative = out-of-range offset and reads as zero), CU channels are in flight per lane, and waves whose span lies inside
+// the row take a path without masks.  Same (channel, tap) order of the same fmaf chain: bit-identical to both kernels above.
+__device__ __forceinline__ float wave_left(float v) {   // lane l: v of lane l - 1 (lane 0: unspecified)
+#ifdef MI355_EMU
+    return __shfl_up(v, 1);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+#endif
+}
+__device__ __forceinline__ float wave_right(float v) {  // lane l: v of lane l + 1 (lane 63: unspecified)
+#ifdef MI355_EMU
+    return __shfl_down(v, 1);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+#endif
+}
+
+constexpr int CPD_NT = 2;                      // tiles per wave
+constexpr int CPD_TW = 248;                    // samples a tile produces (lanes 1 .. 62)
+constexpr int CPD_T = 4 * CPD_TW * CPD_NT;     // samples per workgroup (four waves)
+constexpr int CPD_CU = 4;                      // channels in flight per lane
+
+template <bool MASKED>
+__device__ __forceinline__ void conv_post_span(const BufRsrc xb, unsigned xrow, const float* __restrict__ w, int Cin, int ws, int vl,
+                                                float (&acc)[CPD_NT][4]) {
+    constexpr int K = 7, NT = CPD_NT, CU = CPD_CU;
+    const int lane = threadIdx.x & 63;
+    unsigned vo[NT];
+    bool mo[NT][4];
+    MI355_UNROLL
+    for (int i = 0; i < NT; ++i) {
+        const int t = ws + CPD_TW * i - 4 + 4 * lane;  // this lane's four samples of tile i
+        vo[i] = 4u * (unsigned)t;                       // (t < 0: past the buffer's 2 GiB range = zeros)
+        MI355_UNROLL
+        for (int e = 0; e < 4; ++e) mo[i][e] = t + e < vl;
+    }
+    for (int c0 = 0; c0 < Cin; c0 += CU) {
+        uint4 xo[CU][NT];
+        MI355_UNROLL
+        for (int u = 0; u < CU; ++u)
+            MI355_UNROLL
+            for (int i = 0; i < NT; ++i) xo[u][i] = buf_load_u4(xb, vo[i], (unsigned)(c0 + u) * xrow);
+        MI355_UNROLL
+        for (int u = 0; u < CU; ++u) {
+            float wv[K];
+            MI355_UNROLL
+            for (int k = 0; k < K; ++k) wv[k] = w[(c0 + u) * K + k];
+            MI355_UNROLL
+            for (int i = 0; i < NT; ++i) {
+                float o[4] = {__uint_as_float(xo[u][i].x), __uint_as_float(xo[u][i].y), __uint_as_float(xo[u][i].z), __uint_as_float(xo[u][i].w)};
+                MI355_UNROLL
+                for (int e = 0; e < 4; ++e) {
+                    if (MASKED) o[e] = mo[i][e] ? o[e] : 0.0f;
+                    o[e] = fmaxf(o[e], o[e] * 0.01f);  // leaky-relu(0.01): the bits of `o >= 0 ? o : o * 0.01f`
+                }
+                // xv[j] = lrelu(x[t - 3 + j]), j = 0 .. 9
+                float xv[10];
+                xv[0] = wave_left(o[1]);
+                xv[1] = wave_left(o[2]);
+                xv[2] = wave_left(o[3]);
+                xv[3] = o[0]; xv[4] = o[1]; xv[5] = o[2]; xv[6] = o[3];
+                xv[7] = wave_right(o[0]);
+                xv[8] = wave_right(o[1]);
+                xv[9] = wave_right(o[2]);
+                MI355_UNROLL
+                for (int k = 0; k < K; ++k)
+                    MI355_UNROLL
+                    for (int q = 0; q < 4; ++q) acc[i][q] = fmaf(wv[k], xv[q + k], acc[i][q]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_conv_post_tanh_dpp(const float* __restrict__ x, long x_bs, int x_ld, const float* __restrict__ w, int Cin,
+                                                            int L, const int* valid_len, float* __restrict__ audio, long audio_bs,
+                                                            unsigned* peak_bits) {
+    __shared__ float red[4];
+    constexpr int NT = CPD_NT;
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int b = blockIdx.y;
+    const int ws = blockIdx.x * CPD_T + wid * CPD_TW * NT;  // the first sample this wave produces
+    int vl = valid_len ? valid_len[b] : L;
+    if (vl > L) vl = L;
+    vl = WAVE_UNIFORM(vl);
+    float acc[NT][4];
+    MI355_UNROLL
+    for (int i = 0; i < NT; ++i)
+        MI355_UNROLL
+        for (int q = 0; q < 4; ++q) acc[i][q] = 0.0f;
+    const BufRsrc xb = buf_rsrc(x + (long)b * x_bs);
+    const unsigned xrow = 4u * (unsigned)x_ld;
+    if (ws - 3 < vl) {  // (a span whose every tap lies past the row's end: zeros)
+        if (ws + CPD_TW * NT + 4 <= vl) conv_post_span<false>(xb, xrow, w, Cin, ws, vl, acc);
+        else conv_post_span<true>(xb, xrow, w, Cin, ws, vl, acc);
+    }
+    float pk = 0.0f;
+    MI355_UNROLL
+    for (int i = 0; i < NT; ++i) {
+        const int t = ws + CPD_TW * i - 4 + 4 * lane;
+        if (lane >= 1 && lane <= 62 && t < L) {
+            float y[4];
+            MI355_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                y[q] = tanhf(acc[i][q]);
+                if (t + q < vl) pk = fmaxf(pk, fabsf(y[q]));
+            }
+            float* ap = audio + (long)b * audio_bs + t;
+            if (t + 3 < L) {
+                *reinterpret_cast<float4*>(ap) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+                for (int q = 0; q < 4; ++q)
+                    if (t + q < L) ap[q] = y[q];
+            }
+        }
+    }
+    pk = wave_reduce_max(pk);
+    if (lane == 0) red[wid] = pk;
+    __syncthreads();
+    if (tid == 0) {
+        pk = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(peak_bits + b, __float_as_uint(pk));
+    }
+}
+
 void launch_conv_post_tanh(const float* x, long x_bs, int x_ld, const float* w, int Cin, int K, int B, int L,
                            const int* valid_len, float* audio, long audio_bs, unsigned* peak_bits, hipStream_t s) {
     if (L <= 0 || B <= 0) return;
     static const bool no_vec = lab_getenv("MI355VITS_CONV_POST_STAGED") != nullptr;
     const bool aligned = (x_ld % 4 == 0) && (x_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                          (audio_bs % 4 == 0) && (reinterpret_cast<uintptr_t>(audio) % 16 == 0);
+    const bool no_dpp = lab_getenv("MI355VITS_CONV_POST_V1") != nullptr;  // lab / tests: the round-1 kernels
+    if (aligned && K == 7 && Cin % CPD_CU == 0 && (long)Cin * x_ld * 4 < 0x7fffffffL && !no_vec && !no_dpp) {
+        dim3 grid((L + CPD_T - 1) / CPD_T, B);
+        LAUNCH_KERNEL(k_conv_post_tanh_dpp, grid, dim3(256), 0, s, x, x_bs, x_ld, w, Cin, L, valid_len, audio, audio_bs, peak_bits);
+        return;
+    }
     if (aligned && K <= 9 && (K & 1) && !no_vec) {
         dim3 grid((L + CPV_T - 1) / CPV_T, B);
         LAUNCH_KERNEL(k_conv_post_tanh_vec, grid, dim3(256), 0, s, x, x_bs, x_ld, w, Cin, K, L, valid_len, audio, audio_bs,

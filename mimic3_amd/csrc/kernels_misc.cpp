@@ -1428,4 +1428,87 @@ void launch_speaker_cond(const float* emb_g, const long long* sid, const float* 
     LAUNCH_KERNEL(k_speaker_cond, dim3((Cout + 3) / 4, B), dim3(256), 0, s, emb_g, sid, w, bias, gin, Cout, out);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Box probe (bench.py writes its three numbers into the JSON line next to the kernel table): what a lease's chip gives the access
+// patterns the kernels depend on, measured in ~10 ms before the timed loop — a slow box can then be told from a slow kernel.
+//   (1) L2-hit stream: every CU's workgroup reads the same 2.6 MB table (the size of a WaveNet layer's weight fragments, the
+//       pattern of k_wn_layer_b3 / k_rb_conv / k_ups_pl) with buffer_load_dwordx4, eight loads in flight per lane;
+//   (2) load latency: one dependent chain of vector loads, one wave per CU, over 2 MB (L2 hits), 32 MB (memory-side cache) and
+//       1 GiB (HBM, and a TLB miss on most steps);
+//   (3) HBM copy: 256 MiB read + 256 MiB written with 16-byte accesses.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe_l2_stream(const uint4* __restrict__ tbl, int n16, int reps, unsigned* sink) {
+    const BufRsrc r = buf_rsrc(tbl);
+    unsigned acc = 0u;
+    constexpr int U = 8;
+    const int per_round = 256 * U;
+    const int rounds = n16 / per_round;  // (the table's tail past a whole round is not read)
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int k = 0; k < rounds; ++k) {
+            uint4 v[U];
+            MI355_UNROLL
+            for (int u = 0; u < U; ++u) v[u] = buf_load_u4(r, 16u * (unsigned)(k * per_round + u * 256 + (int)threadIdx.x), 0u);
+            MI355_UNROLL
+            for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[blockIdx.x] = acc;  // (keeps the loads alive)
+}
+// dependent chain of vector loads over a zero-filled region of `nlines` (a power of two) 64-byte lines: the next line is a full-period
+// LCG step of the current one PLUS the loaded word (zero — but only the memory knows), so every load waits for the one before it
+__global__ __launch_bounds__(64) void k_probe_l2_latency(const unsigned* __restrict__ chain, int steps, unsigned nlines, unsigned* out) {
+    const BufRsrc r = buf_rsrc(chain);
+    unsigned idx = (unsigned)blockIdx.x * 2654435761u;
+    for (int k = 0; k < steps; ++k) {
+        idx = idx * 1664525u + 1013904223u;
+        idx += __float_as_uint(buf_load_f32(r, 64u * (idx & (nlines - 1u)), 0u));
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = idx;
+}
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+// the same table stream with HBM traffic flowing through the L2 beside it, 8 : 1 in bytes (what the weight-streaming kernels look
+// like to the cache: a layer's fragments read by every CU again and again while the activations pass through once): per round a
+// workgroup reads 32 KB of the table, 4 KB of its own slice of `src` and writes 4 KB of `dst`
+__global__ __launch_bounds__(256) void k_probe_l2_mixed(const uint4* __restrict__ tbl, int n16, int reps, const uint4* __restrict__ src,
+                                                        uint4* __restrict__ dst, long slice16, unsigned* sink) {
+    const BufRsrc r = buf_rsrc(tbl);
+    unsigned acc = 0u;
+    constexpr int U = 8;
+    const int per_round = 256 * U;
+    const int rounds = n16 / per_round;
+    const uint4* sp = src + (long)blockIdx.x * slice16;
+    uint4* dp = dst + (long)blockIdx.x * slice16;
+    long pos = threadIdx.x;
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int k = 0; k < rounds; ++k) {
+            uint4 v[U];
+            MI355_UNROLL
+            for (int u = 0; u < U; ++u) v[u] = buf_load_u4(r, 16u * (unsigned)(k * per_round + u * 256 + (int)threadIdx.x), 0u);
+            const uint4 sv = sp[pos];
+            MI355_UNROLL
+            for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+            dp[pos] = sv;
+            pos += 256;
+            if (pos >= slice16) pos = threadIdx.x;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[blockIdx.x] = acc;
+}
+void launch_probe_l2_mixed(const void* tbl, int n16, int reps, const void* src, void* dst, long slice16, unsigned* sink, int grid, hipStream_t s) {
+    LAUNCH_KERNEL(k_probe_l2_mixed, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(tbl), n16, reps, static_cast<const uint4*>(src),
+                  static_cast<uint4*>(dst), slice16, sink);
+}
+void launch_probe_l2_stream(const void* tbl, int n16, int reps, unsigned* sink, int grid, hipStream_t s) {
+    LAUNCH_KERNEL(k_probe_l2_stream, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(tbl), n16, reps, sink);
+}
+void launch_probe_l2_latency(const unsigned* chain, int steps, unsigned nlines, unsigned* out, int grid, hipStream_t s) {
+    LAUNCH_KERNEL(k_probe_l2_latency, dim3(grid), dim3(64), 0, s, chain, steps, nlines, out);
+}
+void launch_probe_copy(const void* src, void* dst, long n16, int grid, hipStream_t s) {
+    LAUNCH_KERNEL(k_probe_copy, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
+}
+
 }  // namespace m355

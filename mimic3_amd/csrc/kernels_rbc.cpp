@@ -34,6 +34,7 @@ namespace m355 {
 namespace {
 constexpr size_t RBC_LDS_LIMIT = 160 * 1024;
 constexpr int RBC_C = 128, RBC_G = RBC_C / 32, RBC_REC = RBC_C / 8;
+constexpr int RBC_PW_DEFAULT = 1;  // wide items on the producer-wave form (k_rb_conv_pw)
 constexpr int RBC_WR = 4;  // weight-fragment ring: the running step and three ahead (the step count is a multiple of 4)
 }  // namespace
 
@@ -282,6 +283,272 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
         // ---- epilogue: (res + (acc + bias)) * scale (+ old y); columns past the tensor dropped by the range check.  The old
         // values of an accumulating conv are loaded for all tiles before the first store (a load behind a store cannot be
         // waited for without waiting for the store's acknowledgement: the memory counter retires in order)
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) acc[j][r] = (rq[j][r] + (acc[j][r] + bia[r])) * a.out_scale;
+        if (a.accumulate) {
+            MI355_UNROLL
+            for (int j = 0; j < NCT; ++j) {
+                const int t = im.t0 + 16 * j + n;
+                const int tc = t < a.T ? t : a.T - 1;
+                const unsigned oc = 4u * (unsigned)(co0 * a.y_ld + tc);
+                MI355_UNROLL
+                for (int r = 0; r < 4; ++r) rq[j][r] = buf_load_f32(ybuf, oc, (unsigned)r * yrow);
+            }
+            MI355_UNROLL
+            for (int j = 0; j < NCT; ++j)
+                MI355_UNROLL
+                for (int r = 0; r < 4; ++r) acc[j][r] += rq[j][r];
+        }
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j) {
+            const int t = im.t0 + 16 * j + n;
+            const unsigned o = t < a.T ? 4u * (unsigned)(co0 * a.y_ld + t) : BUF_OOB;
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) buf_store_f32(ybuf, o, (unsigned)r * yrow, acc[j][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_rb_conv_pw — the same conv, the same bits, with PRODUCER WAVES (round 5).  profiles/r04_rbc_step_clocks.txt: a step of k_rb_conv
+// whose instruction stream carries no staging work runs at the matrix pipe's full rate for both waves of a SIMD; a step that issues a
+// staging round's loads, or its leaky-relu / split / ds_write_b128, takes 2 - 6 x — a wave that waits for a slot in the vector-memory or
+// LDS-store queue issues no MFMA meanwhile.  So the staging leaves the matrix waves: twelve waves, three per SIMD (168 registers each);
+// waves 0 .. 7 are the eight 16-row tiles as before and their streams hold nothing but ds_read_b128, MFMA and the weight-fragment
+// loads (+ the residual loads at the end of phase 1); waves 8 .. 11 (one per SIMD) only stage: global -> leaky-relu -> truncation
+// split -> the three planes.  Same two half-buffers, same two barriers per item: during phase h the producers write half 1 - h from
+// registers they LOADED one phase earlier (the data has long arrived: no wait in front of the LDS stores) and then issue the loads
+// of the half after that in one burst — a CU's vector-memory path returns in issue order across waves, so the matrix waves' weight
+// loads wait behind whatever the producers have in flight: one burst per phase costs that once, a trickle would cost it every step.
+// Element by element the arithmetic is k_rb_conv's (k-group, tap, six products small terms first, the same epilogue): bit-identical.
+// PRIO: the SIMD's arbiter serves the OLDER of two ready waves, so of a SIMD's two matrix waves (w and w + 4) the older one takes ~70 %
+// of the matrix pipe while both have work, finishes its phase early and idles at the barrier, and the younger one runs the rest of
+// its phase ALONE — at ~73 % of the pipe's rate (one wave's two accumulator chains and one-pair-ahead LDS reads do not fill it).
+// With PRIO the younger wave runs the first ~3/4 of a phase's steps at s_setprio 1 (it leads), then drops to 0 (the older one
+// leads): both reach the barrier together, and the pipe has two ready waves for the whole phase.
+// (s_setprio takes an immediate and only waves 4 .. 7 want it: the test and the branch live inside ONE asm statement — as a C++ `if`
+// they split the unrolled phase into basic blocks, and hipcc's wait-count pass answers that with vmcnt(0) drains and 92 bytes of spills)
+#ifdef MI355_EMU
+#define RBC_SETPRIO_YOUNG(mt, p) ((void)0)
+#else
+#define RBC_SETPRIO_YOUNG(mt, p) asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio " #p "\n1:" ::"s"(mt) : "scc")
+#endif
+template <int K, int DIL, int WD, bool PRIO>
+__global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
+    constexpr int NCT = 8;
+    using GE = RbcGeo<K, DIL, NCT>;
+    constexpr int G = RBC_G, N = GE::N, PAD = GE::PAD, LD = GE::LD, LDP = GE::LDP, S = G * K, SH = S / 2;
+    constexpr int HALF = GE::HALF, NP = NCT / 2, WR = RBC_WR;
+    constexpr int RP = (HALF + 255) / 256;  // staging rounds of a half-buffer for the 256 producer threads
+    constexpr unsigned REC16 = GE::REC16, PS16 = GE::PS16;
+    static_assert(S % WR == 0 && WD >= 1 && WD < WR && GE::LDS <= RBC_LDS_LIMIT, "shape");
+    DYN_SMEM(float, smem);
+    char* L0 = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wv = WAVE_UNIFORM(tid >> 6);
+    const int nblk = (a.T + N - 1) / N;
+    const int nitems = nblk * a.B;
+    const unsigned xrow = 4u * (unsigned)a.x_ld, yrow = 4u * (unsigned)a.y_ld, rrow = 4u * (unsigned)a.res_ld;
+
+    struct Item { int b, t0, len, last; };
+    auto row_len = [&](int b) MI355_INLINE_LAMBDA {
+#ifdef MI355_EMU
+        return a.in_len[b];
+#else
+        typedef const int __attribute__((address_space(4))) * cptr_t;
+        return ((cptr_t)(a.in_len))[b];
+#endif
+    };
+    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+        Item o;
+        o.b = WAVE_UNIFORM(it / nblk);
+        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
+        int len = row_len(o.b);
+        if (len > a.T) len = a.T;
+        o.len = len;
+        o.last = o.len > 0 ? o.len - 1 : 0;
+        return o;
+    };
+    if ((int)blockIdx.x >= nitems) return;
+
+    if (wv >= 8) {
+        // ================================================================ producer waves: (record, column) pairs pt + 256 round
+        const int pt = tid - 512;
+        auto p_load = [&](const Item& im, int half, int round, float (&sv)[8]) MI355_INLINE_LAMBDA {
+            const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
+            int t2 = pt;
+            OPAQUE_V(t2);
+            int idx = t2 + 256 * round;
+            if (256 * (round + 1) > HALF) idx = idx < HALF ? idx : HALF - 1;  // past the end: the last pair again (same bytes, same slot)
+            const int rec = idx / LD, col = idx - rec * LD;
+            const int t = im.t0 - PAD + col;
+            const int tc = t < 0 ? 0 : (t > im.last ? im.last : t);
+            const unsigned o = 4u * (unsigned)(8 * (8 * half + rec) * a.x_ld + tc);
+            MI355_UNROLL
+            for (int e = 0; e < 8; ++e) sv[e] = buf_load_f32(xb, o, (unsigned)e * xrow);
+        };
+        auto p_store = [&](const Item& im, int half, int round, const float (&sv)[8]) MI355_INLINE_LAMBDA {
+            int t2 = pt;
+            OPAQUE_V(t2);
+            int idx = t2 + 256 * round;
+            if (256 * (round + 1) > HALF) idx = idx < HALF ? idx : HALF - 1;
+            const int rec = idx / LD, col = idx - rec * LD;
+            const int t = im.t0 - PAD + col;
+            const bool in = t >= 0 && t < im.len;
+            uint4 ph[3];
+            unsigned h, m, l;
+            split3_sc(in ? lrelu_f(sv[0], a.in_slope) : 0.0f, in ? lrelu_f(sv[1], a.in_slope) : 0.0f, h, m, l);
+            ph[0].x = h; ph[1].x = m; ph[2].x = l;
+            split3_sc(in ? lrelu_f(sv[2], a.in_slope) : 0.0f, in ? lrelu_f(sv[3], a.in_slope) : 0.0f, h, m, l);
+            ph[0].y = h; ph[1].y = m; ph[2].y = l;
+            split3_sc(in ? lrelu_f(sv[4], a.in_slope) : 0.0f, in ? lrelu_f(sv[5], a.in_slope) : 0.0f, h, m, l);
+            ph[0].z = h; ph[1].z = m; ph[2].z = l;
+            split3_sc(in ? lrelu_f(sv[6], a.in_slope) : 0.0f, in ? lrelu_f(sv[7], a.in_slope) : 0.0f, h, m, l);
+            ph[0].w = h; ph[1].w = m; ph[2].w = l;
+            char* px = L0 + (unsigned)(8 * half + rec) * REC16 + 16u * (unsigned)col;
+            MI355_UNROLL
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(px + (unsigned)p * PS16) = ph[p];
+        };
+        float sv[RP][8];
+        {
+            const Item im = decode(blockIdx.x);
+            MI355_UNROLL
+            for (int r = 0; r < RP; ++r) p_load(im, 0, r, sv[r]);
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int r = 0; r < RP; ++r) p_store(im, 0, r, sv[r]);
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int r = 0; r < RP; ++r) p_load(im, 1, r, sv[r]);
+        }
+        __syncthreads();
+        MI355_NOUNROLL
+        for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+            const Item im = decode(it);
+            const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;  // (no next item: this one again, unread)
+            const Item imn = decode(itn);
+            // phase 0 (the matrix waves read half 0): this item's half 1 from the registers, then the loads of the next item's half 0
+            MI355_UNROLL
+            for (int r = 0; r < RP; ++r) p_store(im, 1, r, sv[r]);
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int r = 0; r < RP; ++r) p_load(imn, 0, r, sv[r]);
+            __syncthreads();
+            // phase 1 (they read half 1): the next item's half 0, then the loads of its half 1
+            MI355_UNROLL
+            for (int r = 0; r < RP; ++r) p_store(imn, 0, r, sv[r]);
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int r = 0; r < RP; ++r) p_load(imn, 1, r, sv[r]);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ==================================================================== matrix waves: wave = 16-row tile of output channels
+    const int mt = wv;
+    const int q = lane >> 4, n = lane & 15;
+    const int co0 = 32 * (mt >> 1) + 8 * q + 4 * (mt & 1);
+    const BufRsrc wbuf = buf_rsrc(a.w);
+    const unsigned wl = 16u * (unsigned)lane;
+    const unsigned wmt = (unsigned)mt * (unsigned)(K * G * 3 * 64 * 16);
+    unsigned lq[3];
+    MI355_UNROLL
+    for (int p = 0; p < 3; ++p) {
+        lq[p] = (unsigned)p * PS16 + (unsigned)(q * LDP + n) * 16u;
+        OPAQUE_V(lq[p]);
+    }
+    auto w_load = [&](int s, uint4 (&w)[3]) MI355_INLINE_LAMBDA {
+        const int g = s / K, k = s % K;
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) w[p] = buf_load_u4(wbuf, wl, wmt + (unsigned)(((k * G + g) * 3 + p) * 64 * 16));
+    };
+    auto b_read = [&](int s, int j, uint4 (&bf)[3]) MI355_INLINE_LAMBDA {
+        const int g = s / K, k = s % K;
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p)
+            bf[p] = *reinterpret_cast<const uint4*>(L0 + lq[p] + (unsigned)((4 * g) * LDP + 16 * j + k * DIL) * 16u);
+    };
+    float bia[4];
+    MI355_UNROLL
+    for (int r = 0; r < 4; ++r) bia[r] = a.bias ? a.bias[co0 + r] : 0.0f;
+    uint4 Wr[WR][3];
+    MI355_UNROLL
+    for (int s = 0; s < WD; ++s) w_load(s, Wr[s]);
+    __syncthreads();
+
+    MI355_NOUNROLL
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const Item im = decode(it);
+        const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
+        const BufRsrc rbuf = buf_rsrc(a.res + (long)im.b * a.res_bs);
+        f32x4 acc[NCT];
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) acc[j][r] = 0.0f;
+        float rq[NCT][4];
+        auto load_res = [&](int j) MI355_INLINE_LAMBDA {
+            const int t = im.t0 + 16 * j + n;
+            const int tc = t < a.T ? t : a.T - 1;
+            const unsigned o = 4u * (unsigned)(co0 * a.res_ld + tc);
+            MI355_UNROLL
+            for (int r = 0; r < 4; ++r) rq[j][r] = buf_load_f32(rbuf, o, (unsigned)r * rrow);
+        };
+        MI355_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            uint4 Bf[2][2][3];
+            b_read(h * SH, 0, Bf[0][0]);
+            b_read(h * SH, 1, Bf[0][1]);
+            if (PRIO) RBC_SETPRIO_YOUNG(mt, 1);
+            MI355_UNROLL
+            for (int sl = 0; sl < SH; ++sl) {
+                const int s = h * SH + sl;
+                if (PRIO && sl == (3 * SH + 2) / 4) RBC_SETPRIO_YOUNG(mt, 0);
+                w_load((s + WD) % S, Wr[(s + WD) % WR]);
+                if (h == 1 && sl >= SH - 2) {  // the residual tiles, four per step in the phase's last two steps
+                    MI355_UNROLL
+                    for (int j = 0; j < 4; ++j) load_res(4 * (sl - (SH - 2)) + j);
+                }
+                SCHED_FENCE();
+                MI355_UNROLL
+                for (int jp = 0; jp < NP; ++jp) {
+                    const int cur = jp & 1;
+                    if (jp + 1 < NP) {
+                        b_read(s, 2 * jp + 2, Bf[cur ^ 1][0]);
+                        b_read(s, 2 * jp + 3, Bf[cur ^ 1][1]);
+                    } else if (sl + 1 < SH) {
+                        b_read(s + 1, 0, Bf[cur ^ 1][0]);
+                        b_read(s + 1, 1, Bf[cur ^ 1][1]);
+                    }
+                    SCHED_FENCE();
+                    {
+                        const uint4(&W)[3] = Wr[s % WR];
+                        f32x4 c0 = acc[2 * jp], c1 = acc[2 * jp + 1];
+                        const uint4(&B0)[3] = Bf[cur][0];
+                        const uint4(&B1)[3] = Bf[cur][1];
+                        c0 = MFMA_16x16x32_BF16(W[2], B0[0], c0);  // small terms first
+                        c1 = MFMA_16x16x32_BF16(W[2], B1[0], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[2], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[2], c1);
+                        c0 = MFMA_16x16x32_BF16(W[1], B0[1], c0);
+                        c1 = MFMA_16x16x32_BF16(W[1], B1[1], c1);
+                        c0 = MFMA_16x16x32_BF16(W[1], B0[0], c0);
+                        c1 = MFMA_16x16x32_BF16(W[1], B1[0], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[1], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[1], c1);
+                        c0 = MFMA_16x16x32_BF16(W[0], B0[0], c0);
+                        c1 = MFMA_16x16x32_BF16(W[0], B1[0], c1);
+                        acc[2 * jp] = c0;
+                        acc[2 * jp + 1] = c1;
+                    }
+                    SCHED_FENCE();
+                }
+            }
+            __syncthreads();
+        }
+        // ---- epilogue (k_rb_conv's, operation by operation)
         MI355_UNROLL
         for (int j = 0; j < NCT; ++j)
             MI355_UNROLL
@@ -605,7 +872,7 @@ struct Ups64Geo {
     static constexpr size_t LDS = 2 * (size_t)BUF;
 };
 
-template <int NCT>
+template <int NCT, bool ST16>
 __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
     using GE = Ups64Geo<NCT>;
     constexpr int G = GE::G, K = GE::K, S = GE::S, NPOS = GE::NPOS, LD = GE::LD, LDP = GE::LDP, ROUNDS = GE::ROUNDS, FULL = GE::FULL, NP = NCT / 2;
@@ -721,6 +988,7 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
         const Item im1 = decode(clampi(it + (int)gridDim.x)), im2 = decode(clampi(it + 2 * (int)gridDim.x));
         const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
         const unsigned other = cur == 0u ? BUF : 0u;  // the buffer item i + 1 is staged into
+        const bool edge = im.t0 == 0 || 4 * (im.t0 + NPOS) + 1 >= a.shuf_T;  // position 0 or the row's last position belongs to this item
         unsigned lq[3];
         MI355_UNROLL
         for (int p = 0; p < 3; ++p) {
@@ -788,7 +1056,10 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
                 }
                 SCHED_FENCE();
             });
-            // this pair is complete: bias, the four phases of a channel as two 8-byte stores per tile (n = 4 i - 2 + phase)
+            // this pair is complete: bias, the four phases of a channel side by side (n = 4 i - 2 + phase): ONE 16-byte store per tile
+            // (8-byte aligned: the memory pipe is paid per store instruction and per 64-byte segment touched, and two 8-byte stores
+            // 16 bytes apart touch every segment twice); the first and the last item of a row, where half a position falls outside
+            // the row, take the two 8-byte stores with their own range tests (a wave-uniform choice)
             MI355_UNROLL
             for (int e = 0; e < 2; ++e) {
                 const f32x4& c = e == 0 ? c0 : c1;
@@ -796,10 +1067,15 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
                 const int i = im.t0 + il;
                 const bool on = il < NPOS && i < a.T;
                 const int ch = m0 >> 2, n0 = 4 * i - 2;
-                const unsigned o0 = (on && i >= 1) ? 4u * (unsigned)(ch * a.y_ld + n0) : BUF_OOB;
-                const unsigned o1 = (on && n0 + 3 < a.shuf_T) ? 4u * (unsigned)(ch * a.y_ld + n0 + 2) : BUF_OOB;
-                buf_store_f2(ybuf, o0, 0u, c[0] + bia[0], c[1] + bia[1]);
-                buf_store_f2(ybuf, o1, 0u, c[2] + bia[2], c[3] + bia[3]);
+                if (ST16 && !edge) {
+                    const unsigned o = on ? 4u * (unsigned)(ch * a.y_ld + n0) : BUF_OOB;
+                    buf_store_f4(ybuf, o, 0u, c[0] + bia[0], c[1] + bia[1], c[2] + bia[2], c[3] + bia[3]);
+                } else {
+                    const unsigned o0 = (on && i >= 1) ? 4u * (unsigned)(ch * a.y_ld + n0) : BUF_OOB;
+                    const unsigned o1 = (on && n0 + 3 < a.shuf_T) ? 4u * (unsigned)(ch * a.y_ld + n0 + 2) : BUF_OOB;
+                    buf_store_f2(ybuf, o0, 0u, c[0] + bia[0], c[1] + bia[1]);
+                    buf_store_f2(ybuf, o1, 0u, c[2] + bia[2], c[3] + bia[3]);
+                }
             }
         });
         __syncthreads();
@@ -833,9 +1109,20 @@ void launch_rb_conv(ConvArgs a, hipStream_t s) {
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(512), lds, s, a);
     };
+    // wide items: the producer-wave form (twelve waves), MI355VITS_RBC_PW=0 (lab / tests): staging inside the matrix waves' streams
+    int pw = RBC_PW_DEFAULT;
+    if (const char* f = lab_getenv("MI355VITS_RBC_PW")) pw = atoi(f);
+    auto go_pw = [&](auto kfn, size_t lds) {
+        const long nitems = (long)((a.T + 127) / 128) * a.B;
+        dim3 grid((unsigned)(nitems < cus ? nitems : cus));
+        set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
+        LAUNCH_KERNEL(kfn, grid, dim3(768), lds, s, a);
+    };
 #define RBC_CASE(KK, DD)                                                             \
     if (a.K == KK && a.dil == DD) {                                                  \
-        if (wide) go(k_rb_conv<KK, DD, 8>, RbcGeo<KK, DD, 8>::LDS, 128);             \
+        if (wide && pw == 2) go_pw(k_rb_conv_pw<KK, DD, 3, true>, RbcGeo<KK, DD, 8>::LDS); \
+        else if (wide && pw) go_pw(k_rb_conv_pw<KK, DD, 3, false>, RbcGeo<KK, DD, 8>::LDS); \
+        else if (wide) go(k_rb_conv<KK, DD, 8>, RbcGeo<KK, DD, 8>::LDS, 128);        \
         else go(k_rb_conv<KK, DD, 2>, RbcGeo<KK, DD, 2>::LDS, 32);                   \
         return;                                                                      \
     }
@@ -923,8 +1210,11 @@ void launch_ups_pl(ConvArgs a, hipStream_t s) {
         const long n127 = (long)a.B * ((a.T + 126) / 127);
         bool wide = n127 >= cus;
         if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;
-        if (wide) go(k_ups64<8>, Ups64Geo<8>::LDS, 127);
-        else go(k_ups64<2>, Ups64Geo<2>::LDS, 31);
+        const bool st8 = lab_getenv("MI355VITS_UPS64_ST8") != nullptr;  // lab / tests: two 8-byte stores per tile (round 4)
+        if (wide && st8) go(k_ups64<8, false>, Ups64Geo<8>::LDS, 127);
+        else if (wide) go(k_ups64<8, true>, Ups64Geo<8>::LDS, 127);
+        else if (st8) go(k_ups64<2, false>, Ups64Geo<2>::LDS, 31);
+        else go(k_ups64<2, true>, Ups64Geo<2>::LDS, 31);
     }
 }
 

@@ -438,6 +438,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 // ------------------------------------------------------------------------------------------------
 constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
 constexpr int WNB_DEFAULT_WAVES = 4;
+constexpr int WNB_RING = 4;  // weight-fragment buffers of the four-wave form
 // phase clocks of one workgroup (lab build, MI355VITS_WN_ABLATE bit 64): shader-clock deltas printed by workgroup (3, 5), wave 0
 #if defined(MI355_LAB) && !defined(MI355_EMU)
 #define WN_TS_DECL() long long wn_ts[7] = {0, 0, 0, 0, 0, 0, 0}
@@ -469,7 +470,8 @@ constexpr int WNB_DEFAULT_WAVES = 4;
 // SIMD with 170 registers each — the same fragments fetched once per workgroup, the same products in the same order per
 // accumulator (bit-identical), but three instruction streams per SIMD to cover each other's L2 / LDS waits in the matrix loops
 // (the four-wave form loses 40 % on a box whose fabric answers slower).
-template <bool W1, int NT, bool H2 = false, int MW = 3>
+// RA: weight-fragment ring of the four-wave form (b3.h b3_chunk_ra): 2 = one group ahead (rounds 2 - 4), 4 = three groups ahead
+template <bool W1, int NT, bool H2 = false, int MW = 3, int RA = 2>
 __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     constexpr int NWV = 12 / MW, NTH = 64 * NWV;
     static_assert(!(W1 && H2), "one reduced-operand variant at a time");
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
             // (twelve waves: 170 registers each — the form with the B fragments single-buffered, same products in the same order)
             if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
             else if constexpr (MW == 1) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+            else if constexpr (RA > 2) b3_chunk_ra<MW, NT, NG, NT, W1, RA>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
             else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         }
         __syncthreads();  // every wave is done with the h planes: the raw result takes their place
@@ -599,6 +602,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
             if (two || MW == 1) {  // (twelve waves, six tiles: waves 6 .. 11 recompute the last tile, discarded below)
                 if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else if constexpr (MW == 1) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                else if constexpr (RA > 2) b3_chunk_ra<MW, NT, NG, NT, W1, RA>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
             } else if constexpr (MW == 3) {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
                 f32x16 a2[2][NT];
@@ -725,8 +729,12 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
         else go(k_wn_layer_b3<false, 3, false, 1>, 768);
 #endif
     } else {
+        // default math, large grids: the weight fragments three groups ahead (WNB_RING; MI355VITS_WN_RING=2: one group ahead)
+        int ring = WNB_RING;
+        if (const char* f = lab_getenv("MI355VITS_WN_RING")) ring = atoi(f);
         if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 3, true>, 256);
         else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3>, 256);
+        else if (ring > 2) go(k_wn_layer_b3<false, 3, false, 3, 4>, 256);
         else go(k_wn_layer_b3<false, 3>, 256);
     }
 }

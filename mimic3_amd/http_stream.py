@@ -24,6 +24,7 @@ model of the kernels).  Nothing here touches the GPU; it is scheduling above ``I
 """
 from __future__ import annotations
 
+import asyncio
 import threading
 from concurrent.futures import ThreadPoolExecutor
 from copy import deepcopy
@@ -96,19 +97,33 @@ def plan_request(tts, text: str, ssml: bool = False, text_language: Optional[str
     return plan
 
 
-_POOLS: dict = {}
+_POOL: Optional[ThreadPoolExecutor] = None
+_POOL_WORKERS = 0
 _pools_lock = threading.Lock()
+_streams_lock = threading.Lock()
+_ACTIVE_STREAMS = 0
 
 
 def _shared_pool(look_ahead: int) -> ThreadPoolExecutor:
-    """One pool per look-ahead width for the whole process (requests share it: a pool per request costs thread start-up on
-    every call and puts no bound on the threads a burst of requests creates)."""
+    """ONE pool for the whole process, created by the first stream and never replaced (a pool per request costs thread start-up on
+    every call and puts no bound on the threads a burst of requests creates; a pool per look-ahead value never shrinks): two full
+    windows of the first request's look-ahead, at least 32 workers.  A later request that asks for a wider window than the pool
+    has workers simply gets the pool's width (``_fair_share``)."""
+    global _POOL, _POOL_WORKERS
     with _pools_lock:
-        pool = _POOLS.get(look_ahead)
-        if pool is None:
-            pool = _POOLS[look_ahead] = ThreadPoolExecutor(max_workers=2 * look_ahead,
-                                                           thread_name_prefix="mi355vits-http-stream")
-        return pool
+        if _POOL is None:
+            _POOL_WORKERS = max(32, 2 * look_ahead)
+            _POOL = ThreadPoolExecutor(max_workers=_POOL_WORKERS, thread_name_prefix="mi355vits-http-stream")
+        return _POOL
+
+
+def _fair_share(look_ahead: int) -> int:
+    """Sentences one stream may keep in flight right now: the pool's workers divided among the streams that are running, never
+    more than its own look-ahead, never fewer than two (head + one behind it) — so a request that arrives while others stream
+    finds free workers for its first sentences instead of queueing FIFO behind the earlier requests' whole windows."""
+    with _streams_lock:
+        n = max(1, _ACTIVE_STREAMS)
+    return max(2, min(look_ahead, _POOL_WORKERS // n))
 
 
 def stream_plan(tts, plan: List[Tuple[str, Any]], look_ahead: int = 16, sample_rate: Optional[int] = None) -> Iterator[bytes]:
@@ -136,16 +151,25 @@ def stream_plan(tts, plan: List[Tuple[str, Any]], look_ahead: int = 16, sample_r
             pending.append(pool.submit(lambda p=phonemes, s=settings: original(tts, p, settings=s).audio_bytes))
         return True
 
+    global _ACTIVE_STREAMS
+    with _streams_lock:
+        _ACTIVE_STREAMS += 1
     try:
-        while len(pending) < look_ahead and submit_next():
+        while len(pending) < _fair_share(look_ahead) and submit_next():
             pass
         while pending:
             head = pending.pop(0)
             chunk = head if isinstance(head, (bytes, bytearray)) else head.result()  # raises here if this sentence failed
-            submit_next()
+            while len(pending) < _fair_share(look_ahead) and submit_next():  # (the share grows back when other streams end)
+                pass
             if chunk:
                 yield chunk
     finally:
+        with _streams_lock:
+            _ACTIVE_STREAMS -= 1
+        # an abandoned stream (client gone, a sentence failed): what has not started is cancelled; what is running finishes on
+        # its lane (a synthesis call cannot be interrupted) and its result is dropped — at most `look_ahead` calls, and the
+        # fair share above keeps them from starving the streams that go on
         for f in pending:
             if not isinstance(f, (bytes, bytearray)):
                 f.cancel()
@@ -184,18 +208,24 @@ def add_stream_route(app, tts, quart_module, args=None, look_ahead: int = 16, ru
         ssml_str = a.get("ssml")
         ssml = (ssml_str.strip().lower() in {"true", "1", "yes", "on"}) if ssml_str else request.content_type == "application/ssml+xml"
         voice = a.get("voice") or (getattr(args, "voice", None) if args is not None else None) or DEFAULT_VOICE  # app.py:168
-        # the plan step is the only part that touches tts.settings / tts.voice: done here, under the lock, exactly as
-        # do_synthesis sets them (synthesis.py:41-47: ALL of them on every request, None = the voice's own default), so that
-        # nothing leaks from one request into the next.  The stream itself runs outside the lock: concurrent requests overlap.
-        with lock:
-            tts.speaker = None
-            tts.voice = str(voice)
-            for key, name in (("noiseScale", "noise_scale"), ("noiseW", "noise_w"), ("lengthScale", "length_scale")):
-                v = a.get(key)
-                base = getattr(args, name, None) if args is not None else None
-                setattr(tts.settings, name, float(v) if v else base)
-            plan = plan_request(tts, text, ssml=ssml, text_language=a.get("textLanguage"))
+        # the plan step is the only part that touches tts.settings / tts.voice: done under the lock, exactly as do_synthesis sets
+        # them (synthesis.py:41-47: ALL of them on every request, None = the voice's own default), so that nothing leaks from one
+        # request into the next.  It phonemises the whole text and may load a voice: seconds for a 10k-character request — so it
+        # runs in a worker thread (the lock is taken THERE: a threading.Lock held across an await would stall the loop), and the
+        # event loop keeps serving the other requests' chunks meanwhile.  The stream itself runs outside the lock.
+        params = {name: (float(a.get(key)) if a.get(key) else (getattr(args, name, None) if args is not None else None))
+                  for key, name in (("noiseScale", "noise_scale"), ("noiseW", "noise_w"), ("lengthScale", "length_scale"))}
+        text_language = a.get("textLanguage")
 
+        def locked_plan():
+            with lock:
+                tts.speaker = None
+                tts.voice = str(voice)
+                for name, v in params.items():
+                    setattr(tts.settings, name, v)
+                return plan_request(tts, text, ssml=ssml, text_language=text_language)
+
+        plan = await asyncio.get_running_loop().run_in_executor(None, locked_plan)
         return Response(stream_plan(tts, plan, look_ahead=look_ahead), mimetype="audio/wav")
 
     return app_tts_stream

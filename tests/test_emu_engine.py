@@ -508,6 +508,17 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
     assert np.array_equal(by_nw["4", "bf16x3"], by_nt["3"])
     for mode in ("bf16x3", "bf16w"):
         assert np.array_equal(by_nw["4", mode], by_nw["12", mode]), mode
+    # ... and the four-wave form's weight-fragment ring: three groups ahead (the default, round 5) against one group ahead
+    os.environ["MI355VITS_WN_B3_NT"] = "3"
+    os.environ["MI355VITS_WN_RING"] = "2"
+    try:
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math("bf16x3")
+        ring2 = eng.run(ids, np.array([30, 17]), (0.667, 1.0, 0.8), sid, forced_durations=forced, seed=3)["audio"]
+        eng.close()
+    finally:
+        del os.environ["MI355VITS_WN_B3_NT"], os.environ["MI355VITS_WN_RING"]
+    assert np.array_equal(ring2, by_nt["3"])
 
 
 def test_f16x2_mode_fused_mrf_stages(emu_lib):
@@ -751,8 +762,12 @@ def test_resblock_conv_128_channels_resident_input(emu_lib, monkeypatch):
     ids = np.random.default_rng(8).integers(1, cfg.num_symbols, (3, Tx))
     lengths = np.array([Tx, Tx - 9, Tx - 1])
     outs, taps = {}, {}
-    for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
-        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
+    # "wide" = 128-column items on the producer-wave form (k_rb_conv_pw: twelve waves, waves 8 .. 11 only stage; the default), "wide_pw0"
+    # = the same items with the staging inside the matrix waves' streams (k_rb_conv), "wide_pw2" = weight fragments two steps ahead
+    for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("wide_pw0", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "0"}),
+                     ("wide_pw2", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "2"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}),
+                     ("old", {"MI355VITS_NO_RBC": "1"})):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_RBC_PW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -765,8 +780,9 @@ def test_resblock_conv_128_channels_resident_input(emu_lib, monkeypatch):
         assert "dec.rb.s0" in labels, labels
         taps[tag] = eng.tap("dec.mrf.0")
         eng.close()
-    assert np.array_equal(taps["wide"], taps["narrow"])
-    assert np.array_equal(outs["wide"]["audio"], outs["narrow"]["audio"])
+    for tag in ("wide_pw0", "wide_pw2", "narrow"):
+        assert np.array_equal(taps["wide"], taps[tag]), tag
+        assert np.array_equal(outs["wide"]["audio"], outs[tag]["audio"]), tag
     for bi in range(3):
         L = int(outs["old"]["lengths"][bi])
         L0 = L * taps["old"].shape[2] // outs["old"]["audio"].shape[1]  # the row's own columns in stage 0 (past them: unmasked leftovers)
@@ -791,8 +807,10 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
     ids = np.random.default_rng(9).integers(1, cfg.num_symbols, (2, Tx))
     lengths = np.array([Tx, Tx - 5])
     outs, taps = {}, {}
-    for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
-        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
+    # "..._st8": k_ups64 with the round-4 epilogue (two 8-byte stores per tile instead of one 16-byte store in a row's interior items)
+    for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"}),
+                     ("wide_st8", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_UPS64_ST8": "1"}), ("narrow_st8", {"MI355VITS_RBC_WIDE": "0", "MI355VITS_UPS64_ST8": "1"})):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_UPS64_ST8"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -803,7 +821,8 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
         taps[tag] = {k: eng.tap(k) for k in ("dec.ups.0", "dec.ups.1", "dec.ups.2")}
         eng.close()
     for k in taps["wide"]:
-        assert np.array_equal(taps["wide"][k], taps["narrow"][k]), k
+        for tag in ("narrow", "wide_st8", "narrow_st8"):
+            assert np.array_equal(taps["wide"][k], taps[tag][k]), (k, tag)
         assert not np.array_equal(taps["wide"][k], taps["old"][k]), k  # (another kernel did run: another order of summation)
     assert np.array_equal(outs["wide"]["audio"], outs["narrow"]["audio"])
     for bi in range(2):
@@ -812,6 +831,96 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
             Lk = L * taps["old"][k].shape[2] // outs["old"]["audio"].shape[1]
             assert rel_rms(taps["wide"][k][bi, :, :Lk], taps["old"][k][bi, :, :Lk]) < 2e-6, k
         assert rel_rms(outs["wide"]["audio"][bi, :L], outs["old"]["audio"][bi, :L]) < 2e-5
+
+
+@pytest.mark.parametrize("kd,wide", [((3, 2), "1"), ((5, 6), "0"), ((7, 12), "1"), ((7, 3), "0")])
+def test_resident_input_resblock_conv_vs_fp64(emu_lib, kd, wide, monkeypatch):
+    """The kernel-level hook of k_rb_conv_pw / k_rb_conv (mi355vits_test_conv1d impl 4) on the CPU model against an fp64 conv, next to
+    the f32-MFMA kernel: 128- and 32-column items, a ragged row, write and accumulate (the GPU suite runs all six shapes at
+    full size: tests/test_gpu_parity.py)."""
+    import torch
+    import torch.nn.functional as F
+
+    K, dil = kd
+    monkeypatch.setenv("MI355VITS_RBC_WIDE", wide)
+    B, T, C = 2, 300, 128
+    rng = np.random.default_rng(100 * K + dil)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal((B, C, T)).astype(np.float32)
+    y0 = rng.standard_normal((B, C, T)).astype(np.float32)
+    in_len = np.array([T, T - 61], np.int32)
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).double()[:, None, :]
+    xt = F.leaky_relu(torch.from_numpy(x).double() * tm, 0.1)
+    conv = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil, padding=(K * dil - dil) // 2)
+    ref = ((conv + torch.from_numpy(res).double()) * 0.5).numpy()
+    for acc in (False, True):
+        want = ref + (y0.astype(np.float64) if acc else 0.0)
+        err = {}
+        for impl in (1, 4):
+            y = emu_lib.test_conv1d(x, w, bias, res, dilation=dil, impl=impl, in_len=in_len, in_slope=0.1, out_scale=0.5,
+                                    accumulate_into=y0 if acc else None)
+            err[impl] = float(np.sqrt(np.mean((y - want) ** 2)))
+        assert err[4] < 1e-6 and err[4] <= 1.25 * err[1] + 2e-8, (acc, err)
+
+
+@pytest.mark.parametrize("case,wide", [((128, 64, 8, 16), "1"), ((64, 32, 4, 8), "1"), ((64, 32, 4, 8), "0"), ((256, 128, 8, 16), "0")])
+def test_resident_input_upsamplers_vs_fp64(emu_lib, case, wide, monkeypatch):
+    """mi355vits_test_conv_transpose1d impl 3 (k_ups_pl / k_ups64) on the CPU model against an fp64 ConvTranspose1d, next to the
+    f32-MFMA polyphase kernel."""
+    import torch
+    import torch.nn.functional as F
+
+    Cin, Cout, stride, K = case
+    monkeypatch.setenv("MI355VITS_RBC_WIDE", wide)
+    B, Tin = 2, 150
+    rng = np.random.default_rng(Cin)
+    x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(Cin * K / stride)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(), torch.from_numpy(bias).double(),
+                             stride=stride, padding=(K - stride) // 2).numpy()
+    err = {}
+    for impl in (1, 3):
+        y = emu_lib.test_conv_transpose1d(x, w, bias, stride, in_slope=0.1, impl=impl)
+        err[impl] = float(np.sqrt(np.mean((y - ref) ** 2)))
+    assert err[3] < 1e-6 and err[3] <= 1.25 * err[1] + 2e-8, err
+
+
+def test_conv_post_dpp_kernel_is_bitwise_the_round1_kernel(emu_lib, monkeypatch):
+    """k_conv_post_tanh_dpp (round 5: one 16-byte load per lane, channel and tile; the taps' neighbours through DPP wave shifts; tiles of
+    248 produced samples overlapping by two float4) against the round-1 kernel (MI355VITS_CONV_POST_V1=1: eight samples per lane,
+    four overlapping loads per channel): the same fmaf chain in the same (channel, tap) order, so the waveform, the per-row peak
+    (int16 scale) and the int16 samples must be identical — rows ending inside a tile, inside a wave's span and inside a workgroup's
+    span, a one-phoneme row, and against the oracle through check_parity."""
+    cfg = VitsConfig.tiny_wide(initial_channel=256)
+    cfg.upsample_rates = (8, 8, 4)
+    cfg.upsample_kernel_sizes = (16, 16, 8)
+    cfg.hop_length = 256
+    w = W.synthetic_weights(cfg, seed=95, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 12
+    forced = np.full((4, Tx), 2, np.int32)
+    forced[3, :] = 1
+    ids = np.random.default_rng(10).integers(1, cfg.num_symbols, (4, Tx))
+    lengths = np.array([Tx, 7, 1, 9])
+    outs = {}
+    for tag, env in (("dpp", None), ("v1", "1")):
+        if env is None:
+            monkeypatch.delenv("MI355VITS_CONV_POST_V1", raising=False)
+        else:
+            monkeypatch.setenv("MI355VITS_CONV_POST_V1", env)
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math("bf16x3")
+        outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=95, weights=w, engine=eng)
+        eng.close()
+    assert np.array_equal(outs["dpp"]["lengths"], outs["v1"]["lengths"])
+    for b in range(4):
+        L = int(outs["v1"]["lengths"][b])
+        assert L > 0
+        assert np.array_equal(outs["dpp"]["audio"][b, :L], outs["v1"]["audio"][b, :L]), b
+        assert np.array_equal(outs["dpp"]["pcm"][b], outs["v1"]["pcm"][b]), b
 
 
 ENC_CASES = [(2, 192, 576, 70, 1), (1, 192, 192, 1, 1), (2, 96, 192, 130, 1), (1, 96, 40, 65, 3), (3, 192, 768, 130, 3), (2, 768, 192, 65, 3), (1, 192, 29, 64, 1),

@@ -177,8 +177,13 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
     lengths = np.array([Tx, Tx, 97, Tx, 64, Tx, 1, 127])
     forced = np.full((B, Tx), 6, np.int32)
     res = {}
-    for tag, env in (("default", {}), ("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
-        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC"):
+    # "wide" = 128-column items on the producer-wave form (k_rb_conv_pw, the default), run TWICE ("wide_again": a race between the producer
+    # waves' LDS stores and the matrix waves' reads would show as a difference between two runs — the CPU model cannot see one); "wide_pw0" =
+    # the staging inside the matrix waves' streams (k_rb_conv), "wide_pw2" = weight fragments two steps ahead instead of three
+    for tag, env in (("default", {}), ("wide", {"MI355VITS_RBC_WIDE": "1"}), ("wide_again", {"MI355VITS_RBC_WIDE": "1"}),
+                     ("wide_pw0", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "0"}), ("wide_pw2", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "2"}),
+                     ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_RBC_PW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -189,7 +194,7 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
         assert ("dec.mrf_fused.s0" in labels) == (tag == "old"), (tag, labels)
         res[tag] = eng.tap("dec.mrf.0"), out["audio"].copy(), out["lengths"].copy(), eng.tap("dec.ups.1"), eng.tap("dec.ups.2"), eng.tap("dec.ups.0")
         eng.close()
-    for tag in ("default", "narrow"):
+    for tag in ("default", "narrow", "wide_again", "wide_pw0", "wide_pw2"):
         for k in (0, 1, 3, 4, 5):
             assert np.array_equal(res[tag][k], res["wide"][k]), (tag, k)
     for bi in range(B):
@@ -198,3 +203,59 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
             hop = res["old"][1].shape[1] // res["old"][k].shape[2]
             assert rel_rms(res["wide"][k][bi, :, : n // hop], res["old"][k][bi, :, : n // hop]) < 2e-6, (bi, k)
         assert rel_rms(res["wide"][1][bi, :n], res["old"][1][bi, :n]) < REL_RMS_TOL, bi
+
+
+def test_round5_memory_bound_kernels_on_the_device(lab_lib, monkeypatch):
+    """Round 5's two memory-side rewrites against the kernels they replace, on the MI355X at the full-size shapes, BIT FOR BIT:
+    k_conv_post_tanh_dpp (one 16-byte load per lane, channel and tile, the taps' neighbours through DPP wave shifts — `wave_shr:1`
+    exists on the device only: the CPU model uses its shuffle) vs the round-1 kernel (MI355VITS_CONV_POST_V1=1), and k_ups64's
+    one 16-byte store per tile vs two 8-byte stores (MI355VITS_UPS64_ST8=1).  Waveform, lengths, int16 and the 64 -> 32 upsampler's
+    tap; ragged rows (ending inside a tile / an item), a one-phoneme row; each variant also against itself on a second engine."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    blob = W.pack(cfg, w)
+    B, Tx = 8, 128
+    ids = np.random.default_rng(8).integers(1, 50, (B, Tx))
+    lengths = np.array([Tx, Tx, 97, Tx, 64, Tx, 1, 127])
+    forced = np.full((B, Tx), 6, np.int32)
+    res = {}
+    for tag, env in (("new", {}), ("new_again", {}), ("post_v1", {"MI355VITS_CONV_POST_V1": "1"}), ("st8", {"MI355VITS_UPS64_ST8": "1"}),
+                     ("both_old", {"MI355VITS_CONV_POST_V1": "1", "MI355VITS_UPS64_ST8": "1"})):
+        for k in ("MI355VITS_CONV_POST_V1", "MI355VITS_UPS64_ST8"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(blob, library=lab_lib, device=0)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True, want_pcm16=True)
+        res[tag] = out["audio"].copy(), out["lengths"].copy(), out["pcm"].copy(), eng.tap("dec.ups.2")
+        eng.close()
+    for tag in ("new_again", "post_v1", "st8", "both_old"):
+        for k in range(4):
+            assert np.array_equal(res[tag][k], res["new"][k]), (tag, k)
+
+
+def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, monkeypatch):
+    """k_wn_layer_b3 with its weight fragments three groups ahead (a ring of four buffers: the default since round 5, for the boxes
+    whose L2 loses the layer's fragments to the activation stream) against one group ahead (MI355VITS_WN_RING=2) at the bench
+    shape's tile form: z and the waveform BIT FOR BIT (the same products in the same order per accumulator)."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=1234)
+    blob = W.pack(cfg, w)
+    B, Tx = 8, 128
+    ids = np.random.default_rng(9).integers(1, 50, (B, Tx))
+    lengths = np.array([Tx, 100, Tx, 3, Tx, 77, Tx, 128])
+    forced = np.full((B, Tx), 6, np.int32)
+    res = {}
+    monkeypatch.setenv("MI355VITS_WN_B3_NT", "3")
+    for tag, ring in (("ring4", None), ("ring2", "2"), ("ring4_again", None)):
+        if ring is None:
+            monkeypatch.delenv("MI355VITS_WN_RING", raising=False)
+        else:
+            monkeypatch.setenv("MI355VITS_WN_RING", ring)
+        eng = Engine(blob, library=lab_lib, device=0)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
+        res[tag] = eng.tap("z"), out["audio"].copy(), out["lengths"].copy()
+        eng.close()
+    for tag in ("ring2", "ring4_again"):
+        for k in range(3):
+            assert np.array_equal(res[tag][k], res["ring4"][k]), (tag, k)

@@ -350,6 +350,67 @@ def test_split_bf16_staged_conv_kernel_vs_fp64(gpu_lib, case):
     assert err[2] < 2e-6 and err[2] <= 1.25 * err[1] + 2e-8, err
 
 
+RBC_SHAPES = [(3, 1), (3, 2), (5, 2), (5, 6), (7, 3), (7, 12)]
+
+
+@pytest.mark.parametrize("kd", RBC_SHAPES)
+@pytest.mark.parametrize("grid", ["wide", "narrow"])
+def test_resident_input_resblock_conv_vs_fp64(gpu_lib, kd, grid):
+    """k_rb_conv_pw / k_rb_conv (impl 4: one conv of the 128-channel ResBlock2 stage with every input channel resident in LDS, MATH_BF16X3)
+    against an fp64 conv, next to the f32-MFMA kernel (impl 1) on the same data — all six (taps, dilation) instantiations, the
+    128-column items of large grids (producer-wave form: waves 8 .. 11 stage, waves 0 .. 7 only multiply) and the 32-column items
+    of small ones, ragged rows (one ending inside an item, one a column short), writing and accumulating (`y +=`: the stage's second
+    and third resblock).  At least as accurate as f32 arithmetic: a kernel that dropped one of its six partial products (l x h:
+    ~1e-5 of the output) fails this by a factor of 40."""
+    K, dil = kd
+    B, T = (9, 3800) if grid == "wide" else (2, 700)  # 9 x 30 = 270 items of 128 columns >= 256 CUs | 44 items of 32 columns
+    C = 128
+    rng = np.random.default_rng(1000 * K + dil + B)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal((B, C, T)).astype(np.float32)
+    y0 = rng.standard_normal((B, C, T)).astype(np.float32)
+    in_len = np.array([T, T - 61] + [T - 1] * (B - 2), np.int32)
+    tm = (torch.arange(T)[None, :] < torch.from_numpy(in_len.astype(np.int64))[:, None]).double()[:, None, :]
+    xt = F.leaky_relu(torch.from_numpy(x).double() * tm, 0.1)
+    conv = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil, padding=(K * dil - dil) // 2)
+    ref = ((conv + torch.from_numpy(res).double()) * (1.0 / 3.0)).numpy()
+    for acc in (False, True):
+        want = ref + (y0.astype(np.float64) if acc else 0.0)
+        err = {}
+        for impl in (1, 4):
+            y = gpu_lib.test_conv1d(x, w, bias, res, dilation=dil, impl=impl, in_len=in_len, in_slope=0.1, out_scale=1.0 / 3.0,
+                                    accumulate_into=y0 if acc else None)
+            err[impl] = float(np.sqrt(np.mean((y - want) ** 2)))
+        print(f"\nrb_conv k{K} d{dil} {grid} acc={acc}: rms error vs fp64  f32-MFMA {err[1]:.3e}  resident-input split {err[4]:.3e}")
+        assert err[4] < 1e-6 and err[4] <= 1.25 * err[1] + 2e-8, (acc, err)
+
+
+@pytest.mark.parametrize("case", [(256, 128, 8, 16), (128, 64, 8, 16), (64, 32, 4, 8)])
+@pytest.mark.parametrize("grid", ["wide", "narrow"])
+def test_resident_input_upsamplers_vs_fp64(gpu_lib, case, grid):
+    """k_ups_pl / k_ups64 (conv-transpose impl 3: the three upsamplers of the "_low" decoder as two-tap polyphase convs with every
+    input channel resident, MATH_BF16X3; 16-byte phase-interleaved stores) against an fp64 ConvTranspose1d, next to the f32-MFMA
+    polyphase kernel (impl 1) on the same data: wide and narrow work items, first / last output positions included."""
+    Cin, Cout, stride, K = case
+    per_item = 64 if Cin == 256 else 127 if Cin == 64 else 128
+    B, Tin = (5, 52 * per_item + 17) if grid == "wide" else (2, 300)
+    rng = np.random.default_rng(Cin + B)
+    x = rng.standard_normal((B, Cin, Tin)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(Cin * K / stride)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(), torch.from_numpy(bias).double(),
+                             stride=stride, padding=(K - stride) // 2).numpy()
+    err = {}
+    for impl in (1, 3):
+        y = gpu_lib.test_conv_transpose1d(x, w, bias, stride, in_slope=0.1, impl=impl)
+        assert y.shape == ref.shape
+        err[impl] = float(np.sqrt(np.mean((y - ref) ** 2)))
+    print(f"\nupsampler {case} {grid}: rms error vs fp64  f32-MFMA {err[1]:.3e}  resident-input split {err[3]:.3e}")
+    assert err[3] < 1e-6 and err[3] <= 1.25 * err[1] + 2e-8, err
+
+
 def test_f16x2_mode_bench_workload_matches_oracle(gpu_lib):
     """MATH_F16X2 (experimental: fused MRF stages on two-term fp16 operands) at the benchmarked shape, every decoder stage
     tapped, default tolerances; and batched == unbatched bitwise."""

@@ -10,6 +10,13 @@ from oracle.vits_oracle import VitsOracle, audio_float_to_int16
 # rel. RMS 2e-5..8e-5 and <= 12 LSB; its acceptance test allows 10 % of int16 samples to differ.
 REL_RMS_TOL = 1e-4
 MAX_ABS_TOL = 1e-3
+# ... that is the CONTRACT (what a user of the reference may rely on).  What the engine delivers in its f32-grade math modes
+# (f32 MFMA; f32 operands split exactly into 3 x bf16, the default) is 50 x better — measured on the MI355X and on the CPU model
+# alike: 1.1e-6 .. 1.6e-6 per decoder stage, 1.5e-6 .. 2.0e-6 end to end, against an oracle (PyTorch-CPU fp32) that is itself
+# 1.1e-6 from fp64 — and the tests hold it to THAT: a kernel that lost one of its six partial products (the l x h term: an error of
+# 2^-17 .. 2^-16 of every product, ~1e-5 of a conv's output) passes the contract figure and must not pass the suite.
+TIGHT_REL_RMS_TOL = 5e-6
+TIGHT_MATH_MODES = ("f32", "bf16x3")
 INT16_DIFF_FRACTION_TOL = 0.10
 INT16_MAX_LSB = 16
 
@@ -39,6 +46,12 @@ def decoder_stage_names(cfg: VitsConfig):
     return names
 
 
+def parity_tol(eng: Engine) -> float:
+    """rel. RMS bound of a tap / waveform for this engine's math mode: the measured level (x 2.5) in the f32-grade modes, the
+    contract figure elsewhere (f16x2 is experimental, bf16w has its own tolerance in its own tests)."""
+    return TIGHT_REL_RMS_TOL if eng.math in TIGHT_MATH_MODES else REL_RMS_TOL
+
+
 def check_decoder_stages(eng: Engine, cfg: VitsConfig, o1, rows=None):
     """Per-stage decoder taps (conv_pre, every upsampler, every MRF stage) against the oracle's, over each row's own
     frames: a compensating error between two stages cannot hide behind the end-to-end tolerance."""
@@ -46,6 +59,7 @@ def check_decoder_stages(eng: Engine, cfg: VitsConfig, o1, rows=None):
     B = len(y_len)
     rows = range(B) if rows is None else rows
     worst = {}
+    tol = parity_tol(eng)
     for name in decoder_stage_names(cfg):
         got = eng.tap(name)
         for b in rows:
@@ -58,7 +72,7 @@ def check_decoder_stages(eng: Engine, cfg: VitsConfig, o1, rows=None):
             assert ref.shape[0] == got.shape[1] and ref.shape[1] >= n, (name, ref.shape, got.shape)
             e = rel_rms(got[b, :, :n], ref[:, :n])
             worst[name] = max(worst.get(name, 0.0), e)
-            assert e < REL_RMS_TOL, (name, b, e)
+            assert e < tol, (name, b, e, f"bound {tol:g} for math mode {eng.math}; contract {REL_RMS_TOL:g}")
     return worst
 
 
@@ -95,6 +109,7 @@ def check_parity(lib, cfg: VitsConfig, B=2, Tx=9, seed=0, scales=(0.0, 1.0, 0.0)
         kw["noise_z"] = rng.standard_normal((B, cfg.inter_channels, max(1, Ty))).astype(np.float32)
     o1 = ora.infer(ids, lengths, scales, noise_w=kw.get("noise_w"), noise_z=kw.get("noise_z"), **okw)
     out = eng.run(ids, lengths, scales, sid, forced_durations=forced, want_pcm16=True, debug_taps=taps, **kw)
+    tol = parity_tol(eng)
     assert np.array_equal(out["lengths"], o1["audio_lengths"]), (out["lengths"], o1["audio_lengths"])
     if taps:
         assert np.array_equal(eng.tap("w_ceil"), o1["w_ceil"]), "durations (ceil) differ"
@@ -108,12 +123,14 @@ def check_parity(lib, cfg: VitsConfig, B=2, Tx=9, seed=0, scales=(0.0, 1.0, 0.0)
                 # they never reach a valid frame (every consumer masks), so compare valid frames only
                 ym = (np.arange(got.shape[2])[None, :] < o1["y_lengths"][:, None])[:, None, :]
                 got, ref = got * ym, ref * ym
-            assert rel_rms(got, ref) < REL_RMS_TOL, (name, rel_rms(got, ref))
+            assert rel_rms(got, ref) < tol, (name, rel_rms(got, ref), f"bound {tol:g} for math mode {eng.math}; contract {REL_RMS_TOL:g}")
+            out.setdefault("tap_errors", {})[name] = rel_rms(got, ref)
         out["stage_errors"] = check_decoder_stages(eng, cfg, o1, rows=stage_rows)
     for b in range(B):
         L = int(out["lengths"][b])
         a, r = out["audio"][b, :L], o1["audio"][b, 0, :L]
-        assert rel_rms(a, r) < REL_RMS_TOL, (b, rel_rms(a, r))
+        out["audio_error"] = max(out.get("audio_error", 0.0), rel_rms(a, r) if L else 0.0)
+        assert rel_rms(a, r) < tol, (b, rel_rms(a, r), f"bound {tol:g} for math mode {eng.math}; contract {REL_RMS_TOL:g}")
         assert np.abs(a - r).max() < MAX_ABS_TOL, (b, np.abs(a - r).max())
         # A2: int16 conversion is bit-exact on the engine's own float output ...
         assert np.array_equal(out["pcm"][b, :L], audio_float_to_int16(a)), "pcm16 differs from audio_float_to_int16"

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 TAG=${TAG:-run}
-BENCH="python $R/bench.py --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --no-extra --no-b1 --no-roofline --no-traffic ${MATH:+--math $MATH}"
+BENCH="python $R/bench.py --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --no-extra --no-b1 --no-roofline --no-traffic ${MATH:+--math $MATH} ${BATCH:+--batch $BATCH}"
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_sq1 $O/prof_sq2 $O/prof_sq3 $O/prof_sq4
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats -- $BENCH > $O/rocprof_stats.log 2>&1
 if [ -z "$STATS_ONLY" ]; then
