@@ -242,6 +242,10 @@ int mi355vits_test_mfma_layout(int device, float* err);
  * weight-streaming kernel), out[5] = GB/s streaming a 24 MB table (fits the memory-side cache, not an XCD's L2), out[6] / out[7] =
  * ns per dependent load over 32 MB (memory-side cache) / 1 GiB (HBM, mostly TLB misses). */
 int mi355vits_probe_device(int device, double out[8]);
+/* The same L2 stream over 2.6 MB windows of THIS handle's weight arena (the bytes the kernels actually stream): out[0..2] = min /
+ * median / max GB/s over the windows with eight 16-byte loads in flight per lane, out[3..5] = with one (the latency a kernel sees
+ * that fetches its fragments a step ahead), out[6] = windows measured, out[7] = low 36 bits of the arena's device address. */
+int mi355vits_probe_weights(mi355vits_handle h, double out[8]);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "mi355vits_get_config", "mi355vits_run", "mi355vits_fetch", "mi355vits_free_result",
     "mi355vits_last_error", "mi355vits_profile_enable", "mi355vits_profile_reset",
     "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_list_taps",
-    "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout", "mi355vits_bench_conv1d", "mi355vits_probe_device",
+    "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout", "mi355vits_bench_conv1d", "mi355vits_probe_device", "mi355vits_probe_weights",
 )
 
 
@@ -142,6 +142,7 @@ class NativeLibrary:
         L.mi355vits_test_mfma_layout.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.mi355vits_bench_conv1d.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_float)]
         L.mi355vits_probe_device.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.mi355vits_probe_weights.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 
     def version(self) -> str:
         return self.lib.mi355vits_version().decode()
@@ -414,6 +415,14 @@ class Engine:
     # ---- profiling / debugging ------------------------------------------------------------------
     def last_run_ms(self) -> float:
         return float(self.native.lib.mi355vits_last_run_ms(self._h))
+
+    def probe_weights(self) -> dict:
+        """L2 stream over this replica's own weight arena (include/mi355vits.h mi355vits_probe_weights): GB/s min / median / max
+        over 2.6 MB windows, eight loads in flight per lane and one."""
+        out = (ctypes.c_double * 8)()
+        self._check(self.native.lib.mi355vits_probe_weights(self._h, out))
+        return {"arena_stream8_GBps": [round(out[0]), round(out[1]), round(out[2])], "arena_stream1_GBps": [round(out[3]), round(out[4]), round(out[5])],
+                "windows": int(out[6]), "arena_addr_low36": hex(int(out[7]))}
 
     def profile_enable(self, on: bool = True) -> None:
         self._check(self.native.lib.mi355vits_profile_enable(self._h, int(on)))

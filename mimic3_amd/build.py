@@ -17,15 +17,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
-SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_mrfs1.cpp", "kernels_rbc.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
+SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_rbc.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
 PER_FILE_FLAGS = {}
 LAB_FILE_FLAGS = {}  # per-file flags of the lab build's side of a running A/B (none at the moment)
 # sources the lab build compiles exactly as the product does (no -DMI355_LAB): k_mrf_p's in-loop ablation tests cost 15 % of its
 # time, and it is now the REFERENCE side of the sweep kernels' A/B (its own ablations are in profiles/r03_mrf_experiments.txt)
 LAB_AS_PRODUCT = {"kernels_mrfp.cpp"}
-# sources of the lab build and the CPU model only: designs that measured EQUAL or worse than what the product runs, kept with their
-# tests as the A/B of that statement (k_mrf_s1: the 32-channel stage as a single-pass sweep, 2.33 vs k_mrf_p's 2.34 ms)
-LAB_ONLY = {"kernels_mrfs1.cpp"}
+# sources of the lab build and the CPU model only (designs that measured equal or worse than what the product runs, kept for ONE round as
+# the A/B of that statement; round 4's k_mrf_s1 was deleted in round 5 when k_rb_conv's staging-in-the-matrix-waves form took that place
+# inside kernels_rbc.cpp)
+LAB_ONLY = set()
 HIP_LIB = os.path.join(CSRC, "libmi355vits.so")
 EMU_LIB = os.path.join(EMU, "libmi355vits_emu.so")
 
@@ -60,9 +61,10 @@ def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = 
     """One object per source (compiled in parallel, rebuilt only when the source or a header changed), then one link.
     ``lab=True`` builds ``libmi355vits_lab.so`` with -DMI355_LAB (timing / kernel-choice experiments for tools/; never
     loaded by the product)."""
-    target = HIP_LIB.replace(".so", "_lab.so") if lab else HIP_LIB
+    variant = os.environ.get("MI355_LAB_VARIANT", "") if lab else ""  # "plain": the lab build without LAB_FILE_FLAGS, as libmi355vits_lab_plain.so
+    target = HIP_LIB.replace(".so", "_lab%s.so" % ("_" + variant if variant else "")) if lab else HIP_LIB
     hdrs = [d for d in _deps() if d.endswith(".h")]
-    objdir = os.path.join(CSRC, "build", "lab" if lab else "hip")
+    objdir = os.path.join(CSRC, "build", ("lab_" + variant if variant else "lab") if lab else "hip")
     os.makedirs(objdir, exist_ok=True)
     hipcc = find_hipcc()
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result",
@@ -74,7 +76,7 @@ def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = 
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".cpp", ".o"))
         if force or verbose_resources or _stale(obj, [src] + hdrs):
-            lab_flags = (["-DMI355_LAB"] if s not in LAB_AS_PRODUCT else []) + LAB_FILE_FLAGS.get(s, []) if lab else []
+            lab_flags = (["-DMI355_LAB"] if s not in LAB_AS_PRODUCT else []) + ([] if variant else LAB_FILE_FLAGS.get(s, [])) if lab else []
             jobs.append(base + PER_FILE_FLAGS.get(s, []) + lab_flags + ["-c", src, "-o", obj])
     if jobs:
         from concurrent.futures import ThreadPoolExecutor

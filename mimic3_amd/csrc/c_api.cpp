@@ -196,6 +196,12 @@ long mi355vits_profile_report(mi355vits_handle h, char* buf, size_t cap) {
     });
     return rc == MI355VITS_OK ? n : rc;
 }
+int mi355vits_probe_weights(mi355vits_handle h, double out[8]) {
+    if (!h || !out) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    return guarded(h, [&] { h->eng->probe_weights(out); });
+}
+
 float mi355vits_last_run_ms(mi355vits_handle h) {
     if (!h) return -1.0f;
     std::lock_guard<std::mutex> lk(h->eng->mu);

@@ -594,6 +594,49 @@ void Engine::construct(const WeightsFile& wf, int device) {
     std::vector<float>().swap(host_stage_);
 }
 
+void Engine::probe_weights(double out[8]) {
+    HIP_CHECK(hipSetDevice(device_));
+    const int cus = current_device_cu_count();
+    const int n16 = 256 * 8 * 80;  // 2.62 MB windows
+    const size_t win = (size_t)n16 * 16;
+    const int nwin = (int)std::min<size_t>(model_->bytes / win, 24);
+    if (nwin < 1) throw EngineError(MI355VITS_ERR_INVALID, "weight arena smaller than one probe window");
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    unsigned* sink = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sink), (size_t)cus * 4 + 16));
+    std::vector<double> g8, g1;
+    for (int wdx = 0; wdx < nwin; ++wdx) {
+        const char* base = reinterpret_cast<const char*>(model_->dev_weights) + (size_t)wdx * win;
+        for (int mode = 0; mode < 2; ++mode) {
+            auto go = [&] {
+                if (mode == 0) launch_probe_l2_stream(base, n16, 4, sink, cus, stream_);
+                else launch_probe_l2_stream1(base, n16, 1, sink, cus, stream_);
+            };
+            go();
+            HIP_CHECK(hipEventRecord(e0, stream_));
+            go();
+            go();
+            HIP_CHECK(hipEventRecord(e1, stream_));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double gbs = (double)cus * (mode == 0 ? 4 : 1) * win / (ms * 0.5e-3) / 1e9;
+            (mode == 0 ? g8 : g1).push_back(gbs);
+        }
+    }
+    (void)hipFree(sink);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::sort(g8.begin(), g8.end());
+    std::sort(g1.begin(), g1.end());
+    out[0] = g8.front(); out[1] = g8[g8.size() / 2]; out[2] = g8.back();
+    out[3] = g1.front(); out[4] = g1[g1.size() / 2]; out[5] = g1.back();
+    out[6] = (double)nwin;
+    out[7] = (double)(reinterpret_cast<uintptr_t>(model_->dev_weights) & 0xfffffffffULL);  // low bits of the arena's virtual address
+}
+
 void Engine::release() noexcept {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
@@ -1189,27 +1232,15 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
                     // large grids: the row sweep (k_mrf_s: fragments register-resident per segment, no halo recompute); small ones:
                     // (row, column block) items (k_mrf_p).  The two agree bit for bit, so the choice may follow the grid.
-                    // 64 channels: one pass per resblock (k_mrf_s).  32 channels: k_mrf_p — its single-pass sweep (k_mrf_s1) measured
-                    // equal (2.33 vs 2.34 ms) and lives in the lab build / CPU model only (MI355VITS_MRF_SWEEP_SEG32 = segment length)
-                    bool s1 = false;
+                    // 64 channels: one pass per resblock (k_mrf_s).  32 channels: k_mrf_p (its single-pass sweep, k_mrf_s1, measured equal in
+                    // round 4 — 2.33 vs 2.34 ms, 2.37 vs 2.36 with 48-column steps — and was deleted in round 5: DESIGN.md §6)
                     bool sw_ok = ch != 32 && mrf_s_supported(ch, nk, m.k, m.d1, m.d2);
                     int seg = !sw_ok ? 0 : mrf_s_segment(ch, B, (int)T, current_device_cu_count());
                     if (const char* f = lab_getenv("MI355VITS_MRF_SWEEP_SEG")) seg = sw_ok ? atoi(f) : 0;  // lab / tests
-#if defined(MI355_LAB) || defined(MI355_EMU)
-                    if (ch == 32 && mrf_s1_supported(ch, nk, m.k, m.d1, m.d2)) {
-                        const char* f = lab_getenv("MI355VITS_MRF_SWEEP_SEG32");
-                        if (!f) f = lab_getenv("MI355VITS_MRF_SWEEP_SEG");
-                        if (f && atoi(f) > 0) { s1 = true; seg = atoi(f); }
-                    }
-#endif
                     if (seg > 0) {
                         m.seg = seg;
                         ProfScope ps(prof_, i == 1 ? "dec.mrf_s.s1" : (i == 2 ? "dec.mrf_s.s2" : "dec.mrf_s"), flops, 8.0 * B * (double)T * ch);
-#if defined(MI355_LAB) || defined(MI355_EMU)
-                        if (s1) launch_mrf_s1(m, stream_);
-                        else
-#endif
-                            launch_mrf_s(m, stream_);
+                        launch_mrf_s(m, stream_);
                     } else {
                         ProfScope ps(prof_, i == 1 ? "dec.mrf_p.s1" : (i == 2 ? "dec.mrf_p.s2" : "dec.mrf_p"), flops, 8.0 * B * (double)T * ch);
                         launch_mrf_p(m, stream_);
@@ -1224,6 +1255,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                         ConvArgs probe;
                         probe.Cin = w.Cin; probe.Cout = w.Cout; probe.K = w.K; probe.dil = q == 0 ? m.d1[j] : m.d2[j];
                         probe.pad = (w.K - 1) / 2 * probe.dil; probe.res = d_bufA_; probe.in_len = slen; probe.T = (int)T;
+                        probe.x_ld = probe.res_ld = probe.y_ld = (int)T;  // (the stage's tensors are dense rows: what the launches below pass)
                         rbc_stage = rbc_stage && rbc_ok(w, probe);
                     }
                 // the longest prefix of resblocks whose tiles fit LDS together (128 channels: only the narrow ones)

@@ -123,6 +123,9 @@ class Engine {
     Engine(const WeightsFile& wf, int device);
     explicit Engine(const Engine& lane0);  // another lane on lane0's device, sharing its weight replica
     ~Engine();
+    // diagnostics (mi355vits_probe_weights): how fast every CU together streams 2.6 MB windows of THIS replica's weight arena out of
+    // the L2 — eight loads in flight per lane (bandwidth) and one (latency per fragment); min / median / max over the windows
+    void probe_weights(double out[8]);
     const std::shared_ptr<Model>& model() const { return model_; }
     // device pointers of the last run's results (valid until the next run on this handle); for device-side gathers
     void device_buffers(const int16_t** pcm, const float** audio, long* row_stride, int* batch, const int** dev_lengths);

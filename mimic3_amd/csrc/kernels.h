@@ -146,11 +146,6 @@ void launch_mrf_p(MrfArgs a, hipStream_t s);
 bool mrf_s_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 int mrf_s_segment(int C, int B, int T, int cus);
 void launch_mrf_s(MrfArgs a, hipStream_t s);
-// The 32-channel stage as a SINGLE-pass sweep (kernels_mrfs1.cpp; lab build and CPU model only: it measured equal to k_mrf_p): waves
-// specialised by (row tile, conv, resblock group), x staged once, y written once; same bits as k_mrf_p.
-bool mrf_s1_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
-int mrf_s1_segment(int B, int T, int cus);
-void launch_mrf_s1(MrfArgs a, hipStream_t s);
 // One dense conv of a 128-channel ResBlock2 (HiFi-GAN stage 0) in MATH_BF16X3 with all input channels resident in LDS (kernels_rbc.cpp):
 // y (+)= (res + bias + conv(lrelu(x * mask))) * out_scale; a.w = pack_conv_weights_p16 fragments; K / dilation pairs of the "_low" voices.
 bool rb_conv_supported(const ConvArgs& a);
@@ -307,6 +302,7 @@ void launch_mfma_selftest(float* out /*[32*32 + 16*16 + 16*16]*/, hipStream_t s)
 void launch_probe_l2_stream(const void* tbl, int n16, int reps, unsigned* sink, int grid, hipStream_t s);
 void launch_probe_l2_latency(const unsigned* chain, int steps, unsigned nlines, unsigned* out, int grid, hipStream_t s);
 void launch_probe_copy(const void* src, void* dst, long n16, int grid, hipStream_t s);
+void launch_probe_l2_stream1(const void* tbl, int n16, int reps, unsigned* sink, int grid, hipStream_t s);
 void launch_probe_l2_mixed(const void* tbl, int n16, int reps, const void* src, void* dst, long slice16, unsigned* sink, int grid, hipStream_t s);
 
 }  // namespace m355

@@ -1501,6 +1501,22 @@ void launch_probe_l2_mixed(const void* tbl, int n16, int reps, const void* src, 
     LAUNCH_KERNEL(k_probe_l2_mixed, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(tbl), n16, reps, static_cast<const uint4*>(src),
                   static_cast<uint4*>(dst), slice16, sink);
 }
+// the table stream with ONE load in flight per lane (a wave waits for each 1 KiB before asking for the next): what a kernel sees that
+// streams its weight fragments a step or two ahead of the matrix cores — latency per fragment, not bandwidth
+__global__ __launch_bounds__(256) void k_probe_l2_stream1(const uint4* __restrict__ tbl, int n16, int reps, unsigned* sink) {
+    const BufRsrc r = buf_rsrc(tbl);
+    unsigned acc = 0u;
+    const int rounds = n16 / 256;
+    for (int rep = 0; rep < reps; ++rep)
+        for (int k = 0; k < rounds; ++k) {
+            const uint4 v = buf_load_u4(r, 16u * (unsigned)(k * 256 + (int)threadIdx.x) + (acc & 0u), 0u);  // (address depends on the last load)
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    if (acc == 0x9e3779b9u) sink[blockIdx.x] = acc;
+}
+void launch_probe_l2_stream1(const void* tbl, int n16, int reps, unsigned* sink, int grid, hipStream_t s) {
+    LAUNCH_KERNEL(k_probe_l2_stream1, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(tbl), n16, reps, sink);
+}
 void launch_probe_l2_stream(const void* tbl, int n16, int reps, unsigned* sink, int grid, hipStream_t s) {
     LAUNCH_KERNEL(k_probe_l2_stream, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(tbl), n16, reps, sink);
 }

@@ -55,7 +55,7 @@ namespace m355 {
 namespace {
 constexpr size_t MRFS_LDS_LIMIT = 160 * 1024;
 constexpr int MRFS_NT = 3;  // 16-column tiles per wave and iteration
-constexpr int MRFS_CONV2_PRIO = 0;
+constexpr int MRFS_CONV2_PRIO = 4;  // dynamic: the conv2 waves lead for the first two of an iteration's three tiles (round 5: - 3 %)
 }  // namespace
 
 // compile-time ring lengths (columns) and dilations of the "_low" voices' stages, or MrfSDyn = take them from the arguments
@@ -347,6 +347,15 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                         float4 x1n = *reinterpret_cast<const float4*>(rawq + 16u * mrfs_wrap(rwr + (unsigned)(chh * (16 * NT)) + (unsigned)n, (unsigned)RR));
                         MI355_UNROLL  // straight-line iteration bodies: the wait-count pass then counts the younger loads / stores exactly
                         for (int i = 0; i < NT; ++i) {
+#if !defined(MI355_EMU)
+                            // a.vec == 4 (lab experiment, MI355VITS_MRF_PRIO=4): the younger wave of the SIMD pair leads for the first
+                            // two of an iteration's three tiles, the older one for the last — instead of the older one leading throughout
+                            // and idling at the barrier.  (Test and branch inside one asm statement: kernels_rbc.cpp RBC_SETPRIO_YOUNG.)
+                            // (a.vec: 4 = prio 1 for tiles 0, 1; 5 = for tile 0 only; 6 = for the whole iteration's tiles, 0 for its staging store)
+                            if (i == 0) asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(a.vec) : "scc");
+                            if (i == 1) asm volatile("s_cmp_lg_u32 %0, 5\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.vec) : "scc");
+                            if (i == NT - 1) asm volatile("s_cmp_lg_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.vec) : "scc");
+#endif
                             const int t0 = c0 + m * TS + chh * (16 * NT) + 16 * i;
                             const unsigned off = (unsigned)(chh * (16 * NT) + 16 * i);
                             const float x1a[4] = {x1n.x, x1n.y, x1n.z, x1n.w};
@@ -375,6 +384,9 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                         }
                         x1r = mrfs_wrap(x1r + TS, (unsigned)X1R);
                         rwr = mrfs_wrap(rwr + TS, (unsigned)RR);
+#if !defined(MI355_EMU)
+                        asm volatile("s_cmp_lg_u32 %0, 6\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.vec) : "scc");
+#endif
                     }
                     MRFS_CLK(ck_1);
                     stage_store(it, sv, xsw);
@@ -404,7 +416,7 @@ struct GeoS { int TS, XR, X1R, RR; size_t lds; };
 // ring lengths: multiples of 16 columns (a 16-lane fragment read then touches 16 consecutive 16-byte slots modulo the ring:
 // conflict-free), at least the span between a ring's oldest column still read and its newest column written in an iteration
 inline bool geometry_s(int C, int nrb, const int* k, const int* d1, const int* d2, GeoS* g) {
-    if (C != 64) return false;  // (the 32-channel stage: kernels_mrfs1.cpp)
+    if (C != 64) return false;  // (the 32-channel stage stays on k_mrf_p: its sweep forms lost or tied)
     const int TS = 16 * MRFS_NT * (4 / (C / 16));
     int r1m = 0, r2m = 0;
     for (int j = 0; j < nrb; ++j) {
@@ -492,7 +504,7 @@ void launch_mrf_s(MrfArgs a, hipStream_t s) {
     const int k1 = a.nrb > 1 ? a.k[1] : 0, k2 = a.nrb > 2 ? a.k[2] : 0;
     if (!(a.k[0] == 3 && k1 == 5 && k2 == 7)) throw std::runtime_error("mrf_s: unsupported tap counts");
     const bool low = a.d1[0] == 1 && a.d2[0] == 2 && a.d1[1] == 2 && a.d2[1] == 6 && a.d1[2] == 3 && a.d2[2] == 12;  // the "_low" voices
-    if (a.C != 64) throw std::runtime_error("mrf_s: 64 channels only (32: launch_mrf_s1)");
+    if (a.C != 64) throw std::runtime_error("mrf_s: 64 channels only");
     if (low && g.XR == 128 && g.X1R == 176 && g.RR == 144) { go(k_mrf_s<64, 3, 5, 7, MrfSShape<128, 176, 144, 1, 2, 2, 6, 3, 12>>); return; }
 #ifdef MI355_EMU
     go(k_mrf_s<64, 3, 5, 7, MrfSDyn>);

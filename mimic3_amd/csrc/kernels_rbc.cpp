@@ -25,6 +25,8 @@
 // The sum order of an output element — k-group, tap, six products small terms first — does not depend on the item width, so the
 // 32-column form used for small grids (one utterance) gives the same bits as the 128-column form.
 // Weights: pack_conv_weights_p16 fragments (the k_mrf_p order: [row tile][tap][k-group][plane][lane]).
+#include <algorithm>
+#include <vector>
 #include <type_traits>
 
 #include "kernels.h"
@@ -335,7 +337,9 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
 #else
 #define RBC_SETPRIO_YOUNG(mt, p) asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio " #p "\n1:" ::"s"(mt) : "scc")
 #endif
-template <int K, int DIL, int WD, bool PRIO>
+// CLK (lab build, MI355VITS_RBC_CLOCKS=1): shader-clock stamps of waves 0, 4 (the two matrix waves of one SIMD) and 8 (its producer)
+// at the phase boundaries of every item, written by lane 0 to a.part ([workgroup][wave slot][item][8 stamps], low 32 bits)
+template <int K, int DIL, int WD, int PRIO, bool CLK = false>  // PRIO: 0 off, 1 = 3/4 of a phase, 2 = every other step, 3 = every other tile pair
 __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
     constexpr int NCT = 8;
     using GE = RbcGeo<K, DIL, NCT>;
@@ -371,9 +375,21 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
         return o;
     };
     if ((int)blockIdx.x >= nitems) return;
+    [[maybe_unused]] int clk_item = 0;
+    auto stamp = [&](int slot, int k) MI355_INLINE_LAMBDA {
+#ifndef MI355_EMU
+        if constexpr (CLK) {
+            const unsigned t = (unsigned)__builtin_readcyclecounter();
+            const BufRsrc dbg = buf_rsrc(a.part);
+            const unsigned o = (lane == 0 && slot >= 0 && clk_item < 8) ? 4u * (unsigned)((((int)blockIdx.x * 3 + slot) * 8 + clk_item) * 8 + k) : BUF_OOB;
+            buf_store_f32(dbg, o, 0u, __uint_as_float(t));
+        }
+#endif
+    };
 
     if (wv >= 8) {
         // ================================================================ producer waves: (record, column) pairs pt + 256 round
+        const int cslot = wv == 8 ? 2 : -1;
         const int pt = tid - 512;
         auto p_load = [&](const Item& im, int half, int round, float (&sv)[8]) MI355_INLINE_LAMBDA {
             const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
@@ -429,25 +445,34 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
             const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;  // (no next item: this one again, unread)
             const Item imn = decode(itn);
             // phase 0 (the matrix waves read half 0): this item's half 1 from the registers, then the loads of the next item's half 0
+            stamp(cslot, 0);
             MI355_UNROLL
             for (int r = 0; r < RP; ++r) p_store(im, 1, r, sv[r]);
             SCHED_FENCE();
+            stamp(cslot, 1);
             MI355_UNROLL
             for (int r = 0; r < RP; ++r) p_load(imn, 0, r, sv[r]);
+            stamp(cslot, 2);
             __syncthreads();
+            stamp(cslot, 3);
             // phase 1 (they read half 1): the next item's half 0, then the loads of its half 1
             MI355_UNROLL
             for (int r = 0; r < RP; ++r) p_store(imn, 0, r, sv[r]);
             SCHED_FENCE();
+            stamp(cslot, 4);
             MI355_UNROLL
             for (int r = 0; r < RP; ++r) p_load(imn, 1, r, sv[r]);
+            stamp(cslot, 5);
             __syncthreads();
+            stamp(cslot, 6);
+            ++clk_item;
         }
         return;
     }
 
     // ==================================================================== matrix waves: wave = 16-row tile of output channels
     const int mt = wv;
+    const int cslot = mt == 0 ? 0 : (mt == 4 ? 1 : -1);
     const int q = lane >> 4, n = lane & 15;
     const int co0 = 32 * (mt >> 1) + 8 * q + 4 * (mt & 1);
     const BufRsrc wbuf = buf_rsrc(a.w);
@@ -496,16 +521,21 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
             MI355_UNROLL
             for (int r = 0; r < 4; ++r) rq[j][r] = buf_load_f32(rbuf, o, (unsigned)r * rrow);
         };
+        stamp(cslot, 0);
         MI355_UNROLL
         for (int h = 0; h < 2; ++h) {
             uint4 Bf[2][2][3];
             b_read(h * SH, 0, Bf[0][0]);
             b_read(h * SH, 1, Bf[0][1]);
-            if (PRIO) RBC_SETPRIO_YOUNG(mt, 1);
+            if (PRIO == 1) RBC_SETPRIO_YOUNG(mt, 1);
             MI355_UNROLL
             for (int sl = 0; sl < SH; ++sl) {
                 const int s = h * SH + sl;
-                if (PRIO && sl == (3 * SH + 2) / 4) RBC_SETPRIO_YOUNG(mt, 0);
+                if (PRIO == 1 && sl == (3 * SH + 2) / 4) RBC_SETPRIO_YOUNG(mt, 0);
+                if (PRIO == 2) {
+                    if (sl & 1) RBC_SETPRIO_YOUNG(mt, 0);
+                    else RBC_SETPRIO_YOUNG(mt, 1);
+                }
                 w_load((s + WD) % S, Wr[(s + WD) % WR]);
                 if (h == 1 && sl >= SH - 2) {  // the residual tiles, four per step in the phase's last two steps
                     MI355_UNROLL
@@ -515,6 +545,10 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
                 MI355_UNROLL
                 for (int jp = 0; jp < NP; ++jp) {
                     const int cur = jp & 1;
+                    if (PRIO == 3) {
+                        if (jp & 1) RBC_SETPRIO_YOUNG(mt, 0);
+                        else RBC_SETPRIO_YOUNG(mt, 1);
+                    }
                     if (jp + 1 < NP) {
                         b_read(s, 2 * jp + 2, Bf[cur ^ 1][0]);
                         b_read(s, 2 * jp + 3, Bf[cur ^ 1][1]);
@@ -546,7 +580,10 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
                     SCHED_FENCE();
                 }
             }
+            if (PRIO >= 2) RBC_SETPRIO_YOUNG(mt, 0);
+            stamp(cslot, 1 + 2 * h);
             __syncthreads();
+            stamp(cslot, 2 + 2 * h);
         }
         // ---- epilogue (k_rb_conv's, operation by operation)
         MI355_UNROLL
@@ -574,6 +611,8 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
             MI355_UNROLL
             for (int r = 0; r < 4; ++r) buf_store_f32(ybuf, o, (unsigned)r * yrow, acc[j][r]);
         }
+        stamp(cslot, 5);
+        ++clk_item;
     }
 }
 
@@ -1091,8 +1130,13 @@ inline bool rbc_shape(int K, int dil) {  // the "_low" voices' stage-0 convs (in
 }  // namespace
 
 bool rb_conv_supported(const ConvArgs& a) {
+    // the kernels address x, res and y through 32-bit buffer offsets `row * ld + column` (bytes): every leading dimension must cover
+    // the row (ld >= T) and the farthest element of a batch row must stay inside the 2 GiB range of a buffer resource — a caller
+    // with a larger pitch falls back to the staged kernels instead of reading zeros / dropping stores through the range check
+    const long ld = std::max(std::max((long)a.x_ld, (long)a.res_ld), (long)a.y_ld);
     return a.Cin == RBC_C && a.Cout == RBC_C && rbc_shape(a.K, a.dil) && a.epi == EPI_STD && a.res && a.in_len && !a.cond && !a.relu && !a.res_sub && !a.mask_before_res &&
-           !a.out_len && !a.shuf_s && a.Tin < 0 && a.pad == (a.K - 1) / 2 * a.dil && a.ksplit == 1 && (long)RBC_C * a.T * 4 < 0x7fffffffL;
+           !a.out_len && !a.shuf_s && a.Tin < 0 && a.pad == (a.K - 1) / 2 * a.dil && a.ksplit == 1 && a.x_ld >= a.T && a.res_ld >= a.T && a.y_ld >= a.T &&
+           (long)RBC_C * ld * 4 < 0x7fffffffL;
 }
 
 // a.w = the conv's pack_conv_weights_p16 fragments.  wide = 128-column items (grids that fill the chip), else 32-column items:
@@ -1118,10 +1162,59 @@ void launch_rb_conv(ConvArgs a, hipStream_t s) {
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(768), lds, s, a);
     };
+#if defined(MI355_LAB) && !defined(MI355_EMU)
+    if (wide && lab_getenv("MI355VITS_RBC_CLOCKS") && ((a.K == 7 && a.dil == 3) || (a.K == 3 && a.dil == 1))) {
+        static int shots = 0;
+        if (shots < 4) {  // (two launches of each shape: the first warms the caches)
+            ++shots;
+            const long nitems = (long)((a.T + 127) / 128) * a.B;
+            const int grid = (int)(nitems < cus ? nitems : cus);
+            float* dbg = nullptr;
+            const size_t nb = (size_t)grid * 3 * 8 * 8 * 4;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbg), nb));
+            HIP_CHECK(hipMemsetAsync(dbg, 0, nb, s));
+            ConvArgs c = a;
+            c.part = dbg;
+            const int prio = pw == 2 ? 1 : 0;
+            auto launch_c = [&](auto kfn, size_t lds) {
+                set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
+                LAUNCH_KERNEL(kfn, dim3(grid), dim3(768), lds, s, c);
+            };
+            if (a.K == 7) { if (prio) launch_c(k_rb_conv_pw<7, 3, 3, 1, true>, RbcGeo<7, 3, 8>::LDS); else launch_c(k_rb_conv_pw<7, 3, 3, 0, true>, RbcGeo<7, 3, 8>::LDS); }
+            else { if (prio) launch_c(k_rb_conv_pw<3, 1, 3, 1, true>, RbcGeo<3, 1, 8>::LDS); else launch_c(k_rb_conv_pw<3, 1, 3, 0, true>, RbcGeo<3, 1, 8>::LDS); }
+            HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<unsigned> h((size_t)grid * 3 * 8 * 8);
+            HIP_CHECK(hipMemcpy(h.data(), dbg, nb, hipMemcpyDeviceToHost));
+            (void)hipFree(dbg);
+            const int wg = grid > 7 ? 7 : 0;
+            const char* names[3] = {"matrix wave 0", "matrix wave 4", "producer wave 8"};
+            for (int slot = 0; slot < 3; ++slot) {
+                fprintf(stderr, "rb_conv_pw<%d,%d> prio=%d clocks wg %d %s:", a.K, a.dil, (int)prio, wg, names[slot]);
+                for (int it = 0; it < 6; ++it) {
+                    const unsigned* t = &h[(((size_t)wg * 3 + slot) * 8 + it) * 8];
+                    if (slot < 2) fprintf(stderr, " | item %d: phase0 %u barrier %u phase1 %u barrier %u epilogue %u", it, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
+                    else fprintf(stderr, " | item %d: stores %u loads %u barrier %u stores %u loads %u barrier %u", it, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
+                }
+                const unsigned* t0 = &h[(((size_t)wg * 3 + slot) * 8 + 0) * 8];
+                const unsigned* t5 = &h[(((size_t)wg * 3 + slot) * 8 + 5) * 8];
+                fprintf(stderr, " | items 0..5 span %u\n", t5[slot < 2 ? 5 : 6] - t0[0]);
+            }
+            return;
+        }
+    }
+#endif
+#if defined(MI355_LAB) && !defined(MI355_EMU)
+#define RBC_LAB_PRIO(KK, DD)                                                                     \
+    if (wide && pw == 3) { go_pw(k_rb_conv_pw<KK, DD, 3, 2>, RbcGeo<KK, DD, 8>::LDS); return; }  \
+    if (wide && pw == 4) { go_pw(k_rb_conv_pw<KK, DD, 3, 3>, RbcGeo<KK, DD, 8>::LDS); return; }
+#else
+#define RBC_LAB_PRIO(KK, DD)
+#endif
 #define RBC_CASE(KK, DD)                                                             \
     if (a.K == KK && a.dil == DD) {                                                  \
-        if (wide && pw == 2) go_pw(k_rb_conv_pw<KK, DD, 3, true>, RbcGeo<KK, DD, 8>::LDS); \
-        else if (wide && pw) go_pw(k_rb_conv_pw<KK, DD, 3, false>, RbcGeo<KK, DD, 8>::LDS); \
+        RBC_LAB_PRIO(KK, DD)                                                         \
+        if (wide && pw == 2) go_pw(k_rb_conv_pw<KK, DD, 3, 1>, RbcGeo<KK, DD, 8>::LDS);   \
+        else if (wide && pw) go_pw(k_rb_conv_pw<KK, DD, 3, 0>, RbcGeo<KK, DD, 8>::LDS);   \
         else if (wide) go(k_rb_conv<KK, DD, 8>, RbcGeo<KK, DD, 8>::LDS, 128);        \
         else go(k_rb_conv<KK, DD, 2>, RbcGeo<KK, DD, 2>::LDS, 32);                   \
         return;                                                                      \
@@ -1182,7 +1275,8 @@ bool ups_pl_supported(const ConvArgs& a) {
     return (s8 || s4) && a.K == 2 && a.dil == 1 && a.pad == 1 && a.Cout == a.shuf_s * (a.Cin / 2) && a.shuf_cout == a.Cin / 2 && a.shuf_p == a.shuf_s / 2 &&
            a.epi == EPI_STD && a.bias && a.in_len && a.Tin >= 0 && a.T == a.Tin + 1 && a.shuf_T == a.Tin * a.shuf_s && !a.res && !a.cond && !a.relu &&
            !a.accumulate && a.out_scale == 1.0f && !a.out_len && a.ksplit == 1 && a.y_ld % 4 == 0 && a.y_bs % 4 == 0 &&
-           reinterpret_cast<uintptr_t>(a.y) % 16 == 0 && (long)a.Cin * a.Tin * 4 < 0x7fffffffL && (long)(a.Cin / 2) * a.shuf_T * 4 < 0x7fffffffL;
+           reinterpret_cast<uintptr_t>(a.y) % 16 == 0 && reinterpret_cast<uintptr_t>(a.bias) % 16 == 0 &&  // (16-byte stores of y, float4 loads of the bias)
+           a.x_ld >= a.Tin && a.y_ld >= a.shuf_T && (long)a.Cin * a.x_ld * 4 < 0x7fffffffL && (long)(a.Cin / 2) * a.y_ld * 4 < 0x7fffffffL;
 }
 
 // a.w = the polyphase filter's pack_conv_weights_p16n fragments

@@ -1,5 +1,4 @@
-// mrfs.h — device building blocks of the row-sweep MRF kernels (kernels_mrfs.cpp: one pass per resblock, 64 channels;
-// kernels_mrfs1.cpp: one pass for the whole stage, 32 channels): LDS rings of bf16 planes addressed modulo their length, and one
+// mrfs.h — device building blocks of the row-sweep MRF kernel (kernels_mrfs.cpp: one pass per resblock, 64 channels): LDS rings of bf16 planes addressed modulo their length, and one
 // wave's 16-column tile of one conv on v_mfma_f32_16x16x32_bf16 in k_mrf_p's order of operations (bit-identical results).
 #pragma once
 #include "kernels.h"

@@ -713,7 +713,7 @@ def test_bf16x3_mrf_stage_split_once_weights_in_registers(emu_lib, dils):
 
 @pytest.mark.parametrize("dils,seg", [(((1, 2), (2, 6), (3, 12)), 96), (((1, 2), (2, 6), (3, 12)), 288), (((1, 3), (1, 3), (1, 3)), 192), (((3, 1), (2, 1), (1, 2)), 96)])
 def test_mrf_row_sweep_is_bitwise_the_block_kernel(emu_lib, dils, seg, monkeypatch):
-    """k_mrf_s (kernels_mrfs.cpp): the 64- and 32-channel MRF stages as a row sweep — work item = (row, segment), one pass per
+    """k_mrf_s (kernels_mrfs.cpp): the 64-channel MRF stage as a row sweep — work item = (row, segment), one pass per
     resblock, conv1 / conv2 on specialised waves with their fragments in registers for the whole segment, x / x1 planes in LDS
     rings addressed modulo their length, y accumulating the resblocks in place — against k_mrf_p on the same inputs: every decoder
     stage tap and the waveform BIT FOR BIT (same MFMA sequences, same order of additions), for the "_low" dilations, a narrow
@@ -738,8 +738,8 @@ def test_mrf_row_sweep_is_bitwise_the_block_kernel(emu_lib, dils, seg, monkeypat
         eng.profile_enable(True)
         outs[tag], _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=78, weights=w, engine=eng)
         labels = set(eng.profile_report())
-        assert ("dec.mrf_s.s1" in labels) == (tag == "s") and ("dec.mrf_p.s1" in labels) == (tag == "p"), labels
-        assert ("dec.mrf_s" in labels) == (tag == "s"), labels  # the 64-channel stage
+        assert ("dec.mrf_s" in labels) == (tag == "s") and ("dec.mrf_p" in labels) == (tag == "p"), labels  # the 64-channel stage
+        assert "dec.mrf_p.s1" in labels and "dec.mrf_s.s1" not in labels, labels  # the 32-channel stage stays on k_mrf_p
         taps[tag] = {k: eng.tap(k) for k in ("dec.mrf.0", "dec.mrf.1")}
         eng.close()
     for k in taps["p"]:

@@ -132,12 +132,11 @@ def test_flow_pointwise_convs_slice_kernel_equals_general(lab_lib, monkeypatch):
 
 
 def test_mrf_row_sweeps_equal_block_kernel_bitwise_on_the_device(lab_lib, monkeypatch):
-    """The row-sweep MRF kernels — k_mrf_s (64 channels: one pass per resblock, conv-specialised waves, fragments in registers, LDS
-    rings) and k_mrf_s1 (32 channels: ONE pass for all three resblocks, waves specialised by row tile x conv x resblock group, the
-    partial sum handed from group to group through LDS; lab build only: it measured equal to k_mrf_p) — vs k_mrf_p
-    (MI355VITS_MRF_SWEEP_SEG=0) on the MI355X at full-size shapes: both MRF stage taps and the waveform BIT FOR BIT, so the launcher
-    may pick by grid size.  The product's default (sweep for the 64-channel stage only), both sweeps at a forced short segment (1,632
-    columns: a multiple of both kernels' steps, several items per CU); ragged rows ending inside a segment, a one-phoneme row."""
+    """The row-sweep MRF kernel k_mrf_s (64 channels: one pass per resblock, conv-specialised waves, fragments in registers, LDS
+    rings) vs k_mrf_p (MI355VITS_MRF_SWEEP_SEG=0) on the MI355X at full-size shapes: both MRF stage taps and the waveform BIT FOR
+    BIT, so the launcher may pick by grid size.  The product's default and a forced short segment (1,632 columns: several items per
+    CU); ragged rows ending inside a segment, a one-phoneme row.  (The 32-channel stage stays on k_mrf_p: its single-pass sweep,
+    k_mrf_s1, tied it twice in round 4 and was deleted in round 5.)"""
     cfg = VitsConfig.apope_low()
     w = W.synthetic_weights(cfg, seed=1234)
     blob = W.pack(cfg, w)
@@ -155,7 +154,7 @@ def test_mrf_row_sweeps_equal_block_kernel_bitwise_on_the_device(lab_lib, monkey
         eng.profile_enable(True)
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
         labels = set(eng.profile_report())
-        assert ("dec.mrf_s.s1" in labels) == (tag != "block") and ("dec.mrf_s.s2" in labels) == (tag == "short_segments"), (tag, labels)
+        assert ("dec.mrf_s.s1" in labels) == (tag != "block") and "dec.mrf_s.s2" not in labels, (tag, labels)
         res[tag] = eng.tap("dec.mrf.1"), eng.tap("dec.mrf.2"), out["audio"].copy()
         eng.close()
     for tag in ("default", "short_segments"):

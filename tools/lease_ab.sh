@@ -7,13 +7,14 @@ python -c "from mimic3_amd._native import default_library; print(default_library
 if [ -n "$TESTS" ]; then timeout ${TEST_TIMEOUT:-1200} python -m pytest $TESTS -q -m gpu -x > $O/${TAG}_pytest.log 2>&1; tail -4 $O/${TAG}_pytest.log; fi
 for v in $VARIANTS; do
   t=${v%%:*}; e=${v#*:}; e=${e//,/ }
-  env $e timeout 300 python tools/lab_bench.py --batch ${BATCH:-32} --steps ${STEPS:-40} --warmup 10 --no-extra --no-cpu-baseline --no-traffic --no-b1 > $O/${TAG}_bench_$t.json 2> $O/${TAG}_bench_$t.err
+  B=tools/lab_bench.py; case "$e" in *PRODUCT=1*) B=bench.py;; esac
+  env $e timeout 300 python $B --batch ${BATCH:-32} --steps ${STEPS:-40} --warmup 10 --no-extra --no-cpu-baseline --no-traffic --no-b1 > $O/${TAG}_bench_$t.json 2> $O/${TAG}_bench_$t.err
   python - <<PY
 import json
 try:
     d = json.loads(open("$O/${TAG}_bench_$t.json").read().strip().splitlines()[-1])
     r = d.get("roofline", {})
-    print("$t: ms/step %.3f | " % d["ms_per_step"] + "  ".join("%s=%s" % (k[3:], v) for k, v in r.items() if k.startswith("ms:")) + " | " + str(d["config"].get("device")))
+    print("$t: ms/step %.3f | " % d["ms_per_step"] + "  ".join("%s=%s" % (k[3:], v) for k, v in r.items() if k.startswith("ms:")) + " | " + str(d["config"].get("device")) + " | arena " + str({k: v for k, v in (d.get("box_probe") or {}).items() if k.startswith("arena")}))
 except Exception as ex:
     print("$t: no bench json:", ex)
 PY
