@@ -406,7 +406,7 @@ def main():
     B, Tx, fpi = (256 // n_gpus if strong else args.batch), args.tx, args.frames_per_id
     # handles in flight per GPU: a 256-row batch fills the chip for 68 ms and takes 27 GB of workspace per handle — two overlap the
     # text side of one batch with the decoder of the other just as well as three
-    n_streams = max(1, args.streams) if B < 128 else min(2, max(1, args.streams))
+    n_streams = max(1, args.streams) if B < 128 else min(int(os.environ.get("MI355VITS_BENCH_BIG_STREAMS", "2")), max(1, args.streams))
     # single-process: every step of every device is one batch of B utterances; the job's step = n_gpus batches
     wl = Workload(cfg, weights, devices, n_streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
                   math=args.math)

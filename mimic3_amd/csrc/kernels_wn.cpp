@@ -439,6 +439,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
 constexpr int WNB_DEFAULT_WAVES = 4;
 constexpr int WNB_RING = 4;  // weight-fragment buffers of the four-wave form
+constexpr int WNB_EPI = 1;   // epilogue form of the four-wave, 96-column kernel (template parameter EP; 1 since round 5: profiles/r05_wn_epilogue_ab.txt)
 // phase clocks of one workgroup (lab build, MI355VITS_WN_ABLATE bit 64): shader-clock deltas printed by workgroup (3, 5), wave 0
 #if defined(MI355_LAB) && !defined(MI355_EMU)
 #define WN_TS_DECL() long long wn_ts[7] = {0, 0, 0, 0, 0, 0, 0}
@@ -471,7 +472,11 @@ constexpr int WNB_RING = 4;  // weight-fragment buffers of the four-wave form
 // accumulator (bit-identical), but three instruction streams per SIMD to cover each other's L2 / LDS waits in the matrix loops
 // (the four-wave form loses 40 % on a box whose fabric answers slower).
 // RA: weight-fragment ring of the four-wave form (b3.h b3_chunk_ra): 2 = one group ahead (rounds 2 - 4), 4 = three groups ahead
-template <bool W1, int NT, bool H2 = false, int MW = 3, int RA = 2>
+// EP: the epilogue's old-value loads (h residual: L2 hits, skip accumulator: HBM) — 0 = one tile ahead of the stores (rounds 2 - 4), 1 = three
+// tiles ahead (48 loads in flight per lane: the nine tiles of a wave were nine dependent round trips), 2 = three ahead AND the first three
+// tiles' loads issued in front of the gate phase (no vector-memory instruction in it: they land under its VALU / LDS work and the res/skip
+// conv's first weight fragments do not queue behind them in the in-order memory counter)
+template <bool W1, int NT, bool H2 = false, int MW = 3, int RA = 2, int EP = 0>
 __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     constexpr int NWV = 12 / MW, NTH = 64 * NWV;
     static_assert(!(W1 && H2), "one reduced-operand variant at a time");
@@ -539,6 +544,60 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     }
     __syncthreads();
     WN_TS(3);
+    const int ntr = a.Crs / 32;
+    const float* src[MW];
+    float* dst[MW];
+    long ldr[MW];
+    bool valid[MW], use_old[MW], to_h[MW];
+    MI355_UNROLL
+    for (int i = 0; i < MW; ++i) {
+        const int q = w + NWV * i;
+        valid[i] = q < ntr;
+        const int qc = valid[i] ? q : ntr - 1;
+        to_h[i] = two && 32 * qc < H;  // wave-uniform
+        if (to_h[i]) {
+            src[i] = a.h_in + (long)b * a.h_bs + (long)(32 * qc) * a.h_ld;
+            dst[i] = a.h_out + (long)b * a.h_bs + (long)(32 * qc) * a.h_ld;
+            ldr[i] = a.h_ld;
+            use_old[i] = true;
+        } else {
+            const int sub = two ? H : 0;
+            src[i] = a.skip + (long)b * a.s_bs + (long)(32 * qc - sub) * a.s_ld;
+            dst[i] = a.skip + (long)b * a.s_bs + (long)(32 * qc - sub) * a.s_ld;
+            ldr[i] = a.s_ld;
+            use_old[i] = !a.skip_init;
+        }
+    }
+    auto load_tile = [&](int i, int j, float (&old)[16]) {
+        const int t = t0 + j * 32 + bcol;
+        const int tc = t < a.T ? t : a.T - 1;
+        if (valid[i] && use_old[i]) {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) old[r] = src[i][(long)((r & 3) + 8 * (r >> 2) + 4 * brow) * ldr[i] + tc];
+        } else {
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) old[r] = 0.0f;
+        }
+    };
+    constexpr int EPA = EP == 0 ? 1 : 3, EPR = EPA + 1;  // tiles ahead; ring of old-value tiles
+    float old[EPR][16];
+    // EP >= 1: the same loads / stores as buffer instructions — a tile's base in the resource, ONE lane offset per tile, the row offsets in
+    // SGPRs, and the wave-uniform / per-lane conditions folded into the offset (out of range: the load returns 0, the store is dropped), so
+    // nothing between a load's issue and its use is conditional (hipcc's wait-count pass: DESIGN 4.6 item 1)
+    auto load_tile_b = [&](int i, int j, float (&o)[16]) MI355_INLINE_LAMBDA {
+        const int t = t0 + j * 32 + bcol;
+        const int tc = t < a.T ? t : a.T - 1;
+        const BufRsrc rs = buf_rsrc(src[i]);
+        const unsigned row4 = 4u * (unsigned)ldr[i];
+        const unsigned vo = (valid[i] && use_old[i]) ? (unsigned)(4 * brow) * row4 + 4u * (unsigned)tc : BUF_OOB;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) o[r] = buf_load_f32(rs, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * row4);
+    };
+    if constexpr (EP == 2) {
+        MI355_UNROLL
+        for (int k = 0; k < EPA; ++k) load_tile_b(k / NT, k % NT, old[k]);
+        SCHED_FENCE();
+    }
     // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
     constexpr int ITEMS = NG * 2 * T_B / NTH;  // four waves: 9 (96 columns) or 3 (32); twelve: 3 or 1
     float u[ITEMS][8];
@@ -582,7 +641,6 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     __syncthreads();
     WN_TS(4);
     // ---- res/skip 1x1 conv: Crs / 32 row tiles (12, last layer 6), tile q on wave q % 4
-    const int ntr = a.Crs / 32;
     f32x16 acc[MW][NT];
     {
         const uint4* wp[MW];
@@ -634,40 +692,6 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     // lane needs per 32 x 32 tile are loaded unconditionally (clamped column) and one tile ahead of the stores: the
     // memory counter retires in order, so a load issued after a store cannot be waited for without waiting for that
     // store's acknowledgement too — with tile k + 1's loads in front of tile k's stores no wait includes a fresh store.
-    const float* src[MW];
-    float* dst[MW];
-    long ldr[MW];
-    bool valid[MW], use_old[MW], to_h[MW];
-    MI355_UNROLL
-    for (int i = 0; i < MW; ++i) {
-        const int q = w + NWV * i;
-        valid[i] = q < ntr;
-        const int qc = valid[i] ? q : ntr - 1;
-        to_h[i] = two && 32 * qc < H;  // wave-uniform
-        if (to_h[i]) {
-            src[i] = a.h_in + (long)b * a.h_bs + (long)(32 * qc) * a.h_ld;
-            dst[i] = a.h_out + (long)b * a.h_bs + (long)(32 * qc) * a.h_ld;
-            ldr[i] = a.h_ld;
-            use_old[i] = true;
-        } else {
-            const int sub = two ? H : 0;
-            src[i] = a.skip + (long)b * a.s_bs + (long)(32 * qc - sub) * a.s_ld;
-            dst[i] = a.skip + (long)b * a.s_bs + (long)(32 * qc - sub) * a.s_ld;
-            ldr[i] = a.s_ld;
-            use_old[i] = !a.skip_init;
-        }
-    }
-    auto load_tile = [&](int i, int j, float (&old)[16]) {
-        const int t = t0 + j * 32 + bcol;
-        const int tc = t < a.T ? t : a.T - 1;
-        if (valid[i] && use_old[i]) {
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) old[r] = src[i][(long)((r & 3) + 8 * (r >> 2) + 4 * brow) * ldr[i] + tc];
-        } else {
-            MI355_UNROLL
-            for (int r = 0; r < 16; ++r) old[r] = 0.0f;
-        }
-    };
     auto store_tile = [&](int i, int j, const float (&old)[16]) {
         const int t = t0 + j * 32 + bcol;
         if (!valid[i] || t >= a.T) return;
@@ -675,14 +699,36 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
         MI355_UNROLL
         for (int r = 0; r < 16; ++r) dst[i][(long)((r & 3) + 8 * (r >> 2) + 4 * brow) * ldr[i] + t] = live ? old[r] + acc[i][j][r] : 0.0f;
     };
-    float old[2][16];
-    load_tile(0, 0, old[0]);
-    MI355_UNROLL
-    for (int k = 0; k < MW * NT; ++k) {
-        if (k + 1 < MW * NT) load_tile((k + 1) / NT, (k + 1) % NT, old[(k + 1) & 1]);
-        SCHED_FENCE();
-        store_tile(k / NT, k % NT, old[k & 1]);
-        SCHED_FENCE();
+    if constexpr (EP == 0) {
+        load_tile(0, 0, old[0]);
+        MI355_UNROLL
+        for (int k = 0; k < MW * NT; ++k) {
+            if (k + 1 < MW * NT) load_tile((k + 1) / NT, (k + 1) % NT, old[(k + 1) & 1]);
+            SCHED_FENCE();
+            store_tile(k / NT, k % NT, old[k & 1]);
+            SCHED_FENCE();
+        }
+    } else {
+        auto store_tile_b = [&](int i, int j, const float (&o)[16]) MI355_INLINE_LAMBDA {
+            const int t = t0 + j * 32 + bcol;
+            const bool live = t < len || !to_h[i];
+            const BufRsrc rs = buf_rsrc(dst[i]);
+            const unsigned row4 = 4u * (unsigned)ldr[i];
+            const unsigned vo = (valid[i] && t < a.T) ? (unsigned)(4 * brow) * row4 + 4u * (unsigned)t : BUF_OOB;
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) buf_store_f32(rs, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * row4, live ? o[r] + acc[i][j][r] : 0.0f);
+        };
+        if constexpr (EP == 1) {
+            MI355_UNROLL
+            for (int k = 0; k < EPA && k < MW * NT; ++k) load_tile_b(k / NT, k % NT, old[k]);
+        }
+        MI355_UNROLL
+        for (int k = 0; k < MW * NT; ++k) {
+            if (k + EPA < MW * NT) load_tile_b((k + EPA) / NT, (k + EPA) % NT, old[(k + EPA) % EPR]);
+            SCHED_FENCE();
+            store_tile_b(k / NT, k % NT, old[k % EPR]);
+            SCHED_FENCE();
+        }
     }
     WN_TS_END();
 }
@@ -732,8 +778,13 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
         // default math, large grids: the weight fragments three groups ahead (WNB_RING; MI355VITS_WN_RING=2: one group ahead)
         int ring = WNB_RING;
         if (const char* f = lab_getenv("MI355VITS_WN_RING")) ring = atoi(f);
+        int epi = WNB_EPI;
+        if (const char* f = lab_getenv("MI355VITS_WN_EPI")) epi = atoi(f);
+        if ((long)a.h_ld * 128 >= 0x7fffffffL || (long)a.s_ld * 128 >= 0x7fffffffL) epi = 0;  // a 32-row tile must fit the buffer range
         if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 3, true>, 256);
         else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 3>, 256);
+        else if (ring > 2 && epi == 2) go(k_wn_layer_b3<false, 3, false, 3, 4, 2>, 256);
+        else if (ring > 2 && epi == 1) go(k_wn_layer_b3<false, 3, false, 3, 4, 1>, 256);
         else if (ring > 2) go(k_wn_layer_b3<false, 3, false, 3, 4>, 256);
         else go(k_wn_layer_b3<false, 3>, 256);
     }

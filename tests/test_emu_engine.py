@@ -519,6 +519,19 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
     finally:
         del os.environ["MI355VITS_WN_B3_NT"], os.environ["MI355VITS_WN_RING"]
     assert np.array_equal(ring2, by_nt["3"])
+    # ... and the epilogue's old-value loads three tiles ahead as buffer instructions (EP = 1), the first three issued in front of the
+    # gate phase (EP = 2): the same additions on the same values
+    for epi in ("1", "2"):
+        os.environ["MI355VITS_WN_B3_NT"] = "3"
+        os.environ["MI355VITS_WN_EPI"] = epi
+        try:
+            eng = Engine(blob, library=emu_lib)
+            eng.set_math("bf16x3")
+            got = eng.run(ids, np.array([30, 17]), (0.667, 1.0, 0.8), sid, forced_durations=forced, seed=3)["audio"]
+            eng.close()
+        finally:
+            del os.environ["MI355VITS_WN_B3_NT"], os.environ["MI355VITS_WN_EPI"]
+        assert np.array_equal(got, by_nt["3"]), epi
 
 
 def test_f16x2_mode_fused_mrf_stages(emu_lib):

@@ -8,7 +8,8 @@ if [ -n "$TESTS" ]; then timeout ${TEST_TIMEOUT:-1200} python -m pytest $TESTS -
 for v in $VARIANTS; do
   t=${v%%:*}; e=${v#*:}; e=${e//,/ }
   B=tools/lab_bench.py; case "$e" in *PRODUCT=1*) B=bench.py;; esac
-  env $e timeout 300 python $B --batch ${BATCH:-32} --steps ${STEPS:-40} --warmup 10 --no-extra --no-cpu-baseline --no-traffic --no-b1 > $O/${TAG}_bench_$t.json 2> $O/${TAG}_bench_$t.err
+  vb=$(echo "$e" | grep -o 'BATCH=[0-9]*' | cut -d= -f2); vs=$(echo "$e" | grep -o 'STEPS=[0-9]*' | cut -d= -f2)  # per-variant batch / steps
+  env $e timeout 300 python $B --batch ${vb:-${BATCH:-32}} --steps ${vs:-${STEPS:-40}} --warmup 10 --no-extra --no-cpu-baseline --no-traffic --no-b1 > $O/${TAG}_bench_$t.json 2> $O/${TAG}_bench_$t.err
   python - <<PY
 import json
 try:
