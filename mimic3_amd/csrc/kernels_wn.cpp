@@ -439,6 +439,7 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
 constexpr int WNB_DEFAULT_WAVES = 4;
 constexpr int WNB_RING = 4;  // weight-fragment buffers of the four-wave form
+constexpr bool WNB_TW = false;  // the two-workgroups-per-CU form for large grids (k_wn_layer_b3_tw)
 constexpr int WNB_EPI = 1;   // epilogue form of the four-wave, 96-column kernel (template parameter EP; 1 since round 5: profiles/r05_wn_epilogue_ab.txt)
 // phase clocks of one workgroup (lab build, MI355VITS_WN_ABLATE bit 64): shader-clock deltas printed by workgroup (3, 5), wave 0
 #if defined(MI355_LAB) && !defined(MI355_EMU)
@@ -476,10 +477,15 @@ constexpr int WNB_EPI = 1;   // epilogue form of the four-wave, 96-column kernel
 // tiles ahead (48 loads in flight per lane: the nine tiles of a wave were nine dependent round trips), 2 = three ahead AND the first three
 // tiles' loads issued in front of the gate phase (no vector-memory instruction in it: they land under its VALU / LDS work and the res/skip
 // conv's first weight fragments do not queue behind them in the in-order memory counter)
-template <bool W1, int NT, bool H2 = false, int MW = 3, int RA = 2, int EP = 0>
-__global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
+// TW ("two workgroups per CU"): 64-column tiles whose LDS fits twice into a CU (h planes 68 columns = 76.5 KiB, u planes
+// 72 KiB, the raw in-layer result gated ONE 32-column tile at a time: 48 KiB) with <= 256 registers per wave, so that one workgroup's
+// HBM phases (staging, the h / skip read-modify-write) run under the other's matrix loops — at the price of streaming the layer's
+// fragments once per 64 instead of once per 96 columns.  The same products in the same order per output element: bit-identical.
+template <bool W1, int NT, bool H2, int MW, int RA, int EP, bool TW>
+__device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
     constexpr int NWV = 12 / MW, NTH = 64 * NWV;
     static_assert(!(W1 && H2), "one reduced-operand variant at a time");
+    static_assert(!TW || (NT == 2 && MW == 3 && !H2), "the two-per-CU form: four waves, 64 columns");
     constexpr int H = WNB_H, T_B = 32 * NT, NG = WNB_NG;
     constexpr int NP = H2 ? 2 : 3, GW = H2 ? 128 : 192;  // planes per operand; uint4 per weight-fragment group
     constexpr float ACC = H2 ? F16X2_ACC_SCALE : 1.0f, UNACC = H2 ? 1.0f / F16X2_ACC_SCALE : 1.0f;
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     if (len > a.T) len = a.T;
     const int pad = (a.K - 1) / 2 * a.dil;
     const int tlo = t0 - pad;
-    const int ts = tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3);
+    const int ts = TW ? tlo : (tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3));  // (TW: no alignment slack — 68 staged columns, 76.5 KiB)
     const int toff = tlo - ts;
     const int LD = a.ldx;          // staged columns of the h tile
     WN_TS_DECL();
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     const int PS = NG * 2 * LD;    // uint4 per plane
     const bool two = a.Crs == 2 * H;
 
-    if (!(LAB_ABLATE(a) & 2)) stage_planes<NG, (MW == 3 ? NG : 4), H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, NTH);  // column sets x row batches: one round trip
+    if (!(LAB_ABLATE(a) & 2)) stage_planes<NG, (TW ? 8 : (MW == 3 ? NG : 4)), H2>(a.h_in + (long)b * a.h_bs, a.h_ld, LD, ts, len, 1.0f, planes, PS, tid, NTH);  // column sets x row batches: one round trip
     __syncthreads();
     WN_TS(1);
 
@@ -510,6 +516,8 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     // (speaker conditioning without a branch per element — a test per load makes hipcc wait for each one in turn)
     const float* condp = a.cond ? a.cond + (long)b * a.cond_bs : a.b_in;
     const float cond_on = a.cond ? 1.0f : 0.0f;
+    constexpr int ITEMS = NG * 2 * T_B / NTH;  // gate items per thread — four waves: 9 (96 columns), 6 (64) or 3 (32); twelve: 3 or 1
+    float u[ITEMS][8];
     {
         f32x16 acc[MW][NT];
         const uint4* wp[MW];
@@ -528,21 +536,45 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
         if (!(LAB_ABLATE(a) & 1)) {
             // (twelve waves: 170 registers each — the form with the B fragments single-buffered, same products in the same order)
             if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
-            else if constexpr (MW == 1) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
+            else if constexpr (MW == 1 || TW) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);  // (TW: 256 registers)
             else if constexpr (RA > 2) b3_chunk_ra<MW, NT, NG, NT, W1, RA>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
             else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         }
         __syncthreads();  // every wave is done with the h planes: the raw result takes their place
         WN_TS(2);
-        MI355_UNROLL
-        for (int i = 0; i < MW; ++i)
+        if constexpr (TW) {
+            // one 32-column tile of the raw result at a time ([2H][32] = 48 KiB): store, gate into registers, next tile
             MI355_UNROLL
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j) {
                 MI355_UNROLL
-                for (int r = 0; r < 16; ++r)
-                    R[(32 * (w + NWV * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r] * UNACC;
+                for (int i = 0; i < MW; ++i)
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) R[(32 * (w + NWV * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * 32 + bcol] = acc[i][j][r] * UNACC;
+                __syncthreads();
+                MI355_UNROLL
+                for (int it = 0; it < ITEMS / NT; ++it) {
+                    const int idx = tid + NTH * it;
+                    const int gh = idx >> 5, col = idx & 31;
+                    const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
+                    MI355_UNROLL
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = cbase + 8 * (e >> 2) + (e & 3);
+                        u[j * (ITEMS / NT) + it][e] = wn_gate_f(R[c * 32 + col], R[(H + c) * 32 + col]);
+                    }
+                }
+                __syncthreads();  // the tile has been consumed: the next one (or u's planes) takes its place
+            }
+        } else {
+            MI355_UNROLL
+            for (int i = 0; i < MW; ++i)
+                MI355_UNROLL
+                for (int j = 0; j < NT; ++j)
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        R[(32 * (w + NWV * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r] * UNACC;
+        }
     }
-    __syncthreads();
+    if constexpr (!TW) __syncthreads();
     WN_TS(3);
     const int ntr = a.Crs / 32;
     const float* src[MW];
@@ -599,26 +631,27 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
         SCHED_FENCE();
     }
     // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
-    constexpr int ITEMS = NG * 2 * T_B / NTH;  // four waves: 9 (96 columns) or 3 (32); twelve: 3 or 1
-    float u[ITEMS][8];
-    MI355_UNROLL
-    for (int it = 0; it < ITEMS; ++it) {
-        const int idx = tid + NTH * it;
-        const int gh = idx / T_B, col = idx - gh * T_B;
-        const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
+    if constexpr (!TW) {
         MI355_UNROLL
-        for (int e = 0; e < 8; ++e) {
-            const int c = cbase + 8 * (e >> 2) + (e & 3);
-            const float at = R[c * T_B + col], as = R[(H + c) * T_B + col];
-            const float gate = wn_gate_f(at, as);
-            u[it][e] = gate;
+        for (int it = 0; it < ITEMS; ++it) {
+            const int idx = tid + NTH * it;
+            const int gh = idx / T_B, col = idx - gh * T_B;
+            const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
+            MI355_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int c = cbase + 8 * (e >> 2) + (e & 3);
+                const float at = R[c * T_B + col], as = R[(H + c) * T_B + col];
+                const float gate = wn_gate_f(at, as);
+                u[it][e] = gate;
+            }
         }
+        __syncthreads();  // the raw result has been consumed: u's planes take its place (column pitch T_B)
     }
-    __syncthreads();  // the raw result has been consumed: u's planes take its place (column pitch T_B)
     constexpr int PSU = NG * 2 * T_B;
     MI355_UNROLL
     for (int it = 0; it < ITEMS; ++it) {
-        const int idx = tid + NTH * it;  // = gh * T_B + col
+        // = gh * T_B + col (TW: item it = tile j = it / (ITEMS / NT), (gh, column of the tile) = tid + NTH * (it % (ITEMS / NT)))
+        const int idx = TW ? (((tid + NTH * (it % (ITEMS / NT))) >> 5) * T_B + (it / (ITEMS / NT)) * 32 + ((tid + NTH * (it % (ITEMS / NT))) & 31)) : tid + NTH * it;
         if constexpr (H2) {
             uint4 h4, m4;
             split2_pk(u[it][0] * F16X2_X_SCALE, u[it][1] * F16X2_X_SCALE, h4.x, m4.x);
@@ -659,7 +692,7 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
         if (!(LAB_ABLATE(a) & 1)) {
             if (two || MW == 1) {  // (twelve waves, six tiles: waves 6 .. 11 recompute the last tile, discarded below)
                 if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
-                else if constexpr (MW == 1) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                else if constexpr (MW == 1 || TW) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else if constexpr (RA > 2) b3_chunk_ra<MW, NT, NG, NT, W1, RA>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
             } else if constexpr (MW == 3) {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
@@ -733,6 +766,16 @@ __global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
     WN_TS_END();
 }
 
+template <bool W1, int NT, bool H2 = false, int MW = 3, int RA = 2, int EP = 0>
+__global__ __launch_bounds__(64 * (12 / MW)) void k_wn_layer_b3(WnArgs a) {
+    wn_layer_b3_body<W1, NT, H2, MW, RA, EP, false>(a);
+}
+// the two-per-CU form: <= 256 registers per wave (two waves per SIMD), 76.5 KiB of LDS
+template <bool W1>
+__global__ __launch_bounds__(256, 2) void k_wn_layer_b3_tw(WnArgs a) {
+    wn_layer_b3_body<W1, 2, false, 3, 2, 1, true>(a);
+}
+
 bool wn_layer_b3_supported(int H, int K, int dil) {
     return H == WNB_H && (K % 2) == 1 && K >= 1 && dil >= 1 && (K - 1) * dil <= 24;
 }
@@ -746,11 +789,17 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     // 96-column tiles when they fill the chip, 32-column tiles for small grids (same bits, see k_wn_layer_b3)
     const char* nt_s = lab_getenv("MI355VITS_WN_B3_NT");  // read per launch: tests flip it inside one process
     const long nwg3 = (long)((a.T + 95) / 96) * a.B;
-    const int nt = nt_s ? atoi(nt_s) : (nwg3 < 128 ? 1 : 3);
-    const int tb = nt == 1 ? 32 : 96;
-    a.ldx = (tb + (a.K - 1) * a.dil + 3 + 3) & ~3;
+    int nt = nt_s ? atoi(nt_s) : (nwg3 < 128 ? 1 : 3);
+    // the two-workgroups-per-CU form (64-column tiles, k_wn_layer_b3_tw): large grids of the default / bf16-weights math
+    bool tw = WNB_TW && nt == 3 && a.math != MATH_F16X2;
+    if (const char* f = lab_getenv("MI355VITS_WN_TW")) tw = atoi(f) != 0 && nt == 3 && a.math != MATH_F16X2;
+    if ((long)a.h_ld * 128 >= 0x7fffffffL || (long)a.s_ld * 128 >= 0x7fffffffL) tw = false;  // (its epilogue: a 32-row tile within the buffer range)
+    if (tw && (size_t)3 * WNB_NG * 2 * (64 + (a.K - 1) * a.dil) * 16 > 80 * 1024) tw = false;  // two of them must fit a CU's 160 KiB
+    if (tw) nt = 2;
+    const int tb = 32 * nt;
+    a.ldx = tw ? tb + (a.K - 1) * a.dil : ((tb + (a.K - 1) * a.dil + 3 + 3) & ~3);
     size_t shmem = (size_t)3 * WNB_NG * 2 * a.ldx * 16;
-    const size_t raw = (size_t)2 * WNB_H * tb * sizeof(float);
+    const size_t raw = (size_t)2 * WNB_H * (tw ? 32 : tb) * sizeof(float);
     if (raw > shmem) shmem = raw;
     dim3 grid((a.T + tb - 1) / tb, a.B);
     // four waves (one per SIMD, the whole register file each) is the product's form.  The twelve-wave form (three per SIMD; MW = 1)
@@ -765,7 +814,10 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(threads), shmem, s, a);
     };
-    if (nt == 1) {
+    if (tw) {
+        if (a.math == MATH_BF16W) go(k_wn_layer_b3_tw<true>, 256);
+        else go(k_wn_layer_b3_tw<false>, 256);
+    } else if (nt == 1) {
         if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 1, true>, 256);
         else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>, 256);
         else go(k_wn_layer_b3<false, 1>, 256);

@@ -532,6 +532,19 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
         finally:
             del os.environ["MI355VITS_WN_B3_NT"], os.environ["MI355VITS_WN_EPI"]
         assert np.array_equal(got, by_nt["3"]), epi
+    # ... and the two-workgroups-per-CU form (k_wn_layer_b3_tw: 64-column tiles, 68 staged columns, the raw result gated one 32-column
+    # tile at a time, B fragments single-buffered) in the default and the bf16-weights mode
+    for mode in ("bf16x3", "bf16w"):
+        os.environ["MI355VITS_WN_B3_NT"] = "3"
+        os.environ["MI355VITS_WN_TW"] = "1"
+        try:
+            eng = Engine(blob, library=emu_lib)
+            eng.set_math(mode)
+            got = eng.run(ids, np.array([30, 17]), (0.667, 1.0, 0.8), sid, forced_durations=forced, seed=3)["audio"]
+            eng.close()
+        finally:
+            del os.environ["MI355VITS_WN_B3_NT"], os.environ["MI355VITS_WN_TW"]
+        assert np.array_equal(got, by_nw["4", mode]), mode
 
 
 def test_f16x2_mode_fused_mrf_stages(emu_lib):

@@ -246,10 +246,13 @@ def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, m
     forced = np.full((B, Tx), 6, np.int32)
     res = {}
     monkeypatch.setenv("MI355VITS_WN_B3_NT", "3")
-    for tag, ring in (("ring4", None), ("ring2", "2"), ("ring4_again", None), ("epi0", "e0"), ("epi1", "e1"), ("epi2", "e2")):
+    for tag, ring in (("ring4", None), ("ring2", "2"), ("ring4_again", None), ("epi0", "e0"), ("epi1", "e1"), ("epi2", "e2"), ("tw", "tw")):
         monkeypatch.delenv("MI355VITS_WN_RING", raising=False)
         monkeypatch.delenv("MI355VITS_WN_EPI", raising=False)
-        if ring is not None and ring.startswith("e"):  # the epilogue forms (old values one / three tiles ahead / + issued before the gate)
+        monkeypatch.delenv("MI355VITS_WN_TW", raising=False)
+        if ring == "tw":  # the two-workgroups-per-CU form (64-column tiles)
+            monkeypatch.setenv("MI355VITS_WN_TW", "1")
+        elif ring is not None and ring.startswith("e"):  # the epilogue forms (old values one / three tiles ahead / + issued before the gate)
             monkeypatch.setenv("MI355VITS_WN_EPI", ring[1:])
         elif ring is not None:
             monkeypatch.setenv("MI355VITS_WN_RING", ring)
@@ -257,6 +260,6 @@ def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, m
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
         res[tag] = eng.tap("z"), out["audio"].copy(), out["lengths"].copy()
         eng.close()
-    for tag in ("ring2", "ring4_again", "epi0", "epi1", "epi2"):
+    for tag in ("ring2", "ring4_again", "epi0", "epi1", "epi2", "tw"):
         for k in range(3):
             assert np.array_equal(res[tag][k], res["ring4"][k]), (tag, k)
