@@ -439,7 +439,6 @@ __global__ __launch_bounds__(64 * NW) MIN_WAVES_PER_SIMD(3) void k_wn_layer_h192
 constexpr int WNB_H = 192, WNB_NG = WNB_H / 16;
 constexpr int WNB_DEFAULT_WAVES = 4;
 constexpr int WNB_RING = 4;  // weight-fragment buffers of the four-wave form
-constexpr bool WNB_TW = false;  // the two-workgroups-per-CU form for large grids (k_wn_layer_b3_tw)
 constexpr int WNB_EPI = 1;   // epilogue form of the four-wave, 96-column kernel (template parameter EP; 1 since round 5: profiles/r05_wn_epilogue_ab.txt)
 // phase clocks of one workgroup (lab build, MI355VITS_WN_ABLATE bit 64): shader-clock deltas printed by workgroup (3, 5), wave 0
 #if defined(MI355_LAB) && !defined(MI355_EMU)
@@ -791,8 +790,14 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     const long nwg3 = (long)((a.T + 95) / 96) * a.B;
     int nt = nt_s ? atoi(nt_s) : (nwg3 < 128 ? 1 : 3);
     // the two-workgroups-per-CU form (64-column tiles, k_wn_layer_b3_tw): large grids of the default / bf16-weights math
-    bool tw = WNB_TW && nt == 3 && a.math != MATH_F16X2;
+    // Measured on the MI355X (profiles/r05_wn_two_per_cu_ab.txt): 8.5 % SLOWER than the 96-column form at batch 256 (14.3 vs 13.2 ms per 16
+    // layers x 256 rows), 31 % slower at batch 32 (384 workgroups on 512 slots) — what the overlap of the HBM phases gains, the 1.5 x
+    // weight stream through the L1 and the leaner loop (2 x 3 instead of 3 x 3 tiles per fragment pair) lose again.  Lab build and CPU
+    // model only, as the A/B of that statement (MI355VITS_WN_TW=1).
+    bool tw = false;
+#if defined(MI355_LAB) || defined(MI355_EMU)
     if (const char* f = lab_getenv("MI355VITS_WN_TW")) tw = atoi(f) != 0 && nt == 3 && a.math != MATH_F16X2;
+#endif
     if ((long)a.h_ld * 128 >= 0x7fffffffL || (long)a.s_ld * 128 >= 0x7fffffffL) tw = false;  // (its epilogue: a 32-row tile within the buffer range)
     if (tw && (size_t)3 * WNB_NG * 2 * (64 + (a.K - 1) * a.dil) * 16 > 80 * 1024) tw = false;  // two of them must fit a CU's 160 KiB
     if (tw) nt = 2;
@@ -814,10 +819,13 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
 #endif
         LAUNCH_KERNEL(kfn, grid, dim3(threads), shmem, s, a);
     };
+#if defined(MI355_LAB) || defined(MI355_EMU)
     if (tw) {
         if (a.math == MATH_BF16W) go(k_wn_layer_b3_tw<true>, 256);
         else go(k_wn_layer_b3_tw<false>, 256);
-    } else if (nt == 1) {
+    } else
+#endif
+    if (nt == 1) {
         if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 1, true>, 256);
         else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>, 256);
         else go(k_wn_layer_b3<false, 1>, 256);

@@ -169,14 +169,15 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "derived":
         derived(sys.argv[2])
         raise SystemExit(0)
+    BATCH = int(os.environ.get("BATCH") or 256)  # the profiled bench workload: bench.py's default at --gpus 1 (tools/profile.sh passes BATCH on)
     if len(sys.argv) >= 4 and sys.argv[1] == "traffic-from-text":
-        traffic_from_text(sys.argv[3], sys.argv[2])
+        traffic_from_text(sys.argv[3], sys.argv[2], B=BATCH)
         raise SystemExit(0)
     if len(sys.argv) < 3 or sys.argv[1] not in ("stats", "pmc", "traffic"):
         raise SystemExit(__doc__)
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif sys.argv[1] == "traffic":
-        traffic(sys.argv[3:], sys.argv[2])
+        traffic(sys.argv[3:], sys.argv[2], B=BATCH)
     else:
         pmc(sys.argv[2:])
