@@ -48,6 +48,7 @@ struct ConvArgs {
     // part[((s * B + b) * Cout + co) * T + t] (no epilogue; launch_layernorm adds them up); ksplit = 1: y with the epilogue
     int ksplit = 1;
     float* part = nullptr;
+    int item_order = 0;  // kernels_rbc.cpp (set by its launchers): 1 = the persistent workgroups walk their items XCD-major (rbc_item)
 };
 
 // Short-sequence dense conv of the text encoder (q/k/v, o, FFN: T = phonemes) in MATH_BF16X3 / BF16W: 64 x 64 output tiles, a

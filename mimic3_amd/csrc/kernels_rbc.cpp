@@ -40,6 +40,18 @@ constexpr int RBC_PW_DEFAULT = 1;  // wide items on the producer-wave form (k_rb
 constexpr int RBC_WR = 4;  // weight-fragment ring: the running step and three ahead (the step count is a multiple of 4)
 }  // namespace
 
+// Item order of the persistent workgroups.  Workgroup w runs on XCD w % 8 and walks the items w, w + W, w + 2 W, ... (W = the grid);
+// consecutive items of a row — which share their halo columns, or (k_ups64: 127-position items) the 128-byte lines their rows' ends
+// fall into — would so land on eight different XCDs and be fetched from HBM by each of them.  XCD-major: logical item it = 8 q + x
+// becomes the q-th item of XCD x's contiguous eighth of the items (a bijection for every item count), so that the 32 CUs of an XCD work
+// on neighbouring items at the same time and the shared bytes come out of that XCD's L2 (k_mrf_p has walked its items like this since round 3).
+__device__ __forceinline__ int rbc_item(int it, int n, int order) {
+    if (!order) return it;
+    const int x = it & 7, q = it >> 3, f = n >> 3, rm = n & 7;
+    return x * f + (x < rm ? x : rm) + q;
+}
+constexpr int RBC_ITEM_ORDER = 1;
+
 template <int K, int DIL, int NCT>
 struct RbcGeo {
     static constexpr int N = 16 * NCT, PAD = (K - 1) / 2 * DIL, LD = N + 2 * PAD, LDP = (LD + 15) & ~15;
@@ -92,6 +104,7 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
     };
     auto decode = [&](int it) MI355_INLINE_LAMBDA {
         Item o;
+        it = rbc_item(it, nitems, a.item_order);
         o.b = WAVE_UNIFORM(it / nblk);
         o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
         int len = row_len(o.b);
@@ -366,6 +379,7 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
     };
     auto decode = [&](int it) MI355_INLINE_LAMBDA {
         Item o;
+        it = rbc_item(it, nitems, a.item_order);
         o.b = WAVE_UNIFORM(it / nblk);
         o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
         int len = row_len(o.b);
@@ -690,6 +704,7 @@ __global__ __launch_bounds__(512) void k_ups_pl(ConvArgs a) {
     };
     auto decode = [&](int it) MI355_INLINE_LAMBDA {
         Item o;
+        it = rbc_item(it, nitems, a.item_order);
         o.b = WAVE_UNIFORM(it / nblk);
         o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
         int len = row_len(o.b);
@@ -939,6 +954,7 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
     };
     auto decode = [&](int it) MI355_INLINE_LAMBDA {
         Item o;
+        it = rbc_item(it, nitems, a.item_order);
         o.b = WAVE_UNIFORM(it / nblk);
         o.t0 = WAVE_UNIFORM((it - o.b * nblk) * NPOS);
         int len = row_len(o.b);
@@ -1145,6 +1161,8 @@ void launch_rb_conv(ConvArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!rb_conv_supported(a)) throw std::runtime_error("rb_conv: unsupported shape");
     const int cus = current_device_cu_count();
+    a.item_order = RBC_ITEM_ORDER;
+    if (const char* f = lab_getenv("MI355VITS_RBC_ITEM_ORDER")) a.item_order = atoi(f);  // lab / tests: 0 = items w, w + W, ... as in round 4
     bool wide = (long)a.B * ((a.T + 127) / 128) >= cus;
     if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;  // lab / tests
     auto go = [&](auto kfn, size_t lds, int ncols) {
@@ -1284,6 +1302,8 @@ void launch_ups_pl(ConvArgs a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!ups_pl_supported(a)) throw std::runtime_error("ups_pl: unsupported shape");
     const int cus = current_device_cu_count();
+    a.item_order = RBC_ITEM_ORDER;
+    if (const char* f = lab_getenv("MI355VITS_RBC_ITEM_ORDER")) a.item_order = atoi(f);  // lab / tests: 0 = items w, w + W, ... as in round 4
     auto go = [&](auto kfn, size_t lds, int ncols) {
         const long nitems = (long)((a.T + ncols - 1) / ncols) * a.B;
         dim3 grid((unsigned)(nitems < cus ? nitems : cus));

@@ -792,8 +792,10 @@ def test_resblock_conv_128_channels_resident_input(emu_lib, monkeypatch):
     # = the same items with the staging inside the matrix waves' streams (k_rb_conv), "wide_pw2" = weight fragments two steps ahead
     for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("wide_pw0", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "0"}),
                      ("wide_pw2", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "2"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}),
+                     ("wide_o0", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_ITEM_ORDER": "0"}),  # items w, w + W, ... instead of XCD-major
+                     ("narrow_o0", {"MI355VITS_RBC_WIDE": "0", "MI355VITS_RBC_ITEM_ORDER": "0"}),
                      ("old", {"MI355VITS_NO_RBC": "1"})):
-        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_RBC_PW"):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_RBC_PW", "MI355VITS_RBC_ITEM_ORDER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -806,7 +808,7 @@ def test_resblock_conv_128_channels_resident_input(emu_lib, monkeypatch):
         assert "dec.rb.s0" in labels, labels
         taps[tag] = eng.tap("dec.mrf.0")
         eng.close()
-    for tag in ("wide_pw0", "wide_pw2", "narrow"):
+    for tag in ("wide_pw0", "wide_pw2", "narrow", "wide_o0", "narrow_o0"):
         assert np.array_equal(taps["wide"], taps[tag]), tag
         assert np.array_equal(outs["wide"]["audio"], outs[tag]["audio"]), tag
     for bi in range(3):
@@ -835,8 +837,9 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
     outs, taps = {}, {}
     # "..._st8": k_ups64 with the round-4 epilogue (two 8-byte stores per tile instead of one 16-byte store in a row's interior items)
     for tag, env in (("wide", {"MI355VITS_RBC_WIDE": "1"}), ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"}),
-                     ("wide_st8", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_UPS64_ST8": "1"}), ("narrow_st8", {"MI355VITS_RBC_WIDE": "0", "MI355VITS_UPS64_ST8": "1"})):
-        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_UPS64_ST8"):
+                     ("wide_st8", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_UPS64_ST8": "1"}), ("narrow_st8", {"MI355VITS_RBC_WIDE": "0", "MI355VITS_UPS64_ST8": "1"}),
+                     ("wide_o0", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_ITEM_ORDER": "0"}), ("narrow_o0", {"MI355VITS_RBC_WIDE": "0", "MI355VITS_RBC_ITEM_ORDER": "0"})):
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_UPS64_ST8", "MI355VITS_RBC_ITEM_ORDER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -847,7 +850,7 @@ def test_polyphase_upsamplers_resident_input(emu_lib, monkeypatch):
         taps[tag] = {k: eng.tap(k) for k in ("dec.ups.0", "dec.ups.1", "dec.ups.2")}
         eng.close()
     for k in taps["wide"]:
-        for tag in ("narrow", "wide_st8", "narrow_st8"):
+        for tag in ("narrow", "wide_st8", "narrow_st8", "wide_o0", "narrow_o0"):
             assert np.array_equal(taps["wide"][k], taps[tag][k]), (k, tag)
         assert not np.array_equal(taps["wide"][k], taps["old"][k]), k  # (another kernel did run: another order of summation)
     assert np.array_equal(outs["wide"]["audio"], outs["narrow"]["audio"])

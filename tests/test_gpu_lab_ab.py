@@ -181,8 +181,9 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
     # the staging inside the matrix waves' streams (k_rb_conv), "wide_pw2" = weight fragments two steps ahead instead of three
     for tag, env in (("default", {}), ("wide", {"MI355VITS_RBC_WIDE": "1"}), ("wide_again", {"MI355VITS_RBC_WIDE": "1"}),
                      ("wide_pw0", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "0"}), ("wide_pw2", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_PW": "2"}),
-                     ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"})):
-        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_RBC_PW"):
+                     ("narrow", {"MI355VITS_RBC_WIDE": "0"}), ("old", {"MI355VITS_NO_RBC": "1"}),
+                     ("wide_o0", {"MI355VITS_RBC_WIDE": "1", "MI355VITS_RBC_ITEM_ORDER": "0"})):  # items w, w + W, ... instead of XCD-major
+        for k in ("MI355VITS_RBC_WIDE", "MI355VITS_NO_RBC", "MI355VITS_RBC_PW", "MI355VITS_RBC_ITEM_ORDER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -193,7 +194,7 @@ def test_resblock_conv_128_channels_on_the_device(lab_lib, monkeypatch):
         assert ("dec.mrf_fused.s0" in labels) == (tag == "old"), (tag, labels)
         res[tag] = eng.tap("dec.mrf.0"), out["audio"].copy(), out["lengths"].copy(), eng.tap("dec.ups.1"), eng.tap("dec.ups.2"), eng.tap("dec.ups.0")
         eng.close()
-    for tag in ("default", "narrow", "wide_again", "wide_pw0", "wide_pw2"):
+    for tag in ("default", "narrow", "wide_again", "wide_pw0", "wide_pw2", "wide_o0"):
         for k in (0, 1, 3, 4, 5):
             assert np.array_equal(res[tag][k], res["wide"][k]), (tag, k)
     for bi in range(B):
