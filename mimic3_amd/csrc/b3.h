@@ -6,6 +6,17 @@
 
 namespace m355 {
 
+// Fault injection of the CPU model only (tests/test_emu_engine.py::test_tight_bound_catches_a_dropped_partial_product): with
+// MI355VITS_EMU_DROP = 1 / 2 / 3 the b3 loops leave out the l_w x h_x / h_w x l_x / m_w x m_x product (the three smallest of the six).
+#ifdef MI355_EMU
+static inline int b3_drop() {  // 0 none, 1 = l_w x h_x, 2 = h_w x l_x, 3 = m_w x m_x
+    const char* e = getenv("MI355VITS_EMU_DROP");
+    return e ? atoi(e) : 0;
+}
+#else
+__device__ __forceinline__ constexpr int b3_drop() { return 0; }
+#endif
+
 // W1: the weights contribute their leading bf16 term only ("bf16 weights", MATH_BF16W): three products per multiply-add
 template <int MT, int NT, int NG, int NA = NT, bool W1 = false>  // NG 16-channel groups per chunk; NA >= NT: accumulator array extent
 __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NA], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS /*plane stride*/,
@@ -14,6 +25,7 @@ __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NA], const uint4* con
     // consecutive taps are groups_per_tap * 192 apart.  xq: (plane 0, group 0, this lane's half and column).
     uint4 ra[2][MT][3];
     uint4 rb[2][NT][3];
+    const int drop = b3_drop();
     constexpr int NPA = W1 ? 1 : 3;  // weight planes fetched
     MI355_UNROLL
     for (int i = 0; i < MT; ++i)
@@ -46,9 +58,9 @@ __device__ __forceinline__ void b3_chunk(f32x16 (&acc)[MT][NA], const uint4* con
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) {
                     f32x16 c = acc[i][j];
-                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[cur][i][2], rb[cur][j][0], c);  // small terms first
-                    c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][2], c);
-                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][1], c);
+                    if constexpr (!W1) if (drop != 1) c = MFMA_32x32x16_BF16(ra[cur][i][2], rb[cur][j][0], c);  // small terms first
+                    if (drop != 2) c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][2], c);
+                    if constexpr (!W1) if (drop != 3) c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][1], c);
                     if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[cur][i][1], rb[cur][j][0], c);
                     c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][1], c);
                     c = MFMA_32x32x16_BF16(ra[cur][i][0], rb[cur][j][0], c);
@@ -71,6 +83,7 @@ __device__ __forceinline__ void b3_chunk_ra(f32x16 (&acc)[MT][NA], const uint4* 
     static_assert(RA >= 2 && NG % RA == 0 && RA - 1 <= NG, "ring of RA weight-fragment buffers");
     uint4 ra[RA][MT][3];
     uint4 rb[2][NT][3];
+    const int drop = b3_drop();
     constexpr int NPA = W1 ? 1 : 3;
     constexpr int D = RA - 1;  // groups ahead
     // linear group index n = k * NG + g of the K * NG groups; past the last one: the last again (every load unconditional)
@@ -108,9 +121,9 @@ __device__ __forceinline__ void b3_chunk_ra(f32x16 (&acc)[MT][NA], const uint4* 
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) {
                     f32x16 c = acc[i][j];
-                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[g % RA][i][2], rb[cur][j][0], c);  // small terms first
-                    c = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[cur][j][2], c);
-                    if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[g % RA][i][1], rb[cur][j][1], c);
+                    if constexpr (!W1) if (drop != 1) c = MFMA_32x32x16_BF16(ra[g % RA][i][2], rb[cur][j][0], c);  // small terms first
+                    if (drop != 2) c = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[cur][j][2], c);
+                    if constexpr (!W1) if (drop != 3) c = MFMA_32x32x16_BF16(ra[g % RA][i][1], rb[cur][j][1], c);
                     if constexpr (!W1) c = MFMA_32x32x16_BF16(ra[g % RA][i][1], rb[cur][j][0], c);
                     c = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[cur][j][1], c);
                     c = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[cur][j][0], c);

@@ -1100,3 +1100,57 @@ def test_bf16_weights_mode_keeps_the_text_side_exact(emu_lib):
         assert np.array_equal(got["bf16x3"][k], got["bf16w"][k]), k
     assert np.array_equal(got["bf16w"]["w_ceil"], ora["w_ceil"])
     assert got["bf16x3"]["err"] < 1e-5 and 1e-5 < got["bf16w"]["err"] < 2e-2, got
+
+
+def test_a_dropped_partial_product_is_caught(emu_lib, monkeypatch):
+    """the suite must fail when a split kernel loses one of its six partial products.  The CPU model's b3 loops (the
+    WaveNet layers, the staged convs, the encoder convs, the duration-predictor stacks) can leave out one of the three SMALL products on
+    request (MI355VITS_EMU_DROP = 1: l_w x h_x, 2: h_w x l_x, 3: m_w x m_x; csrc/b3.h, compiled into the CPU model only).  Measured here:
+    the intact engine is 3.3e-7 from the fp64 oracle (PyTorch fp32 itself: 3.6e-7); without l_w x h_x 2.0e-6, without m x m 6.1e-6,
+    without h_w x l_x 1.2e-5 — all three inside the CONTRACT tolerance (1e-4), which is exactly why the contract figure is not what the
+    suite checks.  Two guards catch them:
+      * check_parity's bound for the f32-grade modes (5e-6 vs the fp32 oracle) trips for the two larger ones;
+      * the self-calibrating criterion `error vs fp64 <= 3 x (PyTorch fp32's own error vs fp64)` (tests/util.py f32_grade_vs_fp64) trips
+        for all three, the weights' rounded l plane included, and holds for the intact engine in both f32-grade modes."""
+    import torch
+
+    from tests.util import REL_RMS_TOL, TIGHT_REL_RMS_TOL, f32_grade_vs_fp64
+
+    cfg = VitsConfig.tiny_h192()
+    w = W.synthetic_weights(cfg, seed=71, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    ids = np.random.default_rng(4).integers(1, cfg.num_symbols, (2, 30))
+    lengths = np.array([30, 17])
+    forced = np.full((2, 30), 4, np.int32)
+    rng = np.random.default_rng(1)
+    nw = rng.standard_normal((2, 2, 30)).astype(np.float32)
+    nz = rng.standard_normal((2, cfg.inter_channels, 120)).astype(np.float32)
+    scales = (0.667, 1.0, 0.8)
+    o64 = VitsOracle(cfg, w, dtype=torch.float64).infer(ids, lengths, scales, noise_w=nw, noise_z=nz, forced_durations=forced)
+    o32 = VitsOracle(cfg, w).infer(ids, lengths, scales, noise_w=nw, noise_z=nz, forced_durations=forced)
+
+    def engine_audio(mode, drop):
+        if drop:
+            monkeypatch.setenv("MI355VITS_EMU_DROP", str(drop))
+        else:
+            monkeypatch.delenv("MI355VITS_EMU_DROP", raising=False)
+        eng = Engine(blob, library=emu_lib)
+        eng.set_math(mode)
+        out = eng.run(ids, lengths, scales, forced_durations=forced, noise_w=nw, noise_z=nz)
+        eng.close()
+        monkeypatch.delenv("MI355VITS_EMU_DROP", raising=False)
+        return out
+
+    for mode in ("bf16x3", "f32"):
+        ok, e, e32 = f32_grade_vs_fp64(engine_audio(mode, 0), o64, o32)
+        assert ok, (mode, e, e32)
+    intact = engine_audio("bf16x3", 0)
+    caught_by_tight = 0
+    for drop in (1, 2, 3):
+        out = engine_audio("bf16x3", drop)
+        ok, e, e32 = f32_grade_vs_fp64(out, o64, o32)
+        assert not ok, (drop, e, e32)                  # the self-calibrating guard sees every one of them
+        assert e < REL_RMS_TOL, (drop, e)              # ... although all are inside the contract tolerance
+        worst = max(rel_rms(out["audio"][b, :int(out["lengths"][b])], intact["audio"][b, :int(out["lengths"][b])]) for b in range(2))
+        caught_by_tight += worst > TIGHT_REL_RMS_TOL
+    assert caught_by_tight >= 2                        # check_parity's 5e-6 bound: h_w x l_x and m x m

@@ -173,3 +173,28 @@ def test_device_side_gather_over_rccl_world_1():
     for b in range(3):
         assert np.array_equal(full[b], ref["pcm"][b, : int(ref["lengths"][b])])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_box_probe_reports_plausible_numbers_and_leaves_the_engine_untouched():
+    """mi355vits_probe_device / mi355vits_probe_weights (bench.py carries them in its line so that a slow lease can be told from a
+    slow kernel): every figure positive and inside what an MI355X can physically do, the weight-arena probe works on a live handle,
+    and a run after the probes gives the same bits as a run before them."""
+    from mimic3_amd._native import Engine, default_library
+
+    lib = default_library()
+    p = lib.probe_device(0)
+    assert p["cus"] > 0
+    assert 1e3 < p["l2_stream_GBps"] < 2e5 and 5e2 < p["hbm_copy_GBps"] < 8.1e3, p
+    assert 20 < p["l2_hit_latency_ns"] < 2e3 and p["l2_hit_latency_ns"] < p["latency_1GiB_ns"] < 5e3, p
+    assert 0 < p["l2_stream_beside_copy_GBps"] <= 1.2 * p["l2_stream_GBps"] and p["table_24MB_stream_GBps"] > 0, p
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=5, frames_per_id=2.0)
+    eng = Engine(W.pack(cfg, w), device=0)
+    ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (2, 40))
+    before = eng.run(ids, [40, 31], [0.667, 1.0, 0.8], seed=9, want_pcm16=True)
+    q = eng.probe_weights()
+    assert q["windows"] >= 1 and 0 < q["arena_stream1_GBps"][0] <= q["arena_stream1_GBps"][2] and 0 < q["arena_stream8_GBps"][0] <= q["arena_stream8_GBps"][2], q
+    after = eng.run(ids, [40, 31], [0.667, 1.0, 0.8], seed=9, want_pcm16=True)
+    assert np.array_equal(before["audio"], after["audio"]) and np.array_equal(before["pcm"], after["pcm"])
+    eng.close()
