@@ -3,8 +3,8 @@
 en_UK/apope_low VITS graph, hot path only (``onnx_model.run`` + ``audio_float_to_int16``, the reference's
 own timed region, mimic3_tts/voice.py:229-232).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W    # N > 1 without a launcher: re-executes itself under torch.distributed.run
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (what the driver launches for N > 1)
     python bench.py --gpus N --single-process        # one process, N devices (the unchanged mimic3-server's shape)
 
 A "step" is one pass of the hot path over the job's batch of synthetic phoneme ids.  Workload: BASELINE.json's
@@ -337,6 +337,50 @@ def print_table(title, table):
               f"{100 * row['share']:5.1f}%  {row['tflops']:7.2f} TFLOP/s  {row['gbs_algorithmic']:8.1f} GB/s", file=sys.stderr)
 
 
+def plan_launch(gpus, single_process, env, visible_devices):
+    """How `bench.py --gpus N` starts (no torch, no device: tests/test_session_and_sharding.py drives it with stubbed counts).
+
+    ("run",)                  this process is one rank of a WORLD_SIZE == N job (or N == 1): go on
+    ("single",)               --single-process: one process, one host thread per device (the mimic3-server shape)
+    ("reexec", make_cmd)      WORLD_SIZE unset and N > 1: `python bench.py --gpus N` re-executes itself as
+                              `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`
+                              (one rank per GPU over RCCL, exactly what the driver launches for N > 1)
+    ("error", message)        N devices requested, fewer visible / WORLD_SIZE disagrees with --gpus
+    """
+    launched = "WORLD_SIZE" in env
+    world = int(env.get("WORLD_SIZE", "1"))
+    if gpus < 1:
+        return ("error", f"--gpus {gpus}: need at least one device")
+    if visible_devices < 1:
+        return ("error", "bench.py needs an MI355X (no HIP device visible); there is no CPU fallback for the measured path")
+    if single_process and world == 1:
+        if visible_devices < gpus:
+            return ("error", f"{gpus} devices requested, {visible_devices} visible")
+        return ("single",)
+    if launched:
+        if world != gpus:
+            return ("error", f"--gpus {gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+        local = int(env.get("LOCAL_RANK", "0"))
+        if local >= visible_devices:
+            return ("error", f"{gpus} devices requested, {visible_devices} visible (LOCAL_RANK {local})")
+        return ("run",)
+    if gpus == 1:
+        return ("run",)
+    if visible_devices < gpus:
+        return ("error", f"{gpus} devices requested, {visible_devices} visible")
+
+    def make_cmd(python, script, argv):
+        import socket
+
+        with socket.socket() as s:  # a free rendezvous port on the loopback
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        return [python, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), script] + list(argv)
+
+    return ("reexec", make_cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,14 +418,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    single = args.single_process and world == 1
-    if not single and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node "
-                         f"{args.gpus}, or pass --single-process")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback for the measured path")
-    if single and torch.cuda.device_count() < args.gpus:
-        raise SystemExit(f"--single-process --gpus {args.gpus}: only {torch.cuda.device_count()} devices visible")
+    plan = plan_launch(args.gpus, args.single_process, os.environ,
+                       torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if plan[0] == "error":
+        raise SystemExit(plan[1])
+    if plan[0] == "reexec":  # plain `python bench.py --gpus N`: become the N-rank job the contract describes
+        cmd = plan[1](sys.executable, os.path.abspath(__file__), sys.argv[1:])
+        print("bench.py: WORLD_SIZE unset, --gpus %d -> %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(cmd[0], cmd)
+    single = plan[0] == "single"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -429,11 +475,16 @@ def main():
         out = w.run_steps(steps, device_only)
         barrier()
         el = time.perf_counter() - t0
-        if dist is not None:
+        per_rank[:] = [el]
+        if dist is not None:  # max over the ranks is the job's time; every rank's own time goes into the line
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            g = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(g, t)
+            per_rank[:] = [float(x.item()) for x in g]
+            el = max(per_rank)
         return el, out
+
+    per_rank = []
 
     wl.size_workspaces()
     mon = DeviceMonitor(local_rank)
@@ -483,6 +534,7 @@ def main():
     barrier()
     mon.start()  # (sampling starts with the warm-up steps; it reads two sysfs files every 10 ms)
     elapsed, out = timed(wl, calls, args.warmup * (n_gpus if single else 1))
+    headline_per_rank_ms = [e / args.steps * 1e3 for e in per_rank]
     dev_window = mon.stop()
     samples_per_call = int(out["lengths"].sum())
     samples_per_step = samples_per_call * n_gpus
@@ -498,8 +550,13 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "per_rank_ms_per_step": headline_per_rank_ms,  # every rank's own clock over the same K steps (ms_per_step = their max)
+        "world_size": (dist.get_world_size() if dist is not None else 1),  # as RCCL sees it (1: no process group)
+        "launch": ("single-process, one host thread per device" if single else
+                   ("torch.distributed.run, one rank per GPU (RCCL barrier + all_gather of the ranks' times)" if dist is not None else "one process")),
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
+        "headline_protocol": "r05+: step = BASELINE's batch 256 over the GPUs (strong); rounds 1-4: 32 utt/GPU (weak) -> compare b32_ms / b256_ms",
         "vs_baseline": None,
         "dtype": "f32" if math == "f32" else (
             "f32 in / out / accumulate; dense-conv operands as 2 x fp16 terms (22 significant bits, 3 f16-MFMA products per multiply-add), "

@@ -579,3 +579,53 @@ def struct_pack_u32(v):
     import struct
 
     return struct.pack("<I", v)
+
+
+def test_bench_launch_plan_with_stubbed_device_counts():
+    """`python bench.py --gpus N` must start by itself.  bench.plan_launch decides from (--gpus, --single-process,
+    the launcher's environment, the visible device count) without touching torch: plain N > 1 re-executes under
+    torch.distributed.run (one rank per GPU, loopback rendezvous), a launched rank goes on, too few devices is the ONE error."""
+    import sys
+
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from bench import plan_launch
+
+    assert plan_launch(1, False, {}, 1) == ("run",)
+    assert plan_launch(1, False, {}, 8) == ("run",)
+    kind, msg = plan_launch(8, False, {}, 1)            # this box: one device
+    assert kind == "error" and msg == "8 devices requested, 1 visible"
+    kind, msg = plan_launch(2, False, {}, 0)
+    assert kind == "error" and "no HIP device" in msg
+    kind, make = plan_launch(8, False, {}, 8)           # an 8-GPU node, no launcher: re-exec
+    assert kind == "reexec"
+    cmd = make("/usr/bin/python3", "/x/bench.py", ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[:3] == ["/usr/bin/python3", "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-7:] == ["/x/bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    # under the launcher (what the driver does for N > 1): every rank goes on; a disagreeing world size is refused
+    env = {"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3"}
+    assert plan_launch(4, False, env, 8) == ("run",)
+    assert plan_launch(8, False, env, 8)[0] == "error"
+    assert plan_launch(4, False, env, 2) == ("error", "4 devices requested, 2 visible (LOCAL_RANK 3)")
+    # WORLD_SIZE=1 exported by a launcher with --nproc-per-node 1 is a launched run too
+    assert plan_launch(1, False, {"WORLD_SIZE": "1"}, 1) == ("run",)
+    assert plan_launch(2, False, {"WORLD_SIZE": "1"}, 2)[0] == "error"
+    # the threads-in-one-process shape of the reference server stays available
+    assert plan_launch(4, True, {}, 4) == ("single",)
+    assert plan_launch(4, True, {}, 1) == ("error", "4 devices requested, 1 visible")
+
+
+def test_bench_cli_fails_only_for_missing_devices():
+    """The command itself, as the driver types it: on a box without (enough) devices it exits with the device-count message,
+    not with a usage error about launchers."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode != 0
+    tail = (r.stderr or r.stdout).strip().splitlines()[-1]
+    assert "devices requested" in tail or "no HIP device visible" in tail, tail
+    assert "torch.distributed.run" not in tail and "--single-process" not in tail
