@@ -198,6 +198,8 @@ float mi355vits_last_run_ms(mi355vits_handle h);
 /* Debug taps (needs MI355VITS_DEBUG_TAPS on the last run): copy the named intermediate to
  * `out` (capacity in floats); dims receives up to 4 extents.  Returns element count or < 0. */
 long mi355vits_get_tap(mi355vits_handle h, const char* name, float* out, size_t capacity, int64_t dims[4]);
+/* The same for rows [row0, row0 + nrows) of the tap's leading (batch) extent only; dims[0] = nrows. */
+long mi355vits_get_tap_rows(mi355vits_handle h, const char* name, long row0, long nrows, float* out, size_t capacity, int64_t dims[4]);
 long mi355vits_list_taps(mi355vits_handle h, char* buf, size_t cap);
 
 /* Kernel unit-test hook: one Conv1d through a chosen implementation on host buffers.

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "mi355vits_device_result", "mi355vits_set_math", "mi355vits_get_math",
     "mi355vits_get_config", "mi355vits_run", "mi355vits_fetch", "mi355vits_free_result",
     "mi355vits_last_error", "mi355vits_profile_enable", "mi355vits_profile_reset",
-    "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_list_taps",
+    "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_get_tap_rows", "mi355vits_list_taps",
     "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout", "mi355vits_bench_conv1d", "mi355vits_probe_device", "mi355vits_probe_weights",
 )
 
@@ -132,6 +132,9 @@ class NativeLibrary:
         L.mi355vits_get_tap.argtypes = [H, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t,
                                         ctypes.POINTER(ctypes.c_int64)]
         L.mi355vits_get_tap.restype = ctypes.c_long
+        L.mi355vits_get_tap_rows.argtypes = [H, ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t,
+                                            ctypes.POINTER(ctypes.c_int64)]
+        L.mi355vits_get_tap_rows.restype = ctypes.c_long
         L.mi355vits_list_taps.argtypes = [H, ctypes.c_char_p, ctypes.c_size_t]
         L.mi355vits_list_taps.restype = ctypes.c_long
         L.mi355vits_test_conv1d.argtypes = [ctypes.c_int, ctypes.POINTER(ConvTest)]
@@ -446,13 +449,19 @@ class Engine:
         self.native.lib.mi355vits_list_taps(self._h, buf, len(buf))
         return [t for t in buf.value.decode().splitlines() if t]
 
-    def tap(self, name: str) -> np.ndarray:
+    def tap(self, name: str, row0: int = 0, nrows: int = -1) -> np.ndarray:
+        """The named intermediate of the last ``debug_taps`` run as [B, C, T]; ``row0`` / ``nrows``: those batch rows only."""
         dims = (ctypes.c_int64 * 4)()
-        n = self.native.lib.mi355vits_get_tap(self._h, name.encode(), None, 0, dims)
+        L = self.native.lib
+        if nrows < 0:
+            get = lambda out, cap: L.mi355vits_get_tap(self._h, name.encode(), out, cap, dims)  # noqa: E731
+        else:
+            get = lambda out, cap: L.mi355vits_get_tap_rows(self._h, name.encode(), row0, nrows, out, cap, dims)  # noqa: E731
+        n = get(None, 0)
         if n < 0:
             self._check(int(n))
         out = np.empty(int(n), np.float32)
-        n2 = self.native.lib.mi355vits_get_tap(self._h, name.encode(), _fptr(out), out.size, dims)
+        n2 = get(_fptr(out), out.size)
         if n2 < 0:
             self._check(int(n2))
         shape = [int(d) for d in dims][:3]  # taps are [B, C, T]

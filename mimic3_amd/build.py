@@ -20,6 +20,8 @@ EMU = os.path.join(ROOT, "tests", "emu")
 SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_rbc.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
 PER_FILE_FLAGS = {}
 LAB_FILE_FLAGS = {}  # per-file flags of the lab build's side of a running A/B (none at the moment)
+# throw-away instrumented twins of the lab build (MI355_LAB_VARIANT=<name> python -m mimic3_amd.build lab -> libmi355vits_lab_<name>.so)
+VARIANT_FILE_FLAGS = {"clk": {"kernels_mrfp.cpp": ["-DMRFP_CLOCKS"]}}  # shader-clock stamps inside k_mrf_p<32> (MI355VITS_MRFP_CLOCKS=1)
 # sources the lab build compiles exactly as the product does (no -DMI355_LAB): k_mrf_p's in-loop ablation tests cost 15 % of its
 # time, and it is now the REFERENCE side of the sweep kernels' A/B (its own ablations are in profiles/r03_mrf_experiments.txt)
 LAB_AS_PRODUCT = {"kernels_mrfp.cpp"}
@@ -76,7 +78,7 @@ def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = 
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".cpp", ".o"))
         if force or verbose_resources or _stale(obj, [src] + hdrs):
-            lab_flags = (["-DMI355_LAB"] if s not in LAB_AS_PRODUCT else []) + ([] if variant else LAB_FILE_FLAGS.get(s, [])) if lab else []
+            lab_flags = (["-DMI355_LAB"] if s not in LAB_AS_PRODUCT else []) + (VARIANT_FILE_FLAGS.get(variant, {}).get(s, []) if variant else LAB_FILE_FLAGS.get(s, [])) if lab else []
             jobs.append(base + PER_FILE_FLAGS.get(s, []) + lab_flags + ["-c", src, "-o", obj])
     if jobs:
         from concurrent.futures import ThreadPoolExecutor

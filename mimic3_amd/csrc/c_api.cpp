@@ -215,6 +215,13 @@ long mi355vits_get_tap(mi355vits_handle h, const char* name, float* out, size_t 
     int rc = guarded(h, [&] { n = h->eng->get_tap(name, out, capacity, dims); });
     return rc == MI355VITS_OK ? n : rc;
 }
+long mi355vits_get_tap_rows(mi355vits_handle h, const char* name, long row0, long nrows, float* out, size_t capacity, int64_t dims[4]) {
+    if (!h || !name || !dims) return MI355VITS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->eng->mu);
+    long n = 0;
+    int rc = guarded(h, [&] { n = h->eng->get_tap(name, out, capacity, dims, row0, nrows < 0 ? 0 : nrows); });
+    return rc == MI355VITS_OK ? n : rc;
+}
 long mi355vits_list_taps(mi355vits_handle h, char* buf, size_t cap) {
     if (!h || !buf || cap == 0) return MI355VITS_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->eng->mu);

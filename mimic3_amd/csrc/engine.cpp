@@ -744,16 +744,22 @@ void Engine::tap(const char* name, const float* dev, std::initializer_list<int64
     taps_.push_back(std::move(t));
 }
 
-long Engine::get_tap(const std::string& name, float* out, size_t cap, int64_t dims[4]) {
+// rows [row0, row0 + nrows) of the leading (batch) extent; nrows < 0: all rows (a batch-256 stage tap is 6.4 GB: the tests fetch the rows they check)
+long Engine::get_tap(const std::string& name, float* out, size_t cap, int64_t dims[4], long row0, long nrows) {
     for (auto& t : taps_)
         if (t.name == name) {
             for (int i = 0; i < 4; ++i) dims[i] = i < (int)t.dims.size() ? t.dims[i] : 1;
+            const long rows = t.dims.empty() ? 1 : (long)t.dims[0];
+            if (nrows < 0) { row0 = 0; nrows = rows; }
+            if (row0 < 0 || nrows < 0 || row0 + nrows > rows) throw EngineError(MI355VITS_ERR_INVALID, "tap rows out of range");
+            const size_t per_row = rows > 0 ? t.count / (size_t)rows : 0, cnt = per_row * (size_t)nrows;
+            dims[0] = nrows;
             if (out) {
-                if (cap < t.count) throw EngineError(MI355VITS_ERR_INVALID, "tap buffer too small");
+                if (cap < cnt) throw EngineError(MI355VITS_ERR_INVALID, "tap buffer too small");
                 HIP_CHECK(hipStreamSynchronize(stream_));
-                HIP_CHECK(hipMemcpy(out, t.dev, t.count * sizeof(float), hipMemcpyDeviceToHost));
+                if (cnt) HIP_CHECK(hipMemcpy(out, t.dev + per_row * (size_t)row0, cnt * sizeof(float), hipMemcpyDeviceToHost));
             }
-            return (long)t.count;
+            return (long)cnt;
         }
     throw EngineError(MI355VITS_ERR_INVALID, "no such tap: " + name);
 }

@@ -136,7 +136,7 @@ class Engine {
     int math() const { return math_; }
     Profiler& profiler() { return prof_; }
     float last_run_ms();
-    long get_tap(const std::string& name, float* out, size_t cap, int64_t dims[4]);
+    long get_tap(const std::string& name, float* out, size_t cap, int64_t dims[4], long row0 = 0, long nrows = -1);
     std::string list_taps() const;
     std::string last_error;
     std::mutex mu;

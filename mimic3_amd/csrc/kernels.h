@@ -132,6 +132,7 @@ struct MrfArgs {
                              // the remaining resblocks are accumulated onto y by the conv-by-conv path)
     int ablate = 0;  // profiling only (MI355VITS_MRF_ABLATE): 1 = skip MFMA loops, 2 = skip staging, 4 = skip output
     int seg = 0;     // launch_mrf_s: columns per work item (a multiple of the kernel's step), from mrf_s_segment
+    unsigned* clk = nullptr;  // -DMRFP_CLOCKS lab builds only: shader-clock stamps (kernels_mrfp.cpp)
 };
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);

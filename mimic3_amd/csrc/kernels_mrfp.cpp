@@ -235,6 +235,21 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
     };
     auto no_fill = [&](int) MI355_INLINE_LAMBDA {};
     const float inv_rb = 1.0f / (float)a.nrb;  // the mean as one multiply per element (k_mrf_s does the same: the two agree bit for bit)
+    // MRFP_CLOCKS (a throw-away lab build): shader-clock stamps of waves 0 and 4 (one SIMD's pair) of workgroup 7, 32 per item
+    [[maybe_unused]] int clk_item = 0;
+    auto stamp = [&](int k) MI355_INLINE_LAMBDA {
+#if defined(MRFP_CLOCKS) && !defined(MI355_EMU)
+        if (a.clk) {
+            const unsigned t = (unsigned)__builtin_readcyclecounter();
+            const BufRsrc dbg = buf_rsrc(a.clk);
+            const int sl = wid == 0 ? 0 : (wid == 4 ? 1 : -1);
+            const unsigned o = (lane == 0 && sl >= 0 && blockIdx.x == 7 && clk_item < 8) ? 4u * (unsigned)((sl * 8 + clk_item) * 32 + k) : BUF_OOB;
+            buf_store_f32(dbg, o, 0u, __uint_as_float(t));
+        }
+#else
+        (void)k;
+#endif
+    };
 
     for (; item < item_end; item += nslot) {
         // lane / wave coordinates, re-derived per item from values the optimiser cannot see through: everything computed
@@ -258,8 +273,11 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         const int item_next = item + nslot;
         const bool more = item_next < item_end;  // wave-uniform
 
+        stamp(0);
         stage_item(b, t0, len);
+        stamp(1);
         __syncthreads();  // x is staged; every wave is done with the previous item's x1
+        stamp(2);
 
         f32x4 out[NT2];
         MI355_UNROLL
@@ -297,6 +315,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                     for (int r = 0; r < 4; ++r) acc1[ti][r] = (LAB_ABLATE(a) & 32) ? 0.0f : xb[(long)(co0 + r) * a.x_ld + tc];
                 }
             }
+            stamp(3 + 8 * j);
             Pend pend;
             pend.base = reinterpret_cast<uint2*>(X1p + (gq * 4 + q) * LD1) + hh;  // this lane's half records of x1, column 0
             MI355_UNROLL
@@ -328,7 +347,9 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                         MI355_UNROLL
                         for (int r = 0; r < 4; ++r) acc1[ti][r] = ab[r] + as[r];
                         if (fin) {
+                            if (oi == 0) stamp(4 + 8 * j);
                             if (j > 0 && oi == 0) __syncthreads();  // every wave is done reading the previous resblock's x1
+                            if (oi == 0) stamp(10 + 8 * j);
                             const int t = t0 - r2 + e;
                             pend.x1 = acc1[ti];
                             pend.e = e;
@@ -337,8 +358,11 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                     }
                 }
             }
+            stamp(5 + 8 * j);
             epi_piece(pend, 0); epi_piece(pend, 1); epi_piece(pend, 2);  // the last tile's epilogue has no MFMAs left to hide behind
+            stamp(6 + 8 * j);
             __syncthreads();
+            stamp(7 + 8 * j);
             // ---- conv2 into the output registers: out += x1 + bias + conv(lrelu(x1)); this wave: tiles cg NT2 .. + NT2 - 1
             const float* bs2 = BS + (j * 2 + 1) * C;
             const float4 bv2 = *reinterpret_cast<const float4*>(bs2 + co0);
@@ -369,8 +393,10 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                     }
                     MI355_UNROLL
                     for (int r = 0; r < 4; ++r) out[i][r] = ab[r] + as[r];
+                    if (g == G - 1 && i == 0) stamp(8 + 8 * j);
                 }
             }
+            stamp(9 + 8 * j);
         };
 
         resblock(std::integral_constant<int, K0>{}, std::integral_constant<int, K1>{}, std::integral_constant<int, 0>{});
@@ -390,6 +416,8 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         };
         if (a.out_scale > 0.0f) store_all(std::false_type{});
         else store_all(std::true_type{});
+        stamp(27);
+        ++clk_item;
     }
 }
 
@@ -523,6 +551,35 @@ void launch_mrf_p(MrfArgs a, hipStream_t s) {
 #endif
     auto go = [&](auto kfn) {
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)MRFP_LDS_LIMIT);
+#if defined(MRFP_CLOCKS) && !defined(MI355_EMU)
+        static int shots = 0;
+        if (a.C == 32 && getenv("MI355VITS_MRFP_CLOCKS") && grid.x > 7 && shots < 3) {  // (the first launch warms the caches)
+            ++shots;
+            unsigned* dbg = nullptr;
+            const size_t nb = 2 * 8 * 32 * sizeof(unsigned);
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbg), nb));
+            HIP_CHECK(hipMemsetAsync(dbg, 0, nb, s));
+            MrfArgs c = a;
+            c.clk = dbg;
+            LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, c);
+            HIP_CHECK(hipStreamSynchronize(s));
+            unsigned h[2 * 8 * 32];
+            HIP_CHECK(hipMemcpy(h, dbg, nb, hipMemcpyDeviceToHost));
+            (void)hipFree(dbg);
+            for (int sl = 0; sl < 2; ++sl)
+                for (int it = 1; it < 6; ++it) {
+                    const unsigned* t = &h[(sl * 8 + it) * 32];
+                    fprintf(stderr, "mrf_p<32> clocks shot %d wave %d item %d: stage %u bar %u |", shots, sl * 4, it, t[1] - t[0], t[2] - t[1]);
+                    for (int j = 0; j < 3; ++j) {
+                        const unsigned* r = t + 3 + 8 * j;  // r[0] conv1 start, r[1] first tile done, r[7] after the x1 barrier (j > 0), r[2] last sweep done, r[3] epilogue tail, r[4] barrier, r[5] conv2 first tile, r[6] conv2 done
+                        fprintf(stderr, " rb%d: c1.init+tile0 %u x1bar %u c1.rest %u tail %u bar %u c2.tile0 %u c2.rest %u |", j, r[1] - r[0], r[7] - r[1], r[2] - r[7], r[3] - r[2],
+                                r[4] - r[3], r[5] - r[4], r[6] - r[5]);
+                    }
+                    fprintf(stderr, " stores %u | item %u\n", t[27] - t[3 + 16 + 6], t[27] - t[0]);
+                }
+            return;
+        }
+#endif
         LAUNCH_KERNEL(kfn, grid, dim3(512), shmem, s, a);
     };
     const int k1 = a.nrb > 1 ? a.k[1] : 0, k2 = a.nrb > 2 ? a.k[2] : 0;
