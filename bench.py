@@ -751,6 +751,7 @@ def main():
         result["longform_total_ms"] = lf["default"]["total_ms"]
         result["longform_bf16w_first_audio_ms"] = lf["bf16w"]["first_audio_ms"]
         result["longform_bf16w_total_ms"] = lf["bf16w"]["total_ms"]
+        result["longform_padding_efficiency"] = lf["default"]["padding_efficiency"]  # valid / computed output samples of the planned batches
         result["config"]["longform_stream"] = (
             "120 sentences %.0f s audio: first audio %.1f ms, all in %.0f ms = %.0f x RT; bf16w %.1f / %.0f ms; chunks==calls %s, lengths== %s" % (
                 lf["default"]["audio_s"], lf["default"]["first_audio_ms"], lf["default"]["total_ms"], lf["default"]["x_realtime"],
@@ -898,7 +899,8 @@ def longform_stream(cfg, weights, math, n_sentences=120, look_ahead=32):
     (what ``/api/tts/stream`` runs per request, mimic3_amd/http_stream.py; the reference joins the sentences of
     ``end_utterance`` into one WAV, mimic3_http/app.py:157-227, tts.py:470-515) on ONE shared session: 3 lanes per device, 1 ms
     micro-batch window, every visible device (``devices="all"``).  first_audio_ms = request start -> first chunk in the caller's
-    hands; total_ms = last chunk.  In-leg check at deterministic scales: the streamed chunks are BITWISE the per-sentence calls."""
+    hands; total_ms = last chunk.  In-leg check at deterministic scales: the streamed chunks are BITWISE the per-sentence calls.
+    padding_efficiency = valid / computed output samples over the planned batches (a batch computes every row to its longest)."""
     from mimic3_amd import streaming as ST
     from mimic3_amd import weights as W
     from mimic3_amd.session import InferenceSession, SessionOptions
@@ -915,15 +917,25 @@ def longform_stream(cfg, weights, math, n_sentences=120, look_ahead=32):
         sentences = [rng.integers(1, 50, int(rng.integers(40, 161))).astype(np.int64).tolist() for _ in range(n_sentences)]
         list(ST.stream_sentences(sess, sentences[:look_ahead], look_ahead=look_ahead))  # warm-up: workspaces of every lane sized
         runs = []
+        stats = {}
         for _ in range(3):
             t0 = time.perf_counter()
             first, n = None, 0
-            for audio in ST.stream_sentences(sess, sentences, look_ahead=look_ahead):
+            # a list: stream_sentences PLANS the request (sentence 0 alone, a head batch, the rest length-sorted inside its
+            # phoneme-length class: mimic3_amd.streaming.plan_batches; tts.py:470-515 holds all pending sentences the same way)
+            for audio in ST.stream_sentences(sess, sentences, look_ahead=look_ahead, stats=stats):
                 if first is None:
                     first = time.perf_counter() - t0
                 n += audio.shape[0]
             runs.append((time.perf_counter() - t0, first, n))
         total, first, n = sorted(runs)[1]  # the median run
+        # round 5's shape for comparison: one call per sentence from a thread pool, batches formed by arrival (a lazy iterable)
+        t0 = time.perf_counter()
+        first_lazy = None
+        for audio in ST.stream_sentences(sess, iter(sentences), look_ahead=look_ahead):
+            if first_lazy is None:
+                first_lazy = time.perf_counter() - t0
+        total_lazy = time.perf_counter() - t0
         # the check: deterministic scales (a call's Philox draws are keyed by its utterance number, which concurrent calls take
         # in arrival order), 16 sentences streamed with 16 in flight == the same sentences one call at a time, bit for bit
         det = (0.0, 1.0, 0.0)
@@ -934,7 +946,11 @@ def longform_stream(cfg, weights, math, n_sentences=120, look_ahead=32):
                 "lanes_per_device": 3, "micro_batch_window_ms": 1.0, "devices": list(sess.devices),
                 "first_audio_ms": first * 1e3, "total_ms": total * 1e3, "audio_s": n / SAMPLE_RATE,
                 "x_realtime": n / SAMPLE_RATE / total, "samples_per_s": n / total, "runs_total_ms": [r[0] * 1e3 for r in runs],
-                "chunks_equal_single_calls": bool(same), "det_lengths": [int(a.shape[0]) for a in streamed]}
+                "chunks_equal_single_calls": bool(same), "det_lengths": [int(a.shape[0]) for a in streamed],
+                "planned_batches": stats.get("batches"), "padding_efficiency": stats.get("padding_efficiency"),
+                "text_padding_efficiency": stats.get("text_padding_efficiency"),
+                "arrival_batched": {"first_audio_ms": first_lazy * 1e3, "total_ms": total_lazy * 1e3,
+                                    "note": "the same request as a lazy iterable: one call per sentence, micro-batched by arrival"}}
     finally:
         sess.close()
 

@@ -135,6 +135,13 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
     constexpr int G = C / 32, T_B = 16 * NWC * NT2, TAP = G * 3 * 64, NT1 = NT2 + NHMAX;
     constexpr int AH = G == 1 ? 2 : 1;  // B fragments ahead of their MFMAs
     constexpr int RB = 4;               // records a thread stages per item (4 G records per column, column sets share them)
+    // PIPE (32 channels; round 6): the x tile is dead once the LAST resblock's conv1 is through, so the NEXT item's x is staged
+    // under that resblock's conv2 — record u's eight loads at the start of tile u, its leaky-relu / split / plane stores dealt out
+    // between the MFMAs of tile u + 1 — and the stage's output leaves tile by tile behind the following tile's loads instead of
+    // in one burst at the end.  Shader-clock stamps of round 5's form (profiles/r06_mrfp_clocks.txt): 4.4 k cycles of staging +
+    // 3 k at its barrier + 1.5 - 2.7 k of stores per 56 k-cycle item with no MFMA in flight.  Same bits.
+    constexpr bool PIPE = G == 1;
+    static_assert(!PIPE || NT2 >= RB + 1, "one staged record per conv2 tile, finished under the next one");
     DYN_SMEM(float, smem);
     const int LDX = SH::LDX ? SH::LDX : a.ldx, LD1 = SH::LD1 ? SH::LD1 : a.ld1, R = a.R;
     const int PSX = G * 4 * LDX, PS1 = G * 4 * LD1;
@@ -198,6 +205,34 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         }
     };
     static_assert(4 * G <= 2 * RB, "one batch of RB records per thread covers a column (at most two column sets)");
+    // PIPE: a thread's column of the NEXT item (every wave takes part: columns past the tile are clamped to its last one, their
+    // lanes write the same bits to the same slots — no divergent branch inside the matrix stream), record u = channels 8 u .. + 7
+    struct NextItem { int b, t0, len; };
+    auto pipe_load = [&](const NextItem& nx, int pc, int u, float (&sv)[8]) MI355_INLINE_LAMBDA {
+        const int lst = nx.len > 0 ? nx.len - 1 : 0;
+        const int tt = nx.t0 - R + pc;
+        const int tc = tt < 0 ? 0 : (tt > lst ? lst : tt);
+        const BufRsrc xr = buf_rsrc(a.x + (long)nx.b * a.x_bs);
+        MI355_UNROLL
+        for (int e = 0; e < 8; ++e) sv[e] = buf_load_f32(xr, 4u * (unsigned)tc, 4u * (unsigned)((8 * u + e) * a.x_ld));
+    };
+    auto pipe_finish = [&](const NextItem& nx, int pc, int u, const float (&sv)[8], unsigned (&h4)[4], unsigned (&m4)[4], unsigned (&l4)[4], int piece) MI355_INLINE_LAMBDA {
+        if (piece < 0 || piece > 3) return;
+        const int tt = nx.t0 - R + pc;
+        const bool s_in = tt >= 0 && tt < nx.len;
+        const float v0 = s_in ? lrelu_f(sv[2 * piece], 0.1f) : 0.0f, v1 = s_in ? lrelu_f(sv[2 * piece + 1], 0.1f) : 0.0f;
+        MRFP_SPLIT(v0, v1, h4[piece], m4[piece], l4[piece]);
+        if (piece == 3) {
+            const int o = u * LDX + pc;
+            uint4 h, m, l;
+            h.x = h4[0]; h.y = h4[1]; h.z = h4[2]; h.w = h4[3];
+            m.x = m4[0]; m.y = m4[1]; m.z = m4[2]; m.w = m4[3];
+            l.x = l4[0]; l.y = l4[1]; l.z = l4[2]; l.w = l4[3];
+            Xp[o] = h;
+            Xp[PSX + o] = m;
+            Xp[2 * PSX + o] = l;
+        }
+    };
 
 
     // conv1's epilogue of one tile in three pieces (dealt out between the next tile's MFMAs): x1 (zero outside the row) ->
@@ -251,6 +286,17 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
 #endif
     };
 
+    if constexpr (PIPE) {  // the workgroup's first item is staged here, every later one under its predecessor's last conv2
+        if (item < item_end) {
+            const int b0 = item / ntile, t00 = (item - b0 * ntile) * T_B;
+            int len0 = a.len ? a.len[b0] : a.T;
+            if (len0 > a.T) len0 = a.T;
+            spart = wid / wpc;
+            scol = wid * 64 + lane - spart * wpc * 64;
+            stager = spart < nparts && scol < LDX && spart * RB < 4 * G;
+            stage_item(b0, t00, len0);
+        }
+    }
     for (; item < item_end; item += nslot) {
         // lane / wave coordinates, re-derived per item from values the optimiser cannot see through: everything computed
         // from them stays inside the loop body (hoisted out, the invariant addresses of ~50 unrolled tiles spill)
@@ -274,8 +320,18 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         const bool more = item_next < item_end;  // wave-uniform
 
         stamp(0);
-        stage_item(b, t0, len);
+        if constexpr (!PIPE) stage_item(b, t0, len);
         stamp(1);
+        // PIPE: the next item of this workgroup (the current one again behind the last: its x tile is dead, the loads hit the L2)
+        NextItem nx;
+        nx.b = more ? WAVE_UNIFORM(item_next / ntile) : b;
+        nx.t0 = more ? WAVE_UNIFORM((item_next - nx.b * ntile) * T_B) : t0;
+        {
+            int ln = a.len ? a.len[nx.b] : a.T;
+            if (ln > a.T) ln = a.T;
+            nx.len = WAVE_UNIFORM(ln);
+        }
+        const int pcol = wid_o * 64 + lane_o < LDX ? wid_o * 64 + lane_o : LDX - 1;
         __syncthreads();  // x is staged; every wave is done with the previous item's x1
         stamp(2);
 
@@ -367,11 +423,32 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
             const float* bs2 = BS + (j * 2 + 1) * C;
             const float4 bv2 = *reinterpret_cast<const float4*>(bs2 + co0);
             const float b2[4] = {bv2.x, bv2.y, bv2.z, bv2.w};
+            [[maybe_unused]] float sv[2][8];          // PIPE: the staged records in flight (loaded under tile u, finished under tile u + 1)
+            [[maybe_unused]] unsigned h4[4], m4[4], l4[4];
+            constexpr bool piped = PIPE && last_rb;
+            static_assert(!piped || K >= 4, "a staged record's four element pairs ride in four steps of a conv2 tile");
+            const float oscale = a.out_scale > 0.0f ? a.out_scale : inv_rb;
+            auto store_tile = [&](int i) MI355_INLINE_LAMBDA {  // (PIPE) the finished output tile i: lanes past the row switched off by the buffer's range check
+                const int t = t0 + (cg * NT2 + i) * 16 + n;
+                const BufRsrc yr = buf_rsrc(a.y + (long)b * a.y_bs);
+                const unsigned vo = t < a.T ? 4u * (unsigned)(co0 * a.y_ld + t) : BUF_OOB;
+                MI355_UNROLL
+                for (int r = 0; r < 4; ++r) buf_store_f32(yr, vo, 4u * (unsigned)(r * a.y_ld), out[i][r] * oscale);
+            };
             MI355_UNROLL
             for (int g = 0; g < G; ++g) {
                 const uint4* wn = g + 1 < G ? wptr(j, 1, K, g + 1) : (last_rb ? wptr(0, 0, K0, 0) : wptr(j + 1, 0, KNEXT, 0));
                 MI355_UNROLL
                 for (int i = 0; i < NT2; ++i) {
+                    if constexpr (piped) {  // loads first, then the previous tile's stores: waiting for a record never waits for a store issued after it
+                        if (i < RB) pipe_load(nx, pcol, i, sv[i & 1]);
+                        if (i > 0) store_tile(i - 1);
+                    }
+                    auto c2fill = [&](int s) MI355_INLINE_LAMBDA {
+                        if constexpr (piped) {
+                            if (i > 0 && i <= RB) pipe_finish(nx, pcol, i - 1, sv[(i - 1) & 1], h4, m4, l4, s);
+                        }
+                    };
                     f32x4 ab = out[i], as;
                     MI355_UNROLL
                     for (int r = 0; r < 4; ++r) {
@@ -381,11 +458,11 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                     const uint4* xq = X1p + (g * 4 + q) * LD1 + (cg * NT2 + i) * 16 + n;
                     if (!(LAB_ABLATE(a) & 1)) {
                         if (i == NT2 - 1 && !(LAB_ABLATE(a) & 8)) {
-                            if (g + 1 < G) mrfp_sweep<K, AH, K>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
-                            else if (!last_rb || more) mrfp_sweep<K, AH, KAFTER>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
-                            else mrfp_sweep<K, AH, 0>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
+                            if (g + 1 < G) mrfp_sweep<K, AH, K>(ab, as, W, xq, PS1, d2, c2fill, wn, lane_o, TAP);
+                            else if (!last_rb || more) mrfp_sweep<K, AH, KAFTER>(ab, as, W, xq, PS1, d2, c2fill, wn, lane_o, TAP);
+                            else mrfp_sweep<K, AH, 0>(ab, as, W, xq, PS1, d2, c2fill, wn, lane_o, TAP);
                         } else {
-                            mrfp_sweep<K, AH, 0>(ab, as, W, xq, PS1, d2, no_fill, wn, lane_o, TAP);
+                            mrfp_sweep<K, AH, 0>(ab, as, W, xq, PS1, d2, c2fill, wn, lane_o, TAP);
                         }
                     } else if (i == NT2 - 1 && !(LAB_ABLATE(a) & 8)) {
                         if (g + 1 < G) mrfp_load_w<K>(W, wn, lane_o, TAP);
@@ -396,6 +473,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                     if (g == G - 1 && i == 0) stamp(8 + 8 * j);
                 }
             }
+            if constexpr (piped) store_tile(NT2 - 1);
             stamp(9 + 8 * j);
         };
 
@@ -414,8 +492,10 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
                 }
             }
         };
-        if (a.out_scale > 0.0f) store_all(std::false_type{});
-        else store_all(std::true_type{});
+        if constexpr (!PIPE) {
+            if (a.out_scale > 0.0f) store_all(std::false_type{});
+            else store_all(std::true_type{});
+        }
         stamp(27);
         ++clk_item;
     }

@@ -286,9 +286,13 @@ class _MicroBatcher:
         self.batches = 0
         self.requests = 0
         self._count_lock = threading.Lock()
+        # batches handed to a lane and not back yet (the dispatcher holds a new batch back while every lane has one)
+        self._inflight = 0
+        self._inflight_cv = threading.Condition()
         # with several lanes the dispatcher hands each batch to a worker and goes back to collecting, so that one batch
         # can run its launch-bound front half while the previous one is still in its matrix-core back half
         lanes = len(getattr(session, "_engines", [None]))
+        self._lanes = max(1, lanes)
         self._pool = None
         if lanes > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -308,24 +312,55 @@ class _MicroBatcher:
         import queue
         import time
 
+        lanes = self._lanes
         while True:
             first = self._q.get()
             if first is None:
                 return
             items = [first]
-            deadline = time.perf_counter() + self._window
-            while len(items) < self._max:
-                left = deadline - time.perf_counter()
-                if left <= 0:
-                    break
+            stop = False
+
+            def take(timeout):  # one more request into `items`; False when there is none (yet) or the batcher is closing
+                nonlocal stop
                 try:
-                    nxt = self._q.get(timeout=left)
+                    nxt = self._q.get(timeout=timeout) if timeout > 0 else self._q.get_nowait()
                 except queue.Empty:
-                    break
+                    return False
                 if nxt is None:
                     self._q.put(None)
-                    break
+                    stop = True
+                    return False
                 items.append(nxt)
+                return True
+
+            # (1) the arrival window — skipped for a lone request on an idle session: nothing is in flight and nothing else has
+            # arrived, so waiting could only add latency to the very call the reference makes most (one sentence, voice.py:230);
+            # a burst then forms behind that first call.  (2) while EVERY lane has a batch, keep collecting instead of queueing
+            # small batches behind the lanes: under load a batch is everything that arrived while the chip was busy (round 5's
+            # fixed window cut 64 closed-loop clients into batches of 8: profiles/r05_serve_bench.log).
+            with self._inflight_cv:
+                idle = self._inflight == 0
+            while len(items) < self._max and not stop and take(0):  # a backlog (the chip was busy) is a batch already
+                pass
+            if len(items) == 1 and not idle:
+                deadline = time.perf_counter() + self._window
+                while len(items) < self._max and not stop:
+                    left = deadline - time.perf_counter()
+                    if left <= 0 or not take(left):
+                        break
+            while not stop:
+                with self._inflight_cv:
+                    if self._inflight < lanes:
+                        break
+                    if len(items) >= self._max:
+                        self._inflight_cv.wait(timeout=0.05)  # a full batch waits for a lane, nothing more to collect
+                        continue
+                if not take(0.0002):
+                    with self._inflight_cv:
+                        if self._inflight >= lanes:
+                            self._inflight_cv.wait(timeout=0.0002)
+            while len(items) < self._max and not stop and take(0):  # whatever arrived meanwhile rides along
+                pass
             # only requests with identical scales / output kind can share a call (the ABI takes one `scales`); and only
             # requests of the same phoneme-length class: the text encoder picks its attention / FFN kernels by the padded
             # length (<= 128, 256, 512, beyond), so within a class a row gets the kernels — and the bits — it would get alone
@@ -336,10 +371,20 @@ class _MicroBatcher:
                 key = (tuple(np.asarray(it[2], np.float32).tolist()), it[3] is None, tuple(sorted(it[4].items())), bucket)
                 groups.setdefault(key, []).append(it)
             for group in groups.values():
+                with self._inflight_cv:
+                    self._inflight += 1
                 if self._pool is not None:
-                    self._pool.submit(self._run_group, group)
+                    self._pool.submit(self._run_counted, group)
                 else:
-                    self._run_group(group)
+                    self._run_counted(group)
+
+    def _run_counted(self, group):
+        try:
+            self._run_group(group)
+        finally:
+            with self._inflight_cv:
+                self._inflight -= 1
+                self._inflight_cv.notify_all()
 
     def _run_group(self, group):
         try:

@@ -43,15 +43,138 @@ def _feed(ids: Sequence[int], scales, sid: Optional[int]) -> Dict[str, np.ndarra
     return feed
 
 
+def _tx_class(n: int) -> int:
+    """The phoneme-length classes within which a batched row gets the kernels — and the bits — it gets alone (the text encoder
+    picks its attention / FFN kernels by the padded length; session._MicroBatcher groups arrivals the same way)."""
+    return 0 if n <= 128 else (1 if n <= 256 else (2 if n <= 512 else 3))
+
+
+def plan_batches(lengths: Sequence[int], head: int = 7, max_batch: int = 48) -> list:
+    """Batches for a request whose sentences are all known (``end_utterance`` holds every pending ``Mimic3Phonemes`` when it
+    starts, ``mimic3_tts/tts.py:470-515``): sentence 0 ALONE (its audio is what the listener waits for), then the next ``head``
+    sentences as one batch (playback continues from them), then everything else sorted by length inside its phoneme-length
+    class and cut into batches of at most ``max_batch`` — rows of one batch have similar lengths, so little of a batched call
+    is padding (the decoder computes every row up to the batch's longest).  Returns lists of sentence indices, in the order the
+    batches should be issued (by the earliest sentence they hold)."""
+    n = len(lengths)
+    if n == 0:
+        return []
+    batches = [[0]]
+    if n > 1:
+        first = list(range(1, min(n, 1 + max(0, head))))
+        by_class: dict = {}
+        for i in first:
+            by_class.setdefault(_tx_class(int(lengths[i])), []).append(i)
+        batches.extend(by_class.values())
+    rest = list(range(1 + max(0, head), n))
+    by_class = {}
+    for i in rest:
+        by_class.setdefault(_tx_class(int(lengths[i])), []).append(i)
+    tail = []
+    for idx in by_class.values():
+        idx.sort(key=lambda i: (int(lengths[i]), i))
+        nb = -(-len(idx) // max(1, max_batch))
+        size = -(-len(idx) // nb)  # equal shares instead of full batches + a remainder
+        for k in range(0, len(idx), size):
+            tail.append(sorted(idx[k:k + size]))
+    tail.sort(key=lambda b: b[0])
+    return batches + tail
+
+
+def _batch_feed(rows: Sequence[Sequence[int]], scales, sid: Optional[int]) -> Dict[str, np.ndarray]:
+    tx = max(len(r) for r in rows)
+    ids = np.zeros((len(rows), tx), np.int64)
+    for b, r in enumerate(rows):
+        ids[b, : len(r)] = np.asarray(r, np.int64)
+    feed = {"input": ids, "input_lengths": np.array([len(r) for r in rows], np.int64), "scales": np.asarray(scales, np.float32)}
+    if sid is not None:
+        feed["sid"] = np.full(len(rows), int(sid), np.int64)
+    return feed
+
+
+def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1.0, 0.8), sid: Optional[int] = None,
+                   volume: Optional[float] = None, head: int = 7, max_batch: int = 48, workers: int = 4,
+                   stats: Optional[dict] = None) -> Iterator[np.ndarray]:
+    """``stream_sentences`` for a request whose sentence list is known up front ("look-ahead batching of all
+    Mimic3Phonemes pending in one end_utterance"): the batches of ``plan_batches`` are issued as BATCHED engine calls on the
+    session's lanes (no arrival window, no per-sentence thread), the chunks are yielded in sentence order as their batches
+    finish.  A batched row is bitwise its single call (same phoneme-length class), so the stream's bytes do not depend on the
+    plan.  ``stats`` (optional dict) receives ``batches``, ``padding_efficiency`` = valid / computed output samples (a batch
+    computes every row up to its longest) and ``text_padding_efficiency`` (the same for phoneme positions).
+
+    A failing sentence: its batch is retried row by row, the error surfaces at that sentence's turn, later ones are not
+    delivered."""
+    sentences = [list(s) for s in sentences]
+    plan = plan_batches([len(s) for s in sentences], head=head, max_batch=max_batch)
+    if not plan:
+        return
+    pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="mi355vits-plan")
+    done: Dict[int, object] = {}
+    valid = computed = tvalid = tcomputed = 0
+
+    def run_batch(idx):
+        try:
+            rows, lengths = session.run_pcm16(_batch_feed([sentences[i] for i in idx], scales, sid), volume=volume)
+            return [np.array(r, copy=True) for r in rows], np.asarray(lengths)
+        except Exception:
+            if len(idx) == 1:
+                raise
+            out = []  # a bad row must not take its batch-mates with it: one call per row, each with its own outcome
+            for i in idx:
+                try:
+                    out.append(session.run_pcm16(_feed(sentences[i], scales, sid), volume=volume)[0][0])
+                except Exception as e:  # noqa: BLE001 - delivered at the sentence's turn
+                    out.append(e)
+            return out, None
+
+    futs = [(idx, pool.submit(run_batch, idx)) for idx in plan]
+    try:
+        nxt = 0
+        for idx, fut in futs:
+            rows, lengths = fut.result()
+            if lengths is not None:
+                valid += int(np.sum(lengths))
+                computed += int(np.max(lengths)) * len(idx)
+                tvalid += sum(len(sentences[i]) for i in idx)
+                tcomputed += max(len(sentences[i]) for i in idx) * len(idx)
+            for i, r in zip(idx, rows):
+                done[i] = r
+            while nxt in done:
+                r = done.pop(nxt)
+                if isinstance(r, Exception):
+                    raise r
+                nxt += 1
+                yield r
+    finally:
+        for _idx, f in futs:
+            f.cancel()
+        pool.shutdown(wait=True)
+        if stats is not None:
+            stats.update({"batches": [len(i) for i in plan], "padding_efficiency": valid / computed if computed else None,
+                          "text_padding_efficiency": tvalid / tcomputed if tcomputed else None})
+
+
 def stream_sentences(session, sentences: Iterable[Sequence[int]], scales=(0.667, 1.0, 0.8), sid: Optional[int] = None,
-                     volume: Optional[float] = None, look_ahead: int = 8) -> Iterator[np.ndarray]:
+                     volume: Optional[float] = None, look_ahead: int = 8, plan: Optional[bool] = None,
+                     stats: Optional[dict] = None) -> Iterator[np.ndarray]:
     """Yield the int16 audio of each sentence (a sequence of phoneme ids, the boundary the reference crosses at
     ``voice.py:180``) in order, keeping up to ``look_ahead`` sentences in flight on ``session``.
+
+    ``plan``: a request that arrives as a list / tuple is planned (``stream_planned``: sentence 0 alone, then batches cut from
+    the whole list — ``look_ahead`` then bounds the first follow-up batch); a lazy iterable is consumed ``look_ahead`` sentences
+    ahead of the consumer, one call per sentence, and batching is left to the session's micro-batcher.  Same chunks either way.
 
     An exception of a sentence surfaces when its turn comes (like the reference, which raises at the failing sentence);
     sentences after it are cancelled or drained, never yielded."""
     if look_ahead < 1:
         raise ValueError("look_ahead must be >= 1")
+    if plan is None:
+        plan = isinstance(sentences, (list, tuple))
+    if plan:
+        lanes = len(getattr(session, "_engines", [None]))
+        yield from stream_planned(session, list(sentences), scales=scales, sid=sid, volume=volume, head=min(7, look_ahead),
+                                  workers=max(2, lanes + 1), stats=stats)
+        return
     it = iter(sentences)
     pool = ThreadPoolExecutor(max_workers=look_ahead, thread_name_prefix="mi355vits-stream")
     pending = []

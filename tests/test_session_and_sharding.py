@@ -2,6 +2,7 @@
 batch sharding across ranks.  On CPU these run on the test model of the kernels (tests/emu); the same checks
 run against the real library in test_gpu_parity.py / test_gpu_session.py."""
 import os
+import threading
 import sys
 
 import numpy as np
@@ -629,3 +630,93 @@ def test_bench_cli_fails_only_for_missing_devices():
     tail = (r.stderr or r.stdout).strip().splitlines()[-1]
     assert "devices requested" in tail or "no HIP device visible" in tail, tail
     assert "torch.distributed.run" not in tail and "--single-process" not in tail
+
+
+def test_planned_batches_of_a_known_request(emu_lib):
+    """SURVEY N2 (tts.py:470-515: end_utterance holds every pending sentence): stream_sentences on a LIST plans its batches —
+    sentence 0 alone, a head batch, the rest length-sorted inside its phoneme-length class — and yields exactly the chunks of
+    one call per sentence, in order; the plan covers every sentence once; padding efficiency is reported."""
+    from mimic3_amd import streaming as ST
+
+    lens = [5, 9, 3, 130, 12, 7, 8, 200, 6, 11, 4, 140, 10, 9, 9, 300, 2, 13, 5, 6, 7, 8, 9, 10, 11]
+    plan = ST.plan_batches(lens, head=4, max_batch=6)
+    assert plan[0] == [0] and sorted(i for b in plan for i in b) == list(range(len(lens)))
+    assert [1, 2, 4] in plan and [3] in plan  # the head window, split by phoneme-length class (130 > 128)
+    for b in plan:
+        assert len(b) <= 6 and len({ST._tx_class(lens[i]) for i in b}) == 1
+    tail = [b for b in plan[1:] if min(b) > 4 and ST._tx_class(lens[b[0]]) == 0]
+    assert len(tail) == 3 and all(5 <= len(b) <= 6 for b in tail)  # 17 short sentences in equal shares, not 6 + 6 + 5 by accident
+    spans = [max(lens[i] for i in b) - min(lens[i] for i in b) for b in tail]
+    assert max(spans) <= 5 and sum(spans) <= 10, spans  # length-sorted: rows of one batch are alike (unsorted windows of six span 7 - 11)
+    assert ST.plan_batches([], head=3) == [] and ST.plan_batches([7], head=3) == [[0]]
+
+    cfg = VitsConfig.tiny()
+    blob = W.pack(cfg, W.synthetic_weights(cfg, seed=3, frames_per_id=2.0))
+    so = SessionOptions()
+    so.lanes = 2
+    so.seed = 5
+    sess = InferenceSession(blob, sess_options=so, _library=emu_lib)
+    plain = InferenceSession(blob, _library=emu_lib)
+    rng = np.random.default_rng(2)
+    sentences = [rng.integers(1, cfg.num_symbols, int(rng.integers(3, 30))).tolist() for _ in range(19)]
+    det = (0.0, 1.0, 0.0)
+    expect = [plain.run_pcm16(ST._feed(s, det, None))[0][0] for s in sentences]
+    stats = {}
+    got = list(ST.stream_sentences(sess, sentences, scales=det, look_ahead=4, stats=stats))
+    assert len(got) == len(expect) and all(np.array_equal(a, b) for a, b in zip(got, expect))
+    assert sum(stats["batches"]) == 19 and stats["batches"][0] == 1 and 0.3 < stats["padding_efficiency"] <= 1.0
+    # the lazy path (a generator) gives the same chunks
+    lazy = list(ST.stream_sentences(sess, (s for s in sentences), scales=det, look_ahead=4))
+    assert all(np.array_equal(a, b) for a, b in zip(lazy, expect))
+    # a failing sentence inside a planned batch: its batch-mates are still delivered up to its turn
+    bad = [list(s) for s in sentences]
+    bad[9] = [cfg.num_symbols + 5]
+    out = []
+    with pytest.raises(ValueError, match="phoneme id"):
+        for a in ST.stream_sentences(sess, bad, scales=det, look_ahead=4):
+            out.append(a)
+    assert len(out) == 9 and all(np.array_equal(a, b) for a, b in zip(out, expect))
+    sess.close()
+    plain.close()
+
+
+def test_micro_batcher_collects_while_every_lane_is_busy(emu_lib):
+    """Round 6: a batch is not cut by the clock while the lanes are busy.  Closed-loop clients on one lane: the first request
+    runs alone at once (no window for a lone call on an idle session), everything that arrives meanwhile forms the next batch —
+    so the mean batch under load is far above what a 1 ms window alone collects; results are bitwise the plain session's."""
+    import time
+
+    cfg = VitsConfig.tiny()
+    blob = W.pack(cfg, W.synthetic_weights(cfg, seed=3, frames_per_id=2.0))
+    so = SessionOptions()
+    so.micro_batch_window_ms = 1.0
+    so.micro_batch_max = 16
+    sess = InferenceSession(blob, sess_options=so, _library=emu_lib)
+    plain = InferenceSession(blob, _library=emu_lib)
+    rng = np.random.default_rng(4)
+    feeds = [{"input": rng.integers(1, cfg.num_symbols, (1, 9)).astype(np.int64), "input_lengths": np.array([9], np.int64),
+              "scales": np.array([0.0, 1.0, 0.0], np.float32)} for _ in range(12)]
+    expect = [plain.run_pcm16(f)[0][0] for f in feeds]
+    t0 = time.perf_counter()
+    lone = sess.run_pcm16(feeds[0])[0][0]
+    t_lone = time.perf_counter() - t0
+    assert np.array_equal(lone, expect[0])
+    t0 = time.perf_counter()
+    plain.run_pcm16(feeds[0])
+    t_plain = time.perf_counter() - t0
+    assert t_lone < t_plain + 0.9e-3 + 0.5 * t_plain, (t_lone, t_plain)  # the 1 ms window was not waited for
+    results = [None] * 12
+    b0, r0 = sess._batcher.batches, sess._batcher.requests
+
+    def client(k):
+        for rep in range(3):
+            results[k] = sess.run_pcm16(feeds[k])[0][0]
+
+    ts = [threading.Thread(target=client, args=(k,)) for k in range(12)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(np.array_equal(results[k], expect[k]) for k in range(12))
+    nb, nr = sess._batcher.batches - b0, sess._batcher.requests - r0
+    assert nr == 36 and nr / nb >= 4.0, (nr, nb)  # (the CPU model takes ~10 ms per call: a 1 ms window alone would give ~1-2)
+    sess.close()
+    plain.close()

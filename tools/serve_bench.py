@@ -90,17 +90,18 @@ def main():
         sess = InferenceSession(blob, sess_options=so)
         sentences = [f["input"][0].tolist() for f in feeds[:120]]  # ~100 phoneme ids each: about 10k characters of text
         list(ST.stream_sentences(sess, sentences[:8], look_ahead=8))  # warm-up
-        for look in (1, 8, 32):
+        for look, planned in ((1, False), (8, False), (32, False), (32, True), (32, True)):
             t0 = time.perf_counter()
             first, n = None, 0
-            for audio in ST.stream_sentences(sess, sentences, look_ahead=look):
+            stats = {}
+            for audio in ST.stream_sentences(sess, sentences if planned else iter(sentences), look_ahead=look, stats=stats):
                 if first is None:
                     first = time.perf_counter() - t0
                 n += audio.shape[0]
             total = time.perf_counter() - t0
-            print(json.dumps({"mode": "stream", "sentences": len(sentences), "look_ahead": look, "first_audio_ms": first * 1e3,
+            print(json.dumps({"mode": "stream", "planned": planned, "sentences": len(sentences), "look_ahead": look, "first_audio_ms": first * 1e3,
                               "total_ms": total * 1e3, "audio_s": n / 22050, "x_realtime": n / 22050 / total,
-                              "devices": sess.devices}), flush=True)
+                              "devices": sess.devices, **stats}), flush=True)
         sess.close()
 
 
