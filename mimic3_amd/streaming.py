@@ -49,13 +49,14 @@ def _tx_class(n: int) -> int:
     return 0 if n <= 128 else (1 if n <= 256 else (2 if n <= 512 else 3))
 
 
-def plan_batches(lengths: Sequence[int], head: int = 7, max_batch: int = 48) -> list:
+def plan_batches(lengths: Sequence[int], head: int = 0, max_batch: int = 48) -> list:
     """Batches for a request whose sentences are all known (``end_utterance`` holds every pending ``Mimic3Phonemes`` when it
-    starts, ``mimic3_tts/tts.py:470-515``): sentence 0 ALONE (its audio is what the listener waits for), then the next ``head``
-    sentences as one batch (playback continues from them), then everything else sorted by length inside its phoneme-length
-    class and cut into batches of at most ``max_batch`` — rows of one batch have similar lengths, so little of a batched call
-    is padding (the decoder computes every row up to the batch's longest).  Returns lists of sentence indices, in the order the
-    batches should be issued (by the earliest sentence they hold)."""
+    starts, ``mimic3_tts/tts.py:470-515``): sentence 0 ALONE (its audio is what the listener waits for), then — optionally — the
+    next ``head`` sentences as one batch (for playback that must continue before the rest is done; at 16,000 x real time the rest
+    of a 10k-character request is done 15 ms later, so the default is 0), then everything else sorted by length inside its
+    phoneme-length class and cut into batches of at most ``max_batch`` — rows of one batch have similar lengths, so little of a
+    batched call is padding (the decoder computes every row up to the batch's longest).  Returns lists of sentence indices, in
+    the order the batches should be issued (by the earliest sentence they hold)."""
     n = len(lengths)
     if n == 0:
         return []
@@ -93,14 +94,16 @@ def _batch_feed(rows: Sequence[Sequence[int]], scales, sid: Optional[int]) -> Di
 
 
 def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1.0, 0.8), sid: Optional[int] = None,
-                   volume: Optional[float] = None, head: int = 7, max_batch: int = 48, workers: int = 4,
-                   stats: Optional[dict] = None) -> Iterator[np.ndarray]:
+                   volume: Optional[float] = None, head: int = 0, max_batch: int = 48, workers: int = 4,
+                   stats: Optional[dict] = None, first_alone: bool = True) -> Iterator[np.ndarray]:
     """``stream_sentences`` for a request whose sentence list is known up front ("look-ahead batching of all
     Mimic3Phonemes pending in one end_utterance"): the batches of ``plan_batches`` are issued as BATCHED engine calls on the
     session's lanes (no arrival window, no per-sentence thread), the chunks are yielded in sentence order as their batches
     finish.  A batched row is bitwise its single call (same phoneme-length class), so the stream's bytes do not depend on the
-    plan.  ``stats`` (optional dict) receives ``batches``, ``padding_efficiency`` = valid / computed output samples (a batch
-    computes every row up to its longest) and ``text_padding_efficiency`` (the same for phoneme positions).
+    plan.  ``first_alone``: sentence 0 has the device to itself — the other batches are issued when its audio is in the caller's
+    hands (issued together, a 40-row batch's kernels fill the chip and the single sentence takes 6 ms instead of 2:
+    profiles/r06_serve_bench.log).  ``stats`` (optional dict) receives ``batches``, ``padding_efficiency`` = valid / computed
+    output samples (a batch computes every row up to its longest) and ``text_padding_efficiency`` (the same for phoneme positions).
 
     A failing sentence: its batch is retried row by row, the error surfaces at that sentence's turn, later ones are not
     delivered."""
@@ -115,7 +118,7 @@ def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1
     def run_batch(idx):
         try:
             rows, lengths = session.run_pcm16(_batch_feed([sentences[i] for i in idx], scales, sid), volume=volume)
-            return [np.array(r, copy=True) for r in rows], np.asarray(lengths)
+            return list(rows), np.asarray(lengths)  # (views of the call's own pinned result buffer, which they keep alive)
         except Exception:
             if len(idx) == 1:
                 raise
@@ -127,11 +130,18 @@ def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1
                     out.append(e)
             return out, None
 
-    futs = [(idx, pool.submit(run_batch, idx)) for idx in plan]
+    futs = [(plan[0], pool.submit(run_batch, plan[0]))]
+    if not first_alone:
+        futs += [(idx, pool.submit(run_batch, idx)) for idx in plan[1:]]
     try:
         nxt = 0
-        for idx, fut in futs:
+        k = 0
+        while k < len(futs):
+            idx, fut = futs[k]
+            k += 1
             rows, lengths = fut.result()
+            if first_alone and k == 1:
+                futs += [(i2, pool.submit(run_batch, i2)) for i2 in plan[1:]]  # the rest starts as sentence 0 is handed over
             if lengths is not None:
                 valid += int(np.sum(lengths))
                 computed += int(np.max(lengths)) * len(idx)
@@ -160,8 +170,8 @@ def stream_sentences(session, sentences: Iterable[Sequence[int]], scales=(0.667,
     """Yield the int16 audio of each sentence (a sequence of phoneme ids, the boundary the reference crosses at
     ``voice.py:180``) in order, keeping up to ``look_ahead`` sentences in flight on ``session``.
 
-    ``plan``: a request that arrives as a list / tuple is planned (``stream_planned``: sentence 0 alone, then batches cut from
-    the whole list — ``look_ahead`` then bounds the first follow-up batch); a lazy iterable is consumed ``look_ahead`` sentences
+    ``plan``: a request that arrives as a list / tuple is planned (``stream_planned``: sentence 0 alone, then length-sorted
+    batches cut from the whole list); a lazy iterable is consumed ``look_ahead`` sentences
     ahead of the consumer, one call per sentence, and batching is left to the session's micro-batcher.  Same chunks either way.
 
     An exception of a sentence surfaces when its turn comes (like the reference, which raises at the failing sentence);
@@ -172,8 +182,7 @@ def stream_sentences(session, sentences: Iterable[Sequence[int]], scales=(0.667,
         plan = isinstance(sentences, (list, tuple))
     if plan:
         lanes = len(getattr(session, "_engines", [None]))
-        yield from stream_planned(session, list(sentences), scales=scales, sid=sid, volume=volume, head=min(7, look_ahead),
-                                  workers=max(2, lanes + 1), stats=stats)
+        yield from stream_planned(session, list(sentences), scales=scales, sid=sid, volume=volume, workers=max(2, lanes + 1), stats=stats)
         return
     it = iter(sentences)
     pool = ThreadPoolExecutor(max_workers=look_ahead, thread_name_prefix="mi355vits-stream")

@@ -642,6 +642,7 @@ def test_planned_batches_of_a_known_request(emu_lib):
     plan = ST.plan_batches(lens, head=4, max_batch=6)
     assert plan[0] == [0] and sorted(i for b in plan for i in b) == list(range(len(lens)))
     assert [1, 2, 4] in plan and [3] in plan  # the head window, split by phoneme-length class (130 > 128)
+    assert [1, 2, 4] not in ST.plan_batches(lens, max_batch=6)  # default: no head window, sentence 0 alone and then the sorted groups
     for b in plan:
         assert len(b) <= 6 and len({ST._tx_class(lens[i]) for i in b}) == 1
     tail = [b for b in plan[1:] if min(b) > 4 and ST._tx_class(lens[b[0]]) == 0]
