@@ -504,10 +504,16 @@ def main():
     hist = []
     box_probe = None
     if rank == 0:
-        try:  # ~10 ms: what this lease's chip gives the kernels' access patterns (include/mi355vits.h mi355vits_probe_device)
-            from mimic3_amd._native import default_library
-            box_probe = default_library().probe_device(local_rank)
-            box_probe.update(eng.probe_weights())
+        try:  # ~10 ms: what this lease's chip gives the kernels' access patterns (include/mi355vits_lab.h mi355vits_probe_device;
+            # the hooks live in libmi355vits_hooks.so = the product's objects + csrc/lab_api.cpp, never in the timed path)
+            from mimic3_amd._native import Engine as _Engine, hooks_library
+            hl = hooks_library()
+            box_probe = hl.probe_device(local_rank)
+            pe = _Engine(W.pack(cfg, weights), device=local_rank, library=hl)  # a replica of the same weights: its arena is probed
+            try:
+                box_probe.update(pe.probe_weights())
+            finally:
+                pe.close()
         except Exception as ex:  # noqa: BLE001 - diagnostics only
             box_probe = {"error": str(ex)[:100]}
     t_ph = time.perf_counter()

@@ -23,14 +23,20 @@ DEBUG_TAPS = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libmi355vits.so")
+# the product's own objects + the hooks of include/mi355vits_lab.h (kernel unit tests, box probes): test infrastructure and bench.py's
+# box probe; the product path (session.py, Engine) never opens it
+HOOKS_LIBRARY = os.path.join(_HERE, "csrc", "libmi355vits_hooks.so")
 
-# every symbol include/mi355vits.h declares
+# every symbol include/mi355vits.h declares (the product ABI)
 EXPORTED_SYMBOLS = (
     "mi355vits_version", "mi355vits_device_count", "mi355vits_create", "mi355vits_create_from_buffer", "mi355vits_clone", "mi355vits_destroy",
     "mi355vits_device_result", "mi355vits_set_math", "mi355vits_get_math",
     "mi355vits_get_config", "mi355vits_run", "mi355vits_fetch", "mi355vits_free_result",
     "mi355vits_last_error", "mi355vits_profile_enable", "mi355vits_profile_reset",
     "mi355vits_profile_report", "mi355vits_last_run_ms", "mi355vits_get_tap", "mi355vits_get_tap_rows", "mi355vits_list_taps",
+)
+# every symbol include/mi355vits_lab.h declares: exported by libmi355vits_hooks.so, the lab build and the CPU model — NOT by the product
+LAB_SYMBOLS = (
     "mi355vits_test_conv1d", "mi355vits_test_conv_transpose1d", "mi355vits_test_mfma_layout", "mi355vits_bench_conv1d", "mi355vits_probe_device", "mi355vits_probe_weights",
 )
 
@@ -137,15 +143,26 @@ class NativeLibrary:
         L.mi355vits_get_tap_rows.restype = ctypes.c_long
         L.mi355vits_list_taps.argtypes = [H, ctypes.c_char_p, ctypes.c_size_t]
         L.mi355vits_list_taps.restype = ctypes.c_long
-        L.mi355vits_test_conv1d.argtypes = [ctypes.c_int, ctypes.POINTER(ConvTest)]
-        L.mi355vits_test_conv_transpose1d.argtypes = [
-            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-            ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
-            ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
-        L.mi355vits_test_mfma_layout.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
-        L.mi355vits_bench_conv1d.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_float)]
-        L.mi355vits_probe_device.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-        L.mi355vits_probe_weights.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        # the hooks of include/mi355vits_lab.h: all of them or none (the product library has none)
+        present = [hasattr(L, sym) for sym in LAB_SYMBOLS]
+        if any(present) and not all(present):
+            raise RuntimeError(f"{self.path} exports only part of include/mi355vits_lab.h")
+        self.has_hooks = all(present)
+        if self.has_hooks:
+            L.mi355vits_test_conv1d.argtypes = [ctypes.c_int, ctypes.POINTER(ConvTest)]
+            L.mi355vits_test_conv_transpose1d.argtypes = [
+                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                ctypes.POINTER(ctypes.c_float), ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
+            L.mi355vits_test_mfma_layout.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+            L.mi355vits_bench_conv1d.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_float)]
+            L.mi355vits_probe_device.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+            L.mi355vits_probe_weights.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+
+    def _need_hooks(self):
+        if not self.has_hooks:
+            raise RuntimeError(f"{self.path} is the product library: the hooks of include/mi355vits_lab.h live in "
+                               "libmi355vits_hooks.so (mimic3_amd._native.hooks_library()), the lab build and the CPU model")
 
     def version(self) -> str:
         return self.lib.mi355vits_version().decode()
@@ -159,6 +176,7 @@ class NativeLibrary:
     # ---- kernel unit-test hooks -------------------------------------------------------------
     def test_conv1d(self, x, w, bias=None, res=None, dilation=1, impl=1, in_len=None, out_len=None, in_slope=1.0,
                     relu=False, out_scale=1.0, res_sub=False, accumulate_into=None, device=0) -> np.ndarray:
+        self._need_hooks()
         x = np.ascontiguousarray(x, np.float32)
         w = np.ascontiguousarray(w, np.float32)
         B, Cin, T = x.shape
@@ -186,6 +204,7 @@ class NativeLibrary:
         return y
 
     def test_conv_transpose1d(self, x, w, bias, stride, in_slope=1.0, device=0, impl=0) -> np.ndarray:
+        self._need_hooks()
         x = np.ascontiguousarray(x, np.float32)
         w = np.ascontiguousarray(w, np.float32)
         B, Cin, Tin = x.shape
@@ -199,6 +218,7 @@ class NativeLibrary:
         return y
 
     def bench_conv1d(self, B, Cin, Cout, T, K, dilation=1, epi=0, reps=20, device=0) -> float:
+        self._need_hooks()
         ms = ctypes.c_float(-1.0)
         rc = self.lib.mi355vits_bench_conv1d(device, B, Cin, Cout, T, K, dilation, epi, reps, ctypes.byref(ms))
         if rc != 0:
@@ -206,7 +226,8 @@ class NativeLibrary:
         return float(ms.value)
 
     def probe_device(self, device=0) -> dict:
-        """The box probe: what this lease's chip gives the kernels' access patterns (include/mi355vits.h)."""
+        """The box probe: what this lease's chip gives the kernels' access patterns (include/mi355vits_lab.h)."""
+        self._need_hooks()
         out = (ctypes.c_double * 8)()
         rc = self.lib.mi355vits_probe_device(device, out)
         if rc != 0:
@@ -216,6 +237,7 @@ class NativeLibrary:
                 "latency_32MB_ns": round(out[6], 1), "latency_1GiB_ns": round(out[7], 1)}
 
     def test_mfma_layout(self, device=0) -> float:
+        self._need_hooks()
         err = ctypes.c_float(-1.0)
         rc = self.lib.mi355vits_test_mfma_layout(device, ctypes.byref(err))
         if rc != 0:
@@ -234,6 +256,21 @@ def default_library() -> NativeLibrary:
         if _default is None:
             _default = NativeLibrary(DEFAULT_LIBRARY)
         return _default
+
+
+_hooks: Optional[NativeLibrary] = None
+
+
+def hooks_library() -> NativeLibrary:
+    """libmi355vits_hooks.so: the product's own object files + the hooks of include/mi355vits_lab.h (kernel unit tests, conv
+    micro-benchmark, box probes).  Test infrastructure and bench.py's box probe; nothing on the product path opens it."""
+    global _hooks
+    with _default_lock:
+        if _hooks is None:
+            _hooks = NativeLibrary(HOOKS_LIBRARY)
+            if not _hooks.has_hooks:
+                raise RuntimeError(f"{HOOKS_LIBRARY} does not export include/mi355vits_lab.h")
+        return _hooks
 
 
 class _ResultHolder:
@@ -420,8 +457,9 @@ class Engine:
         return float(self.native.lib.mi355vits_last_run_ms(self._h))
 
     def probe_weights(self) -> dict:
-        """L2 stream over this replica's own weight arena (include/mi355vits.h mi355vits_probe_weights): GB/s min / median / max
-        over 2.6 MB windows, eight loads in flight per lane and one."""
+        """L2 stream over this replica's own weight arena (include/mi355vits_lab.h mi355vits_probe_weights; the handle must come
+        from a library that carries the hooks): GB/s min / median / max over 2.6 MB windows, eight loads in flight per lane and one."""
+        self.native._need_hooks()
         out = (ctypes.c_double * 8)()
         self._check(self.native.lib.mi355vits_probe_weights(self._h, out))
         return {"arena_stream8_GBps": [round(out[0]), round(out[1]), round(out[2])], "arena_stream1_GBps": [round(out[3]), round(out[4]), round(out[5])],

@@ -1,6 +1,7 @@
 """Build the native library.
 
-``build_hip()``  -> ``mimic3_amd/csrc/libmi355vits.so``  (hipcc, --offload-arch=gfx950; the product)
+``build_hip()``  -> ``mimic3_amd/csrc/libmi355vits.so``  (hipcc, --offload-arch=gfx950; the product: include/mi355vits.h only)
+                    + ``libmi355vits_hooks.so`` (the same objects + csrc/lab_api.cpp: include/mi355vits_lab.h, tests and bench probe)
 ``build_emu()``  -> ``tests/emu/libmi355vits_emu.so``    (g++, -DMI355_EMU; CPU model of the same
                     sources for the ``-m "not gpu"`` tests — never loaded by the product path)
 
@@ -18,6 +19,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
 SOURCES = ["kernels_conv.cpp", "kernels_mrf.cpp", "kernels_mrfp.cpp", "kernels_mrfs.cpp", "kernels_rbc.cpp", "kernels_attn.cpp", "kernels_wn.cpp", "kernels_misc.cpp", "engine.cpp", "c_api.cpp"]
+# csrc/lab_api.cpp = the hooks of include/mi355vits_lab.h (kernel unit tests, conv micro-benchmark, box probes): NOT in the product
+# library; linked with the product's own objects into libmi355vits_hooks.so, and compiled into the lab build and the CPU model
+HOOK_SOURCES = ["lab_api.cpp"]
 PER_FILE_FLAGS = {}
 LAB_FILE_FLAGS = {}  # per-file flags of the lab build's side of a running A/B (none at the moment)
 # throw-away instrumented twins of the lab build (MI355_LAB_VARIANT=<name> python -m mimic3_amd.build lab -> libmi355vits_lab_<name>.so)
@@ -30,6 +34,7 @@ LAB_AS_PRODUCT = {"kernels_mrfp.cpp"}
 # inside kernels_rbc.cpp)
 LAB_ONLY = set()
 HIP_LIB = os.path.join(CSRC, "libmi355vits.so")
+HOOKS_LIB = os.path.join(CSRC, "libmi355vits_hooks.so")
 EMU_LIB = os.path.join(EMU, "libmi355vits_emu.so")
 
 
@@ -43,6 +48,7 @@ def _stale(target: str, deps) -> bool:
 def _deps(extra=()):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".h"))]
     deps.append(os.path.join(ROOT, "include", "mi355vits.h"))
+    deps.append(os.path.join(ROOT, "include", "mi355vits_lab.h"))
     deps.extend(extra)
     return deps
 
@@ -74,7 +80,7 @@ def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = 
     if verbose_resources:
         base.append("-Rpass-analysis=kernel-resource-usage")
     jobs = []
-    srcs = [s for s in SOURCES if lab or s not in LAB_ONLY]
+    srcs = [s for s in SOURCES if lab or s not in LAB_ONLY] + HOOK_SOURCES
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".cpp", ".o"))
         if force or verbose_resources or _stale(obj, [src] + hdrs):
@@ -85,9 +91,12 @@ def build_hip(force: bool = False, verbose_resources: bool = False, lab: bool = 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(_run, jobs))
     objs = [os.path.join(objdir, s.replace(".cpp", ".o")) for s in srcs]
-    if jobs or _stale(target, objs):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"])
-        os.replace(target + ".tmp", target)
+    # the product library: everything but the hooks; the same objects + the hooks = libmi355vits_hooks.so (test infrastructure)
+    links = [(target, objs)] if lab else [(target, [o for o, s in zip(objs, srcs) if s not in HOOK_SOURCES]), (HOOKS_LIB, objs)]
+    for tgt, ob in links:
+        if jobs or _stale(tgt, ob):
+            _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + ob + ["-o", tgt + ".tmp"])
+            os.replace(tgt + ".tmp", tgt)
     return target
 
 
@@ -99,7 +108,7 @@ def build_emu(force: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
     base = [cxx, "-O2", "-std=c++17", "-fPIC", "-DMI355_EMU", "-Wno-psabi", "-Wno-unused-result", "-I", EMU, "-I", os.path.join(ROOT, "include")]
-    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(EMU, "hip_emu_impl.cpp")]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES + HOOK_SOURCES] + [os.path.join(EMU, "hip_emu_impl.cpp")]
     objs = [os.path.join(objdir, os.path.basename(s).replace(".cpp", ".o")) for s in srcs]
     jobs = [base + ["-c", s, "-o", o] for s, o in zip(srcs, objs) if force or _stale(o, [s] + hdrs)]
     if jobs:

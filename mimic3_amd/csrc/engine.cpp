@@ -128,6 +128,9 @@ void DeviceArena::reserve(size_t bytes, hipStream_t s) {
     if (hipMalloc(&p, want) != hipSuccess) throw EngineError(MI355VITS_ERR_NOMEM, "out of device memory (workspace)");
     base_ = static_cast<unsigned char*>(p);
     cap_ = want;
+    // zero-filled once per (re)allocation: the decoder / flow kernels never compute items past a row's length in a ragged batch
+    // (kernels_mrfp.cpp next_item), so those columns keep what the arena held before — which must be finite, not fresh-memory NaNs
+    HIP_CHECK(hipMemsetAsync(base_, 0, want, s));
 }
 void* DeviceArena::alloc_bytes(size_t bytes) {
     const size_t need = padded(bytes);
@@ -601,11 +604,20 @@ void Engine::probe_weights(double out[8]) {
     const size_t win = (size_t)n16 * 16;
     const int nwin = (int)std::min<size_t>(model_->bytes / win, 24);
     if (nwin < 1) throw EngineError(MI355VITS_ERR_INVALID, "weight arena smaller than one probe window");
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
-    unsigned* sink = nullptr;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sink), (size_t)cus * 4 + 16));
+    // (diagnostics of include/mi355vits_lab.h: hipMalloc / hipFree synchronise the device — not for a handle that is serving.)
+    // RAII: a HIP error in between must not leak the events or the sink
+    struct Ev {
+        hipEvent_t e = nullptr;
+        Ev() { HIP_CHECK(hipEventCreate(&e)); }
+        ~Ev() { if (e) (void)hipEventDestroy(e); }
+    } ev0, ev1;
+    struct Sink {
+        unsigned* p = nullptr;
+        explicit Sink(size_t n) { HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), n)); }
+        ~Sink() { (void)hipFree(p); }
+    } sk((size_t)cus * 4 + 16);
+    hipEvent_t e0 = ev0.e, e1 = ev1.e;
+    unsigned* sink = sk.p;
     std::vector<double> g8, g1;
     for (int wdx = 0; wdx < nwin; ++wdx) {
         const char* base = reinterpret_cast<const char*>(model_->dev_weights) + (size_t)wdx * win;
@@ -626,9 +638,6 @@ void Engine::probe_weights(double out[8]) {
             (mode == 0 ? g8 : g1).push_back(gbs);
         }
     }
-    (void)hipFree(sink);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     std::sort(g8.begin(), g8.end());
     std::sort(g1.begin(), g1.end());
     out[0] = g8.front(); out[1] = g8[g8.size() / 2]; out[2] = g8.back();
@@ -727,7 +736,7 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     }
 }
 
-void Engine::tap(const char* name, const float* dev, std::initializer_list<int64_t> dims) {
+void Engine::tap(const char* name, const float* dev, std::initializer_list<int64_t> dims, const int* row_len, int factor) {
     if (!taps_on_) return;
     size_t cnt = 1;
     for (auto d : dims) cnt *= (size_t)d;
@@ -741,6 +750,7 @@ void Engine::tap(const char* name, const float* dev, std::initializer_list<int64
     HIP_CHECK(hipMalloc(&p, cnt * sizeof(float) + 16));
     t.dev = static_cast<float*>(p);
     HIP_CHECK(hipMemcpyAsync(t.dev, dev, cnt * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+    if (row_len && t.dims.size() == 3) launch_zero_row_tails(t.dev, (int)t.dims[0], (int)t.dims[1], (long)t.dims[2], row_len, factor, stream_);
     taps_.push_back(std::move(t));
 }
 
@@ -1064,7 +1074,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         launch_expand_prior(d_stats_, d_cum_, d_ylen_, d_noise_z_, args.noise_z_frames, B, I, Tx, Ty, args.scales[0],
                             args.seed, args.utterance_base, d_z_, stream_);
     }
-    tap("z_p", d_z_, {B, I, Ty});
+    tap("z_p", d_z_, {B, I, Ty}, d_ylen_, 1);
 
     for (int j = c.flow_n_flows - 1; j >= 0; --j) {
         const int e = c.flow_n_flows - 1 - j;
@@ -1159,7 +1169,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         post.B = B; post.T = Ty;
         conv("flow.post_couple", cw(S("flow.%d.post", j)), post);
     }
-    tap("z", d_z_, {B, I, Ty});
+    tap("z", d_z_, {B, I, Ty}, d_ylen_, 1);
 
     // ---- decoder
     const int C0 = c.upsample_initial_channel;
@@ -1170,7 +1180,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
     cp.cond = d_cond_dec_; cp.cond_bs = C0;
     cp.B = B; cp.T = Ty;
     conv("dec.conv_pre", cw("dec.conv_pre"), cp);
-    tap("dec.conv_pre", d_bufC_, {B, C0, Ty});
+    tap("dec.conv_pre", d_bufC_, {B, C0, Ty}, d_ylen_, 1);
 
     int ch = C0;
     long T = Ty;
@@ -1205,7 +1215,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
         T *= r;
         const long sbs = (long)ch * T;
         const int* slen = d_slen_ + (long)(i + 1) * B;  // rows end at their own length (batched == unbatched)
-        tap(S("dec.ups.%d", i).c_str(), d_bufA_, {B, ch, T});
+        tap(S("dec.ups.%d", i).c_str(), d_bufA_, {B, ch, T}, d_ylen_, (int)(T / Ty));
         int n_fused = 0;  // resblocks 0 .. n_fused-1 of this stage run in the fused kernel, the rest conv by conv
         if (!force_generic_ && !no_fused_mrf_ && c.resblock == 2 && nk <= MRF_MAX_RB) {
             MrfArgs m;
@@ -1342,7 +1352,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                 }
             }
         }
-        tap(S("dec.mrf.%d", i).c_str(), d_bufC_, {B, ch, T});
+        tap(S("dec.mrf.%d", i).c_str(), d_bufC_, {B, ch, T}, d_ylen_, (int)(T / Ty));
     }
     {
         ProfScope ps(prof_, "dec.conv_post_tanh", 2.0 * B * (double)T * ch * 7, 4.0 * B * (double)T * (ch + 1));

@@ -160,7 +160,8 @@ class Engine {
     void conv(const char* label, const ConvW& w, ConvArgs a);
     bool rbc_ok(const ConvW& w, const ConvArgs& a) const;    // this conv runs on k_rb_conv (128-channel resblock conv, MATH_BF16X3)
     bool enc_gemm(const ConvW& w, const ConvArgs& a) const;  // this conv runs on k_enc_b3 (phoneme-sized, split-bf16)
-    void tap(const char* name, const float* dev, std::initializer_list<int64_t> dims);
+    // row_len / factor: frame-resolution taps of a ragged batch are zeroed past len[b] * factor (those columns are not computed)
+    void tap(const char* name, const float* dev, std::initializer_list<int64_t> dims, const int* row_len = nullptr, int factor = 1);
     void text_encoder(int B, int Tx);
     void duration_predictor(int B, int Tx, const mi355vits_run_args& args);
     void dds(const std::string& key, float* X, float* Y1, float* Y2, int B, int T);

@@ -133,6 +133,7 @@ struct MrfArgs {
     int ablate = 0;  // profiling only (MI355VITS_MRF_ABLATE): 1 = skip MFMA loops, 2 = skip staging, 4 = skip output
     int seg = 0;     // launch_mrf_s: columns per work item (a multiple of the kernel's step), from mrf_s_segment
     unsigned* clk = nullptr;  // -DMRFP_CLOCKS lab builds only: shader-clock stamps (kernels_mrfp.cpp)
+    int prio = 0;    // k_mrf_s: wave-priority mode of the conv2 waves (0 none, 1-3 a fixed s_setprio, 4-6 dynamic: see the kernel)
 };
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 void launch_mrf_fused(MrfArgs a, hipStream_t s);
@@ -299,6 +300,7 @@ void launch_speaker_cond(const float* emb_g, const long long* sid, const float* 
 
 // misc
 void launch_fill(float* p, float v, size_t n, hipStream_t s);
+void launch_zero_row_tails(float* p, int B, int C, long T, const int* len, int factor, hipStream_t s);  // p[b, :, len[b] * factor:] = 0
 void launch_mfma_selftest(float* out /*[32*32 + 16*16 + 16*16]*/, hipStream_t s);
 // box probe (mi355vits_probe_device): L2-hit 16-byte stream of one table by every CU, L2-hit dependent-load chain, HBM copy
 void launch_probe_l2_stream(const void* tbl, int n16, int reps, unsigned* sink, int grid, hipStream_t s);

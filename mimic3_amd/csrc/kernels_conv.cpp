@@ -1991,7 +1991,10 @@ __device__ __forceinline__ void conv_post_span(const BufRsrc xb, unsigned xrow, 
     MI355_UNROLL
     for (int i = 0; i < NT; ++i) {
         const int t = ws + CPD_TW * i - 4 + 4 * lane;  // this lane's four samples of tile i
-        vo[i] = 4u * (unsigned)t;                       // (t < 0: past the buffer's 2 GiB range = zeros)
+        // (t < 0: past the buffer's 2 GiB range = zeros; MASKED: a lane whose four samples all lie past the row's valid length is
+        // switched off the same way — its values are masked below anyway, and its 16-byte load would otherwise reach up to ~2 KB
+        // past the row, i.e. past the tensor for the last channel of the last row: ADVICE r5)
+        vo[i] = (MASKED && t >= vl) ? BUF_OOB : 4u * (unsigned)t;
         MI355_UNROLL
         for (int e = 0; e < 4; ++e) mo[i][e] = t + e < vl;
     }
@@ -2194,6 +2197,23 @@ void launch_mfma_selftest(float* out, hipStream_t s) { LAUNCH_KERNEL(k_mfma_self
 __global__ __launch_bounds__(256) void k_fill(float* p, float v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
+// debug taps: zero p[b, c, t] for t >= len[b] * factor (rows of a ragged batch are not computed past their length: the taps the
+// tests compare must not carry whatever the workspace held there)
+__global__ __launch_bounds__(256) void k_zero_row_tails(float* p, int C, long T, const int* len, int factor) {
+    const int b = blockIdx.y;
+    const long t0 = (long)len[b] * factor;
+    if (t0 >= T) return;
+    const long w = T - t0, n = (long)C * w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long c = i / w, t = t0 + (i - c * w);
+        p[((long)b * C + c) * T + t] = 0.0f;
+    }
+}
+void launch_zero_row_tails(float* p, int B, int C, long T, const int* len, int factor, hipStream_t s) {
+    if (B <= 0 || C <= 0 || T <= 0) return;
+    LAUNCH_KERNEL(k_zero_row_tails, dim3(64, (unsigned)B), dim3(256), 0, s, p, C, T, len, factor);
+}
+
 void launch_fill(float* p, float v, size_t n, hipStream_t s) {
     if (!n) return;
     size_t g = (n + 255) / 256;

@@ -157,7 +157,22 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
     const int nblk = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int per_xcd = (nitems + 7) >> 3, nslot = (nblk + 7 - xcd) >> 3;  // blocks on this XCD (nblk need not be a multiple of 8)
     const int item_end = (xcd + 1) * per_xcd < nitems ? (xcd + 1) * per_xcd : nitems;
-    int item = xcd * per_xcd + slot;
+    // Ragged batches (round 6): an item that starts at or past its row's length is never computed — its output columns are past
+    // the row's end, every consumer masks its input at the row's length, the workspace is zero-filled when it is allocated —, so a
+    // batch costs the sum of its rows' lengths in this stage, not rows x the longest.  next_item: the first item >= `it` on this
+    // workgroup's stride that has work (a row's remaining column blocks are jumped over in one step).
+    auto next_item = [&](int it) MI355_INLINE_LAMBDA {
+        while (it < item_end) {
+            const int bb = it / ntile;
+            int ln = a.len ? a.len[bb] : a.T;
+            if (ln > a.T) ln = a.T;
+            if ((it - bb * ntile) * T_B < ln) break;
+            const int row_end = (bb + 1) * ntile;                 // first item of the next row
+            it += (row_end - it + nslot - 1) / nslot * nslot;
+        }
+        return WAVE_UNIFORM(it);
+    };
+    int item = next_item(xcd * per_xcd + slot);
 
     uint4 W[MRFP_KMAX][3];
     // fragments of (resblock j, conv c, k-group g) for this wave's row tile (wave-uniform; the lane is a 32-bit index on top)
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
             stage_item(b0, t00, len0);
         }
     }
-    for (; item < item_end; item += nslot) {
+    for (int item_next = item; item < item_end; item = item_next) {
         // lane / wave coordinates, re-derived per item from values the optimiser cannot see through: everything computed
         // from them stays inside the loop body (hoisted out, the invariant addresses of ~50 unrolled tiles spill)
         int lane_o = lane, wid_o = wid;
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         len = WAVE_UNIFORM(len);
         const int last = len > 0 ? len - 1 : 0;
         const float* xb = a.x + (long)b * a.x_bs;
-        const int item_next = item + nslot;
+        item_next = next_item(item + nslot);
         const bool more = item_next < item_end;  // wave-uniform
 
         stamp(0);

@@ -101,9 +101,9 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
     // 4 - 7 (conv2) and then sat at the barrier while the partner finished alone (phase clocks, profiles/r04_mrf_sweep.txt; with the
     // roles swapped the slow side swapped too).  A higher user priority for the younger waves evens the two out.
     if (role == 1) {
-        if (a.vec == 1) __builtin_amdgcn_s_setprio(1);
-        else if (a.vec == 2) __builtin_amdgcn_s_setprio(2);
-        else if (a.vec == 3) __builtin_amdgcn_s_setprio(3);
+        if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     }
 #endif
 
@@ -117,7 +117,11 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
         if (len > a.T) len = a.T;
         len = WAVE_UNIFORM(len);
         const int last = len > 0 ? len - 1 : 0;
-        const int c1 = c0 + a.seg < a.T ? c0 + a.seg : a.T;
+        // ragged batches (round 6): a segment past the row's length is skipped, one that straddles it ends at the length — columns
+        // past a row's end are never read unmasked by any consumer (kernels_mrfp.cpp next_item)
+        if (c0 >= len) continue;
+        const int cend = c0 + a.seg < a.T ? c0 + a.seg : a.T;
+        const int c1 = cend < len ? cend : len;
         const int N = WAVE_UNIFORM((c1 - c0 + TS - 1) / TS);  // output blocks of this segment
         const float* xb = a.x + (long)b * a.x_bs;
         float* yb = a.y + (long)b * a.y_bs;
@@ -348,13 +352,13 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                         MI355_UNROLL  // straight-line iteration bodies: the wait-count pass then counts the younger loads / stores exactly
                         for (int i = 0; i < NT; ++i) {
 #if !defined(MI355_EMU)
-                            // a.vec == 4 (lab experiment, MI355VITS_MRF_PRIO=4): the younger wave of the SIMD pair leads for the first
+                            // a.prio == 4 (the product default, MRFS_CONV2_PRIO; MI355VITS_MRF_PRIO overrides it in the lab build): the younger wave of the SIMD pair leads for the first
                             // two of an iteration's three tiles, the older one for the last — instead of the older one leading throughout
                             // and idling at the barrier.  (Test and branch inside one asm statement: kernels_rbc.cpp RBC_SETPRIO_YOUNG.)
-                            // (a.vec: 4 = prio 1 for tiles 0, 1; 5 = for tile 0 only; 6 = for the whole iteration's tiles, 0 for its staging store)
-                            if (i == 0) asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(a.vec) : "scc");
-                            if (i == 1) asm volatile("s_cmp_lg_u32 %0, 5\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.vec) : "scc");
-                            if (i == NT - 1) asm volatile("s_cmp_lg_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.vec) : "scc");
+                            // (a.prio: 4 = prio 1 for tiles 0, 1; 5 = for tile 0 only; 6 = for the whole iteration's tiles, 0 for its staging store)
+                            if (i == 0) asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio 1\n1:" ::"s"(a.prio) : "scc");
+                            if (i == 1) asm volatile("s_cmp_lg_u32 %0, 5\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.prio) : "scc");
+                            if (i == NT - 1) asm volatile("s_cmp_lg_u32 %0, 4\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.prio) : "scc");
 #endif
                             const int t0 = c0 + m * TS + chh * (16 * NT) + 16 * i;
                             const unsigned off = (unsigned)(chh * (16 * NT) + 16 * i);
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512) void k_mrf_s(MrfArgs a) {
                         x1r = mrfs_wrap(x1r + TS, (unsigned)X1R);
                         rwr = mrfs_wrap(rwr + TS, (unsigned)RR);
 #if !defined(MI355_EMU)
-                        asm volatile("s_cmp_lg_u32 %0, 6\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.vec) : "scc");
+                        asm volatile("s_cmp_lg_u32 %0, 6\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n1:" ::"s"(a.prio) : "scc");
 #endif
                     }
                     MRFS_CLK(ck_1);
@@ -486,8 +490,8 @@ void launch_mrf_s(MrfArgs a, hipStream_t s) {
     a.ldx = g.XR;
     a.ld1 = g.X1R;
     a.R = g.RR;
-    a.vec = MRFS_CONV2_PRIO;  // s_setprio of the conv2 waves (see the kernel)
-    if (const char* pr = lab_getenv("MI355VITS_MRF_PRIO")) a.vec = atoi(pr);
+    a.prio = MRFS_CONV2_PRIO;  // s_setprio of the conv2 waves (see the kernel)
+    if (const char* pr = lab_getenv("MI355VITS_MRF_PRIO")) a.prio = atoi(pr);
     const long nitems = (long)((a.T + a.seg - 1) / a.seg) * a.B;
     const int cus = current_device_cu_count();
     dim3 grid((unsigned)(nitems < cus ? nitems : cus));  // persistent: one workgroup per CU

@@ -169,10 +169,21 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
             bf[p] = *reinterpret_cast<const uint4*>(L0 + lq[p] + (unsigned)((4 * g) * LDP + 16 * j + k * DIL) * 16u);
     };
 
-    if ((int)blockIdx.x >= nitems) return;
+    // ragged batches (round 6): items at or past their row's length are never computed (kernels_mrfp.cpp next_item has the argument);
+    // every role of the workgroup walks the same sequence
+    auto valid_from = [&](int it) MI355_INLINE_LAMBDA {
+        while (it < nitems) {
+            const Item o = decode(it);
+            if (o.t0 < o.len) break;
+            it += (int)gridDim.x;
+        }
+        return WAVE_UNIFORM(it);
+    };
+    const int it_first = valid_from((int)blockIdx.x);
+    if (it_first >= nitems) return;
     // ---- prologue: half 0 of the first item, the first steps' weight fragments
     {
-        const Item im = decode(blockIdx.x);
+        const Item im = decode(it_first);
         const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
         float sv[ROUNDS][8];
         MI355_UNROLL
@@ -192,9 +203,10 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
     __syncthreads();
 
     MI355_NOUNROLL
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    for (int it = it_first, itv = it_first; it < nitems; it = itv) {
+        itv = valid_from(it + (int)gridDim.x);
         const Item im = decode(it);
-        const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;  // (no next item: this one's half 0 again, unread)
+        const int itn = itv < nitems ? itv : it;  // (no next item: this one's half 0 again, unread)
         const Item imn = decode(itn);
         const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs), xbn = buf_rsrc(a.x + (long)imn.b * a.x_bs);
         const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
@@ -388,7 +400,18 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
         o.last = o.len > 0 ? o.len - 1 : 0;
         return o;
     };
-    if ((int)blockIdx.x >= nitems) return;
+    // ragged batches (round 6): items at or past their row's length are never computed (kernels_mrfp.cpp next_item has the argument);
+    // every role of the workgroup walks the same sequence
+    auto valid_from = [&](int it) MI355_INLINE_LAMBDA {
+        while (it < nitems) {
+            const Item o = decode(it);
+            if (o.t0 < o.len) break;
+            it += (int)gridDim.x;
+        }
+        return WAVE_UNIFORM(it);
+    };
+    const int it_first = valid_from((int)blockIdx.x);
+    if (it_first >= nitems) return;
     [[maybe_unused]] int clk_item = 0;
     auto stamp = [&](int slot, int k) MI355_INLINE_LAMBDA {
 #ifndef MI355_EMU
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
         };
         float sv[RP][8];
         {
-            const Item im = decode(blockIdx.x);
+            const Item im = decode(it_first);
             MI355_UNROLL
             for (int r = 0; r < RP; ++r) p_load(im, 0, r, sv[r]);
             SCHED_FENCE();
@@ -454,9 +477,10 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
         }
         __syncthreads();
         MI355_NOUNROLL
-        for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        for (int it = it_first, itv = it_first; it < nitems; it = itv) {
+            itv = valid_from(it + (int)gridDim.x);
             const Item im = decode(it);
-            const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;  // (no next item: this one again, unread)
+            const int itn = itv < nitems ? itv : it;  // (no next item: this one again, unread)
             const Item imn = decode(itn);
             // phase 0 (the matrix waves read half 0): this item's half 1 from the registers, then the loads of the next item's half 0
             stamp(cslot, 0);
@@ -518,7 +542,8 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
     __syncthreads();
 
     MI355_NOUNROLL
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    for (int it = it_first, itv = it_first; it < nitems; it = itv) {
+        itv = valid_from(it + (int)gridDim.x);
         const Item im = decode(it);
         const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
         const BufRsrc rbuf = buf_rsrc(a.res + (long)im.b * a.res_bs);

@@ -497,6 +497,7 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
     const int t0 = blockIdx.x * T_B;
     int len = a.len ? a.len[b] : a.T;
     if (len > a.T) len = a.T;
+    if (t0 >= len) return;  // ragged batches (round 6): a tile past its row's length is never computed (kernels_mrfp.cpp next_item)
     const int pad = (a.K - 1) / 2 * a.dil;
     const int tlo = t0 - pad;
     const int ts = TW ? tlo : (tlo >= 0 ? (tlo & ~3) : -(((-tlo) + 3) & ~3));  // (TW: no alignment slack — 68 staged columns, 76.5 KiB)

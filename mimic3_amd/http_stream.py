@@ -119,11 +119,12 @@ def _shared_pool(look_ahead: int) -> ThreadPoolExecutor:
 
 def _fair_share(look_ahead: int) -> int:
     """Sentences one stream may keep in flight right now: the pool's workers divided among the streams that are running, never
-    more than its own look-ahead, never fewer than two (head + one behind it) — so a request that arrives while others stream
-    finds free workers for its first sentences instead of queueing FIFO behind the earlier requests' whole windows."""
+    more than its own look-ahead, and — when the look-ahead allows it — at least two (head + one behind it), so a request that
+    arrives while others stream finds free workers for its first sentences instead of queueing FIFO behind the earlier
+    requests' whole windows."""
     with _streams_lock:
         n = max(1, _ACTIVE_STREAMS)
-    return max(2, min(look_ahead, _POOL_WORKERS // n))
+    return max(min(2, look_ahead), min(look_ahead, _POOL_WORKERS // n))
 
 
 def stream_plan(tts, plan: List[Tuple[str, Any]], look_ahead: int = 16, sample_rate: Optional[int] = None) -> Iterator[bytes]:

@@ -31,6 +31,15 @@ def gpu_lib():
 
 
 @pytest.fixture(scope="session")
+def gpu_hooks():
+    """libmi355vits_hooks.so on the real device: the PRODUCT's object files + the kernel unit-test / probe hooks of
+    include/mi355vits_lab.h (the product library exports include/mi355vits.h only).  Test infrastructure."""
+    from mimic3_amd._native import hooks_library
+
+    return hooks_library()
+
+
+@pytest.fixture(scope="session")
 def lab_lib():
     """The LAB build of the HIP library (-DMI355_LAB: kernel-choice switches for A/B tests) on the real device; built in-tree by
     ``__graft_entry__.build()`` / ``python -m mimic3_amd.build lab``.  Test infrastructure: the product never opens it."""

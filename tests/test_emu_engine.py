@@ -890,7 +890,8 @@ def test_resident_input_resblock_conv_vs_fp64(emu_lib, kd, wide, monkeypatch):
         for impl in (1, 4):
             y = emu_lib.test_conv1d(x, w, bias, res, dilation=dil, impl=impl, in_len=in_len, in_slope=0.1, out_scale=0.5,
                                     accumulate_into=y0 if acc else None)
-            err[impl] = float(np.sqrt(np.mean((y - want) ** 2)))
+            # over each row's own columns: items at or past a row's length are not computed (ragged batches, round 6)
+            err[impl] = float(np.sqrt(np.mean(((y - want) * tm.numpy()) ** 2)))
         assert err[4] < 1e-6 and err[4] <= 1.25 * err[1] + 2e-8, (acc, err)
 
 
@@ -1111,7 +1112,10 @@ def test_a_dropped_partial_product_is_caught(emu_lib, monkeypatch):
     suite checks.  Two guards catch them:
       * check_parity's bound for the f32-grade modes (5e-6 vs the fp32 oracle) trips for the two larger ones;
       * the self-calibrating criterion `error vs fp64 <= 3 x (PyTorch fp32's own error vs fp64)` (tests/util.py f32_grade_vs_fp64) trips
-        for all three, the weights' rounded l plane included, and holds for the intact engine in both f32-grade modes."""
+        for all three, the weights' rounded l plane included, and holds for the intact engine in both f32-grade modes.
+    Coverage of the injection itself: b3_chunk (WaveNet in-layer / res-skip convs, staged convs, encoder slices, DDS stacks).  The
+    lean / two-term loops (b3_chunk_lean of the polyphase upsamplers, h2_chunk of MATH_F16X2) and the MRF kernels' own MFMA sweeps
+    (k_mrf_p / k_mrf_s / k_rb_conv) carry no injection point: for them the guard is exercised by the fp64 kernel-level tests only."""
     import torch
 
     from tests.util import REL_RMS_TOL, TIGHT_REL_RMS_TOL, f32_grade_vs_fp64

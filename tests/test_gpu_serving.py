@@ -184,7 +184,7 @@ def _conv_ref(x, w, bias, dil):
 
 
 @pytest.mark.parametrize("impl", [1, 2])
-def test_staged_conv_kernels_on_wide_dynamic_range(gpu_lib, impl):
+def test_staged_conv_kernels_on_wide_dynamic_range(gpu_hooks, impl):
     """impl 2 (f32 operands split into three bf16 terms, six products on the bf16 matrix cores) and impl 1 (f32 MFMA) against
     an fp64 conv on inputs far from N(0, 1): all inputs x 2^+100, x 2^-100 (every split term still a normal bf16), per-channel
     scales from 2^-20 to 2^+20 inside one reduction, and x 2^-120 — there the second and third terms of the split
@@ -197,7 +197,7 @@ def test_staged_conv_kernels_on_wide_dynamic_range(gpu_lib, impl):
     zero_b = np.zeros(Cout, np.float32)
 
     def rel_err(x):
-        y = gpu_lib.test_conv1d(x, w, zero_b, None, dilation=dil, impl=impl).astype(np.float64)
+        y = gpu_hooks.test_conv1d(x, w, zero_b, None, dilation=dil, impl=impl).astype(np.float64)
         ref = _conv_ref(x, w, zero_b, dil)
         return float(np.sqrt(np.mean((y - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
 
@@ -216,18 +216,18 @@ def test_staged_conv_kernels_on_wide_dynamic_range(gpu_lib, impl):
     for bad in (np.inf, np.nan):
         xb = x0.copy()
         xb[1, 17, 300] = bad
-        y = gpu_lib.test_conv1d(xb, w, zero_b, None, dilation=dil, impl=impl)
+        y = gpu_hooks.test_conv1d(xb, w, zero_b, None, dilation=dil, impl=impl)
         reach = (K - 1) // 2 * dil
         hit = np.zeros((B, T), bool)
         hit[1, 300 - reach: 300 + reach + 1: dil] = True
         assert np.all(~np.isfinite(y[1][:, hit[1]])), bad
         clean = np.ones((B, Cout, T), bool)
         clean[1][:, hit[1]] = False
-        y0 = gpu_lib.test_conv1d(x0, w, zero_b, None, dilation=dil, impl=impl)
+        y0 = gpu_hooks.test_conv1d(x0, w, zero_b, None, dilation=dil, impl=impl)
         assert np.all(np.isfinite(y[clean])) and np.array_equal(y[clean], y0[clean]), bad
 
 
-def test_encoder_slice_kernel_on_wide_dynamic_range(gpu_lib):
+def test_encoder_slice_kernel_on_wide_dynamic_range(gpu_hooks):
     """impl 3 (k_enc_b3: the text encoder's convs, one 192-channel slice staged once as three bf16 planes) on the same inputs as the
     staged kernels above: x 2^+-100, per-channel scales 2^-20 .. 2^+20 inside one reduction, x 2^-120 (second / third split terms
     subnormal: leading-term accuracy at worst, never garbage), and +inf / NaN staying inside their receptive field."""
@@ -238,7 +238,7 @@ def test_encoder_slice_kernel_on_wide_dynamic_range(gpu_lib):
     zero_b = np.zeros(Cout, np.float32)
 
     def rel_err(x):
-        y = gpu_lib.test_conv1d(x, w, zero_b, None, impl=3).astype(np.float64)
+        y = gpu_hooks.test_conv1d(x, w, zero_b, None, impl=3).astype(np.float64)
         ref = _conv_ref(x, w, zero_b, 1)
         return float(np.sqrt(np.mean((y - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
 
@@ -256,13 +256,13 @@ def test_encoder_slice_kernel_on_wide_dynamic_range(gpu_lib):
     for bad in (np.inf, np.nan):
         xb = x0.copy()
         xb[1, 17, 70] = bad
-        y = gpu_lib.test_conv1d(xb, w, zero_b, None, impl=3)
+        y = gpu_hooks.test_conv1d(xb, w, zero_b, None, impl=3)
         hit = np.zeros(T, bool)
         hit[69:72] = True
         assert np.all(~np.isfinite(y[1][:, hit])), bad
         clean = np.ones((B, Cout, T), bool)
         clean[1][:, hit] = False
-        y0 = gpu_lib.test_conv1d(x0, w, zero_b, None, impl=3)
+        y0 = gpu_hooks.test_conv1d(x0, w, zero_b, None, impl=3)
         assert np.all(np.isfinite(y[clean])) and np.array_equal(y[clean], y0[clean]), bad
 
 

@@ -180,9 +180,10 @@ def test_box_probe_reports_plausible_numbers_and_leaves_the_engine_untouched():
     """mi355vits_probe_device / mi355vits_probe_weights (bench.py carries them in its line so that a slow lease can be told from a
     slow kernel): every figure positive and inside what an MI355X can physically do, the weight-arena probe works on a live handle,
     and a run after the probes gives the same bits as a run before them."""
-    from mimic3_amd._native import Engine, default_library
+    from mimic3_amd._native import Engine, default_library, hooks_library
 
-    lib = default_library()
+    assert not default_library().has_hooks  # the product library exports include/mi355vits.h only
+    lib = hooks_library()                   # the product's objects + include/mi355vits_lab.h
     p = lib.probe_device(0)
     assert p["cus"] > 0
     assert 1e3 < p["l2_stream_GBps"] < 2e5 and 5e2 < p["hbm_copy_GBps"] < 8.1e3, p
@@ -190,7 +191,7 @@ def test_box_probe_reports_plausible_numbers_and_leaves_the_engine_untouched():
     assert 0 < p["l2_stream_beside_copy_GBps"] <= 1.2 * p["l2_stream_GBps"] and p["table_24MB_stream_GBps"] > 0, p
     cfg = VitsConfig.apope_low()
     w = W.synthetic_weights(cfg, seed=5, frames_per_id=2.0)
-    eng = Engine(W.pack(cfg, w), device=0)
+    eng = Engine(W.pack(cfg, w), device=0, library=lib)
     ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (2, 40))
     before = eng.run(ids, [40, 31], [0.667, 1.0, 0.8], seed=9, want_pcm16=True)
     q = eng.probe_weights()

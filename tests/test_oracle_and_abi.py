@@ -120,6 +120,24 @@ def test_product_library_exports_the_c_abi():
     assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
     lib = NativeLibrary(build.build_hip())  # cross-compiles for gfx950 when stale; loading needs no GPU
     assert "gfx950" in lib.version()
+    # the product / lab split: unit-test, micro-benchmark and probe hooks are declared in include/mi355vits_lab.h
+    # and exported by libmi355vits_hooks.so (the product's objects + csrc/lab_api.cpp), the lab build and the CPU model — the
+    # product library carries none of them
+    import subprocess
+
+    from mimic3_amd._native import HOOKS_LIBRARY, LAB_SYMBOLS
+
+    lab_hdr = open(os.path.join(ROOT, "include", "mi355vits_lab.h")).read()
+    lab_declared = set(re.findall(r"\b(mi355vits_[a-z0-9_]+)\s*\(", lab_hdr))
+    assert lab_declared == set(LAB_SYMBOLS) and not (lab_declared & declared), lab_declared ^ set(LAB_SYMBOLS)
+    assert not lib.has_hooks
+    dyn = subprocess.run(["nm", "-D", "--defined-only", lib.path], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(mi355vits_[a-z0-9_]+)\b", dyn))
+    assert exported == declared, exported ^ declared  # nothing beyond include/mi355vits.h leaves the product library
+    hooks = NativeLibrary(HOOKS_LIBRARY)
+    assert hooks.has_hooks and "gfx950" in hooks.version()
+    with pytest.raises(RuntimeError, match="mi355vits_lab.h"):
+        lib.test_mfma_layout()
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -167,3 +167,55 @@ def test_server_error_path_is_the_references(server):
     assert resp.status_code == 500 and "VoiceNotFoundError" in body, body
     ok = asyncio.run(app.dispatch("GET", "/api/healthcheck"))
     assert asyncio.run(ok.get_data()) == b"OK"
+
+
+def test_fair_share_of_concurrent_streams_with_a_fake_tts():
+    """the accounting of concurrent streams (one shared pool, a fair share of its workers per running stream, look_ahead = 1
+    honoured, an abandoned generator gives its share back) — driven with a fake tts, no engine involved."""
+    import threading
+    import time
+
+    from mimic3_amd import http_stream as HS
+
+    class FakeTTS:
+        def __init__(self):
+            self.inflight = 0
+            self.peak = 0
+            self.lock = threading.Lock()
+
+        def speak(self, p, settings=None):
+            with self.lock:
+                self.inflight += 1
+                self.peak = max(self.peak, self.inflight)
+            time.sleep(0.002)
+            with self.lock:
+                self.inflight -= 1
+
+            class R:
+                audio_bytes = bytes([p % 256]) * 4
+            return R()
+
+    FakeTTS._mi355_speak_sentence_original = lambda self, p, settings=None: self.speak(p, settings)
+    tts = FakeTTS()
+    tts.settings = type("S", (), {"sample_rate": 22050})()
+    plan = [("rate", 22050)] + [("speak", (i, None)) for i in range(12)]
+    # look_ahead = 1: never more than one sentence of this stream in flight (round 5 kept two)
+    body = b"".join(HS.stream_plan(tts, plan, look_ahead=1))
+    assert body[44:] == b"".join(bytes([i]) * 4 for i in range(12)) and tts.peak == 1
+    assert HS._fair_share(1) == 1 and HS._ACTIVE_STREAMS == 0
+    # 40 concurrent streams on the one pool: every stream complete and in order, the share never exceeds the pool
+    outs = [None] * 40
+
+    def run(k):
+        outs[k] = b"".join(HS.stream_plan(tts, plan, look_ahead=8))
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(40)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(o == body for o in outs) and tts.peak <= HS._POOL_WORKERS and HS._ACTIVE_STREAMS == 0
+    # an abandoned generator (client gone after two chunks) returns its share
+    g = HS.stream_plan(tts, plan, look_ahead=4)
+    next(g), next(g), next(g)
+    assert HS._ACTIVE_STREAMS == 1
+    g.close()
+    assert HS._ACTIVE_STREAMS == 0

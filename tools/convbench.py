@@ -18,11 +18,11 @@ SHAPES = {
 
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, ROOT)
-    from mimic3_amd._native import default_library
+    from mimic3_amd._native import hooks_library
 
     name = sys.argv[2]
     B, Cin, Cout, T, K, dil, epi = SHAPES[name]
-    ms = default_library().bench_conv1d(B, Cin, Cout, T, K, dil, epi, reps=10)
+    ms = hooks_library().bench_conv1d(B, Cin, Cout, T, K, dil, epi, reps=10)
     fl = 2.0 * B * T * Cout * Cin * K
     print(json.dumps({"shape": name, "cfg": os.environ.get("MI355VITS_CONV_CFG", "auto"),
                       "chunk": os.environ.get("MI355VITS_CONV_CHUNK", "64"), "ms": ms, "tflops": fl / ms / 1e9}))
