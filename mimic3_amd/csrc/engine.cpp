@@ -704,6 +704,9 @@ void Engine::conv(const char* label, const ConvW& w, ConvArgs a) {
     if (rbc_ok(w, a)) {  // 128-channel resblock convs: every input channel resident, one launch per conv (k_rb_conv)
         a.w = P(w.packed_p);
         a.math = MATH_BF16X3;
+        // the host's copy of the row lengths (the per-stage lengths are made on the host and uploaded as one table): the launcher
+        // counts the (row, column block) items that have work from it
+        if (d_slen_ && a.in_len >= d_slen_ && a.in_len < d_slen_ + h_slen_.size()) a.in_len_host = h_slen_.data() + (a.in_len - d_slen_);
         launch_rb_conv(a, stream_);
         return;
     }
@@ -1246,6 +1249,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
                     m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
+                    m.len_host = h_slen_.data() + (size_t)(i + 1) * B;
                     // large grids: the row sweep (k_mrf_s: fragments register-resident per segment, no halo recompute); small ones:
                     // (row, column block) items (k_mrf_p).  The two agree bit for bit, so the choice may follow the grid.
                     // 64 channels: one pass per resblock (k_mrf_s).  32 channels: k_mrf_p (its single-pass sweep, k_mrf_s1, measured equal in
@@ -1300,6 +1304,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     m.x = d_bufA_; m.x_bs = sbs; m.x_ld = (int)T;
                     m.y = d_bufC_; m.y_bs = sbs; m.y_ld = (int)T;
                     m.len = slen; m.B = B; m.C = ch; m.T = (int)T;
+                    m.len_host = h_slen_.data() + (size_t)(i + 1) * B;
                     const double bytes = 8.0 * B * (double)T * ch;
                     ProfScope ps(prof_, i == 1 ? "dec.mrf_fused.s1" : (i == 2 ? "dec.mrf_fused.s2" : (i == 0 ? "dec.mrf_fused.s0" : "dec.mrf_fused")), flops,
                                  bytes);

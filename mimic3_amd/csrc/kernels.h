@@ -22,6 +22,8 @@ struct ConvArgs {
     const float* res = nullptr; long res_bs = 0; int res_ld = 0;  // residual [B,Cout,T] or null
     float* y2 = nullptr; long y2_bs = 0; int y2_ld = 0;           // RESSKIP: skip accumulator [B,H,T]
     const int* in_len = nullptr;   // [B] valid length of the input (x * mask) or null
+    const int* in_len_host = nullptr;  // kernels_rbc.cpp: the host's copy of in_len (launcher: counts the items with work; null: read back)
+    int nvalid = 0;                // kernels_rbc.cpp: (row, column block) items with work, filled by the launcher (mrf_valid_items)
     const int* out_len = nullptr;  // [B] valid length of the output (y * mask) or null
     int B = 1, Cin = 0, Cout = 0, T = 0, K = 1, dil = 1;
     int pad = -1;            // left zero padding; -1 = "same" ((K*dil - dil) / 2), filled in by Engine::conv
@@ -133,6 +135,9 @@ struct MrfArgs {
     int ablate = 0;  // profiling only (MI355VITS_MRF_ABLATE): 1 = skip MFMA loops, 2 = skip staging, 4 = skip output
     int seg = 0;     // launch_mrf_s: columns per work item (a multiple of the kernel's step), from mrf_s_segment
     unsigned* clk = nullptr;  // -DMRFP_CLOCKS lab builds only: shader-clock stamps (kernels_mrfp.cpp)
+    const int* len_host = nullptr;  // the host's copy of `len` (the engine has it: the per-stage lengths are made on the host): lets the
+                                    // launcher count the column blocks that have work; nullptr with len != nullptr: read back (tests)
+    int nvalid = 0;  // k_mrf_p: work items with work = sum over the rows of ceil(len / T_B), filled by the launcher
     int prio = 0;    // k_mrf_s: wave-priority mode of the conv2 waves (0 none, 1-3 a fixed s_setprio, 4-6 dynamic: see the kernel)
 };
 bool mrf_fused_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
@@ -142,6 +147,9 @@ void launch_mrf_fused(MrfArgs a, hipStream_t s);
 size_t p16_packed_words(int Cout, int Cin, int K);
 void pack_conv_weights_p16(const float* w, int Cout, int Cin, int K, uint32_t* out);
 bool mrf_p_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
+// sum over the rows of ceil(min(len, T) / block): the (row, column block) items of a ragged batch that have work.  len_host = the
+// host's copy of the device array len (nullptr: copied back, a synchronising call — unit-test hooks only); len == nullptr: every row T
+int mrf_valid_items(const int* len_host, const int* len_dev, int B, int T, int block);
 void launch_mrf_p(MrfArgs a, hipStream_t s);
 // The same stage, same bits, as a row sweep (kernels_mrfs.cpp): work item = (row, segment), one pass per resblock with the
 // waves specialised by conv, every conv's fragments in registers for the whole segment, no halo recompute; y accumulates the

@@ -150,29 +150,43 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
     float* BS = reinterpret_cast<float*>(X1p + 3 * PS1);  // [nrb][2][C] biases
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
     const int mt = wid % NWM;
-    // work items: item = row * ntile + column block; this workgroup takes first, first + stride, ...  (blocks of one XCD —
-    // block b runs on XCD b % 8 — walk neighbouring items: the halo columns two items share are re-read from that XCD's L2)
-    const int ntile = (a.T + T_B - 1) / T_B;
-    const int nitems = ntile * a.B;
+    // work items = the column blocks that HAVE work: row b contributes nv_b = ceil(len_b / T_B) of them (ragged batches, round 6: a
+    // block that starts at or past its row's length is never computed — its output columns are past the row's end, every consumer
+    // masks its input at the row's length, the workspace is zero-filled when it is allocated — so a batch costs the sum of its rows'
+    // lengths in this stage, not rows x the longest).  Valid items are numbered row by row (a.nvalid of them: counted by the
+    // launcher from the host's copy of the lengths); this workgroup takes first, first + stride, ... of its XCD's contiguous eighth
+    // (blocks of one XCD — block b runs on XCD b % 8 — walk neighbouring items: the halo columns two items share are re-read from
+    // that XCD's L2; the eighths hold equal numbers of VALID items whatever the rows' lengths).  A cursor (row, first valid index
+    // of that row, its count) turns an index into (row, column block); the indices of a workgroup only grow.
+    const int nitems = a.nvalid;
     const int nblk = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int per_xcd = (nitems + 7) >> 3, nslot = (nblk + 7 - xcd) >> 3;  // blocks on this XCD (nblk need not be a multiple of 8)
     const int item_end = (xcd + 1) * per_xcd < nitems ? (xcd + 1) * per_xcd : nitems;
-    // Ragged batches (round 6): an item that starts at or past its row's length is never computed — its output columns are past
-    // the row's end, every consumer masks its input at the row's length, the workspace is zero-filled when it is allocated —, so a
-    // batch costs the sum of its rows' lengths in this stage, not rows x the longest.  next_item: the first item >= `it` on this
-    // workgroup's stride that has work (a row's remaining column blocks are jumped over in one step).
-    auto next_item = [&](int it) MI355_INLINE_LAMBDA {
-        while (it < item_end) {
-            const int bb = it / ntile;
-            int ln = a.len ? a.len[bb] : a.T;
-            if (ln > a.T) ln = a.T;
-            if ((it - bb * ntile) * T_B < ln) break;
-            const int row_end = (bb + 1) * ntile;                 // first item of the next row
-            it += (row_end - it + nslot - 1) / nslot * nslot;
-        }
-        return WAVE_UNIFORM(it);
+    auto row_len = [&](int bb) MI355_INLINE_LAMBDA {
+        int ln = a.len ? a.len[bb] : a.T;
+        return ln > a.T ? a.T : ln;
     };
-    int item = next_item(xcd * per_xcd + slot);
+    struct Cursor { int r, base, nv; };
+    auto locate = [&](int v, Cursor& c) MI355_INLINE_LAMBDA {  // v < a.nvalid: the loop ends inside the batch
+        while (v >= c.base + c.nv) {
+            c.base += c.nv;
+            ++c.r;
+            const int ln = row_len(c.r);
+            c.nv = ln > 0 ? (ln + T_B - 1) / T_B : 0;
+        }
+        c.r = WAVE_UNIFORM(c.r);
+        c.base = WAVE_UNIFORM(c.base);
+        c.nv = WAVE_UNIFORM(c.nv);
+    };
+    int item = xcd * per_xcd + slot;
+    Cursor cur;
+    cur.r = 0;
+    cur.base = 0;
+    {
+        const int ln = row_len(0);
+        cur.nv = ln > 0 ? (ln + T_B - 1) / T_B : 0;
+    }
+    if (item < item_end) locate(item, cur);
 
     uint4 W[MRFP_KMAX][3];
     // fragments of (resblock j, conv c, k-group g) for this wave's row tile (wave-uniform; the lane is a 32-bit index on top)
@@ -303,9 +317,8 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
 
     if constexpr (PIPE) {  // the workgroup's first item is staged here, every later one under its predecessor's last conv2
         if (item < item_end) {
-            const int b0 = item / ntile, t00 = (item - b0 * ntile) * T_B;
-            int len0 = a.len ? a.len[b0] : a.T;
-            if (len0 > a.T) len0 = a.T;
+            const int b0 = cur.r, t00 = (item - cur.base) * T_B;
+            const int len0 = row_len(b0);
             spart = wid / wpc;
             scol = wid * 64 + lane - spart * wpc * 64;
             stager = spart < nparts && scol < LDX && spart * RB < 4 * G;
@@ -325,27 +338,23 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         stager = spart < nparts && scol < LDX && spart * RB < 4 * G;
         const int gq = mt >> 1, hh = mt & 1;
         const int co0 = 32 * gq + 8 * q + 4 * hh;  // this lane's four output channels co0 .. co0 + 3 = half hh of record (gq, q)
-        const int b = WAVE_UNIFORM(item / ntile), t0 = WAVE_UNIFORM((item - b * ntile) * T_B);  // scalar registers, whatever the division ran on
-        int len = a.len ? a.len[b] : a.T;
-        if (len > a.T) len = a.T;
-        len = WAVE_UNIFORM(len);
+        const int b = cur.r, t0 = WAVE_UNIFORM((item - cur.base) * T_B);  // scalar registers
+        const int len = WAVE_UNIFORM(row_len(b));
         const int last = len > 0 ? len - 1 : 0;
         const float* xb = a.x + (long)b * a.x_bs;
-        item_next = next_item(item + nslot);
+        item_next = item + nslot;
         const bool more = item_next < item_end;  // wave-uniform
+        Cursor cn = cur;
+        if (more) locate(item_next, cn);
 
         stamp(0);
         if constexpr (!PIPE) stage_item(b, t0, len);
         stamp(1);
         // PIPE: the next item of this workgroup (the current one again behind the last: its x tile is dead, the loads hit the L2)
         NextItem nx;
-        nx.b = more ? WAVE_UNIFORM(item_next / ntile) : b;
-        nx.t0 = more ? WAVE_UNIFORM((item_next - nx.b * ntile) * T_B) : t0;
-        {
-            int ln = a.len ? a.len[nx.b] : a.T;
-            if (ln > a.T) ln = a.T;
-            nx.len = WAVE_UNIFORM(ln);
-        }
+        nx.b = more ? cn.r : b;
+        nx.t0 = more ? WAVE_UNIFORM((item_next - cn.base) * T_B) : t0;
+        nx.len = WAVE_UNIFORM(row_len(nx.b));
         const int pcol = wid_o * 64 + lane_o < LDX ? wid_o * 64 + lane_o : LDX - 1;
         __syncthreads();  // x is staged; every wave is done with the previous item's x1
         stamp(2);
@@ -513,6 +522,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         }
         stamp(27);
         ++clk_item;
+        cur = cn;
     }
 }
 
@@ -587,6 +597,24 @@ inline bool shape_p(int C, int nrb, const int* k, const int* d1, const int* d2, 
 }
 }  // namespace
 
+int mrf_valid_items(const int* len_host, const int* len_dev, int B, int T, int block) {
+    if (B <= 0 || T <= 0 || block <= 0) return 0;
+    const int full = (T + block - 1) / block;
+    if (!len_dev) return B * full;
+    std::vector<int> tmp;
+    if (!len_host) {
+        tmp.resize((size_t)B);
+        HIP_CHECK(hipMemcpy(tmp.data(), len_dev, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
+        len_host = tmp.data();
+    }
+    long n = 0;
+    for (int b = 0; b < B; ++b) {
+        const int ln = len_host[b] > T ? T : len_host[b];
+        if (ln > 0) n += (ln + block - 1) / block;
+    }
+    return (int)n;
+}
+
 bool mrf_p_supported(int C, int nrb, const int* k, const int* d1, const int* d2) {
     GeoP g;
     int R, ldx, ld1;
@@ -635,7 +663,9 @@ void launch_mrf_p(MrfArgs a, hipStream_t s) {
     size_t shmem = 0;
     if (!geometry_p(a.C, &g) || a.nrb < 1 || a.nrb > MRF_MAX_RB || !shape_p(a.C, a.nrb, a.k, a.d1, a.d2, g, &a.R, &a.ldx, &a.ld1, &shmem))
         throw std::runtime_error("mrf_p: unsupported stage shape");
-    const long nitems = (long)((a.T + g.T_B - 1) / g.T_B) * a.B;
+    a.nvalid = mrf_valid_items(a.len_host, a.len, a.B, a.T, g.T_B);
+    const long nitems = a.nvalid;
+    if (nitems <= 0) return;
     const int cus = current_device_cu_count();
     dim3 grid((unsigned)(nitems < cus ? nitems : cus));  // persistent: one workgroup per CU (160 KiB of LDS each)
 #ifdef MI355_LAB

@@ -87,8 +87,10 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
     float bia[4];
     MI355_UNROLL
     for (int r = 0; r < 4; ++r) bia[r] = a.bias ? a.bias[co0 + r] : 0.0f;
-    const int nblk = (a.T + N - 1) / N;
-    const int nitems = nblk * a.B;
+    // work items = the (row, column block) pairs that HAVE work, a.nvalid of them, numbered row by row (ragged batches, round 6:
+    // kernels_mrfp.cpp has the argument): row b holds ceil(len_b / N); a cursor turns a valid index into (row, block) — the
+    // indices a workgroup decodes only grow
+    const int nitems = a.nvalid;
     const unsigned xrow = 4u * (unsigned)a.x_ld, yrow = 4u * (unsigned)a.y_ld, rrow = 4u * (unsigned)a.res_ld;
 
     struct Item { int b, t0, len, last; };
@@ -102,11 +104,25 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
         return ((cptr_t)(a.in_len))[b];
 #endif
     };
-    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+    struct Cursor { int r, base, nv; };
+    auto row_nv = [&](int b) MI355_INLINE_LAMBDA {
+        int len = row_len(b);
+        if (len > a.T) len = a.T;
+        return len > 0 ? (len + N - 1) / N : 0;
+    };
+    auto decode = [&](int it, Cursor& c) MI355_INLINE_LAMBDA {
         Item o;
         it = rbc_item(it, nitems, a.item_order);
-        o.b = WAVE_UNIFORM(it / nblk);
-        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
+        while (it >= c.base + c.nv) {  // (it < a.nvalid: ends inside the batch)
+            c.base += c.nv;
+            ++c.r;
+            c.nv = row_nv(c.r);
+        }
+        c.r = WAVE_UNIFORM(c.r);
+        c.base = WAVE_UNIFORM(c.base);
+        c.nv = WAVE_UNIFORM(c.nv);
+        o.b = c.r;
+        o.t0 = WAVE_UNIFORM((it - c.base) * N);
         int len = row_len(o.b);
         if (len > a.T) len = a.T;
         o.len = len;
@@ -169,21 +185,15 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
             bf[p] = *reinterpret_cast<const uint4*>(L0 + lq[p] + (unsigned)((4 * g) * LDP + 16 * j + k * DIL) * 16u);
     };
 
-    // ragged batches (round 6): items at or past their row's length are never computed (kernels_mrfp.cpp next_item has the argument);
-    // every role of the workgroup walks the same sequence
-    auto valid_from = [&](int it) MI355_INLINE_LAMBDA {
-        while (it < nitems) {
-            const Item o = decode(it);
-            if (o.t0 < o.len) break;
-            it += (int)gridDim.x;
-        }
-        return WAVE_UNIFORM(it);
-    };
-    const int it_first = valid_from((int)blockIdx.x);
+    const int it_first = (int)blockIdx.x;
     if (it_first >= nitems) return;
+    Cursor cur;
+    cur.r = 0;
+    cur.base = 0;
+    cur.nv = row_nv(0);
     // ---- prologue: half 0 of the first item, the first steps' weight fragments
     {
-        const Item im = decode(it_first);
+        const Item im = decode(it_first, cur);
         const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
         float sv[ROUNDS][8];
         MI355_UNROLL
@@ -204,10 +214,10 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
 
     MI355_NOUNROLL
     for (int it = it_first, itv = it_first; it < nitems; it = itv) {
-        itv = valid_from(it + (int)gridDim.x);
-        const Item im = decode(it);
+        itv = it + (int)gridDim.x;
+        const Item im = decode(it, cur);
         const int itn = itv < nitems ? itv : it;  // (no next item: this one's half 0 again, unread)
-        const Item imn = decode(itn);
+        const Item imn = decode(itn, cur);
         const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs), xbn = buf_rsrc(a.x + (long)imn.b * a.x_bs);
         const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
         const BufRsrc rbuf = buf_rsrc(a.res + (long)im.b * a.res_bs);
@@ -376,8 +386,10 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
     DYN_SMEM(float, smem);
     char* L0 = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = WAVE_UNIFORM(tid >> 6);
-    const int nblk = (a.T + N - 1) / N;
-    const int nitems = nblk * a.B;
+    // work items = the (row, column block) pairs that HAVE work, a.nvalid of them, numbered row by row (ragged batches, round 6:
+    // kernels_mrfp.cpp has the argument): row b holds ceil(len_b / N); a cursor turns a valid index into (row, block) — the
+    // indices a workgroup decodes only grow
+    const int nitems = a.nvalid;
     const unsigned xrow = 4u * (unsigned)a.x_ld, yrow = 4u * (unsigned)a.y_ld, rrow = 4u * (unsigned)a.res_ld;
 
     struct Item { int b, t0, len, last; };
@@ -389,29 +401,37 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
         return ((cptr_t)(a.in_len))[b];
 #endif
     };
-    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+    struct Cursor { int r, base, nv; };
+    auto row_nv = [&](int b) MI355_INLINE_LAMBDA {
+        int len = row_len(b);
+        if (len > a.T) len = a.T;
+        return len > 0 ? (len + N - 1) / N : 0;
+    };
+    auto decode = [&](int it, Cursor& c) MI355_INLINE_LAMBDA {
         Item o;
         it = rbc_item(it, nitems, a.item_order);
-        o.b = WAVE_UNIFORM(it / nblk);
-        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
+        while (it >= c.base + c.nv) {  // (it < a.nvalid: ends inside the batch)
+            c.base += c.nv;
+            ++c.r;
+            c.nv = row_nv(c.r);
+        }
+        c.r = WAVE_UNIFORM(c.r);
+        c.base = WAVE_UNIFORM(c.base);
+        c.nv = WAVE_UNIFORM(c.nv);
+        o.b = c.r;
+        o.t0 = WAVE_UNIFORM((it - c.base) * N);
         int len = row_len(o.b);
         if (len > a.T) len = a.T;
         o.len = len;
         o.last = o.len > 0 ? o.len - 1 : 0;
         return o;
     };
-    // ragged batches (round 6): items at or past their row's length are never computed (kernels_mrfp.cpp next_item has the argument);
-    // every role of the workgroup walks the same sequence
-    auto valid_from = [&](int it) MI355_INLINE_LAMBDA {
-        while (it < nitems) {
-            const Item o = decode(it);
-            if (o.t0 < o.len) break;
-            it += (int)gridDim.x;
-        }
-        return WAVE_UNIFORM(it);
-    };
-    const int it_first = valid_from((int)blockIdx.x);
+    const int it_first = (int)blockIdx.x;
     if (it_first >= nitems) return;
+    Cursor cur;
+    cur.r = 0;
+    cur.base = 0;
+    cur.nv = row_nv(0);
     [[maybe_unused]] int clk_item = 0;
     auto stamp = [&](int slot, int k) MI355_INLINE_LAMBDA {
 #ifndef MI355_EMU
@@ -465,7 +485,7 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
         };
         float sv[RP][8];
         {
-            const Item im = decode(it_first);
+            const Item im = decode(it_first, cur);
             MI355_UNROLL
             for (int r = 0; r < RP; ++r) p_load(im, 0, r, sv[r]);
             SCHED_FENCE();
@@ -478,10 +498,10 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
         __syncthreads();
         MI355_NOUNROLL
         for (int it = it_first, itv = it_first; it < nitems; it = itv) {
-            itv = valid_from(it + (int)gridDim.x);
-            const Item im = decode(it);
+            itv = it + (int)gridDim.x;
+            const Item im = decode(it, cur);
             const int itn = itv < nitems ? itv : it;  // (no next item: this one again, unread)
-            const Item imn = decode(itn);
+            const Item imn = decode(itn, cur);
             // phase 0 (the matrix waves read half 0): this item's half 1 from the registers, then the loads of the next item's half 0
             stamp(cslot, 0);
             MI355_UNROLL
@@ -543,8 +563,8 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
 
     MI355_NOUNROLL
     for (int it = it_first, itv = it_first; it < nitems; it = itv) {
-        itv = valid_from(it + (int)gridDim.x);
-        const Item im = decode(it);
+        itv = it + (int)gridDim.x;
+        const Item im = decode(it, cur);
         const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
         const BufRsrc rbuf = buf_rsrc(a.res + (long)im.b * a.res_bs);
         f32x4 acc[NCT];
@@ -1188,10 +1208,13 @@ void launch_rb_conv(ConvArgs a, hipStream_t s) {
     const int cus = current_device_cu_count();
     a.item_order = RBC_ITEM_ORDER;
     if (const char* f = lab_getenv("MI355VITS_RBC_ITEM_ORDER")) a.item_order = atoi(f);  // lab / tests: 0 = items w, w + W, ... as in round 4
-    bool wide = (long)a.B * ((a.T + 127) / 128) >= cus;
+    // (the form follows the items that HAVE work: a ragged batch is as large as the sum of its rows)
+    bool wide = mrf_valid_items(a.in_len_host, a.in_len, a.B, a.T, 128) >= cus;
     if (const char* f = lab_getenv("MI355VITS_RBC_WIDE")) wide = atoi(f) != 0;  // lab / tests
     auto go = [&](auto kfn, size_t lds, int ncols) {
-        const long nitems = (long)((a.T + ncols - 1) / ncols) * a.B;
+        a.nvalid = mrf_valid_items(a.in_len_host, a.in_len, a.B, a.T, ncols);
+        const long nitems = a.nvalid;
+        if (nitems <= 0) return;
         dim3 grid((unsigned)(nitems < cus ? nitems : cus));  // persistent: one workgroup per CU
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(512), lds, s, a);
@@ -1200,7 +1223,9 @@ void launch_rb_conv(ConvArgs a, hipStream_t s) {
     int pw = RBC_PW_DEFAULT;
     if (const char* f = lab_getenv("MI355VITS_RBC_PW")) pw = atoi(f);
     auto go_pw = [&](auto kfn, size_t lds) {
-        const long nitems = (long)((a.T + 127) / 128) * a.B;
+        a.nvalid = mrf_valid_items(a.in_len_host, a.in_len, a.B, a.T, 128);
+        const long nitems = a.nvalid;
+        if (nitems <= 0) return;
         dim3 grid((unsigned)(nitems < cus ? nitems : cus));
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(768), lds, s, a);
@@ -1210,7 +1235,8 @@ void launch_rb_conv(ConvArgs a, hipStream_t s) {
         static int shots = 0;
         if (shots < 4) {  // (two launches of each shape: the first warms the caches)
             ++shots;
-            const long nitems = (long)((a.T + 127) / 128) * a.B;
+            a.nvalid = mrf_valid_items(a.in_len_host, a.in_len, a.B, a.T, 128);
+            const long nitems = a.nvalid;
             const int grid = (int)(nitems < cus ? nitems : cus);
             float* dbg = nullptr;
             const size_t nb = (size_t)grid * 3 * 8 * 8 * 4;

@@ -73,6 +73,7 @@ int mi355vits_test_conv1d(int device, const mi355vits_conv_test* t) {
             HIP_CHECK(hipMemcpy(dpp.p, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
             a.w = dpp.as<float>();
             a.math = MATH_BF16X3;
+            a.in_len_host = t->in_len;
             launch_rb_conv(a, nullptr);
             HIP_CHECK(hipDeviceSynchronize());
         } else if (t->impl == 1 || t->impl == 2) {

@@ -528,23 +528,24 @@ class InferenceSession:
         return [audio[:, None, :]]
 
     # ---- engine extensions --------------------------------------------------------------------
-    def run_pcm16(self, input_feed: Dict[str, np.ndarray], volume: Optional[float] = None
+    def run_pcm16(self, input_feed: Dict[str, np.ndarray], volume: Optional[float] = None, direct: bool = False
                   ) -> Tuple[List[np.ndarray], np.ndarray]:
         """``run`` + ``audio_float_to_int16`` (``utils.py:237-244``) fused on the GPU, per utterance over its
         valid samples.  Returns ([int16 [L_b]] per row, lengths).
 
         ``volume`` (percent, like ``Mimic3Settings.volume``): additionally applies
         ``audioop.mul(audio_bytes, 2, volume / 100)`` (``tts.py:542-543``) in the same kernel — same bytes as the host
-        call, one pass fewer over the audio."""
+        call, one pass fewer over the audio.  ``direct``: a single-utterance call goes straight to a lane instead
+        of through the micro-batcher's queue (a planned request's first sentence: two thread hand-overs fewer; same bits)."""
         kw = {}
         if volume is not None and float(volume) != 100.0:
             if not float(volume) > 0.0:
                 raise InvalidArgument("volume must be > 0 (percent)")
             kw["pcm_volume"] = float(volume) / 100.0
-        out = self._run(input_feed, want_float=False, want_pcm16=True, **kw)
+        out = self._run(input_feed, _direct=direct, want_float=False, want_pcm16=True, **kw)
         return [out["pcm"][b, : int(out["lengths"][b])] for b in range(out["pcm"].shape[0])], out["lengths"]
 
-    def _run(self, input_feed, **kw) -> Dict[str, np.ndarray]:
+    def _run(self, input_feed, _direct: bool = False, **kw) -> Dict[str, np.ndarray]:
         if not isinstance(input_feed, dict):
             raise InvalidArgument("input_feed must be a dict of numpy arrays")
         required = ["input", "input_lengths", "scales"] + (["sid"] if self.config.is_multispeaker else [])
@@ -563,7 +564,7 @@ class InferenceSession:
             raise InvalidArgument("'input' must be an int64 tensor")
         sid = input_feed.get("sid") if self.config.is_multispeaker else None
         lengths = np.asarray(input_feed["input_lengths"]).reshape(-1)
-        if self._batcher is not None and ids.shape[0] == 1 and lengths.shape[0] == 1 and 0 <= int(lengths[0]) <= ids.shape[1]:
+        if self._batcher is not None and not _direct and ids.shape[0] == 1 and lengths.shape[0] == 1 and 0 <= int(lengths[0]) <= ids.shape[1]:
             sid1 = None if sid is None else np.asarray(sid).reshape(-1)
             out = self._batcher.submit(np.asarray(ids, np.int64), lengths.astype(np.int64), input_feed["scales"], sid1, kw).result()
         else:

@@ -1158,3 +1158,36 @@ def test_a_dropped_partial_product_is_caught(emu_lib, monkeypatch):
         worst = max(rel_rms(out["audio"][b, :int(out["lengths"][b])], intact["audio"][b, :int(out["lengths"][b])]) for b in range(2))
         caught_by_tight += worst > TIGHT_REL_RMS_TOL
     assert caught_by_tight >= 2                        # check_parity's 5e-6 bound: h_w x l_x and m x m
+
+
+def test_ragged_batch_computes_only_the_rows_own_items(emu_lib):
+    """Round 6: the persistent decoder / flow kernels walk the (row, column block) items that HAVE work — numbered row by row, a
+    cursor per workgroup, the XCD eighths equal in valid items — instead of rows x the longest row.  Very unequal rows (1 .. 40 ids,
+    several rows shorter than one work item, the longest over many): every row bitwise what it is alone, all taps and the waveform
+    against the oracle, and again on a REUSED handle whose workspace still holds the previous, longer batch (columns past a row's end
+    keep stale values: they must never reach a valid sample)."""
+    cfg = VitsConfig.tiny_wide(initial_channel=256)
+    w = W.synthetic_weights(cfg, seed=91, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 40
+    rng = np.random.default_rng(12)
+    ids = rng.integers(1, cfg.num_symbols, (6, Tx))
+    lengths = np.array([Tx, 3, 22, 1, Tx, 9])
+    forced = np.full((6, Tx), 4, np.int32)
+    eng = Engine(blob, library=emu_lib)
+    eng.set_math("bf16x3")
+    big = eng.run(rng.integers(1, cfg.num_symbols, (6, Tx)), np.full(6, Tx), [0.667, 1.0, 0.8], forced_durations=forced, seed=1)  # fills the workspace
+    assert np.isfinite(big["audio"]).all()
+    out, _ = check_parity(emu_lib, cfg, ids=ids, lengths=lengths, forced=forced, noise=True, seed=12, weights=w, engine=eng)
+    rng2 = np.random.default_rng(12 + 7)  # check_parity's noise draws (tests/util.py): the same tensors for the solo runs
+    nw = rng2.standard_normal((6, 2, Tx)).astype(np.float32)
+    nz = rng2.standard_normal((6, cfg.inter_channels, Tx * 4)).astype(np.float32)
+    for b in range(6):
+        n = int(lengths[b])
+        one = eng.run(ids[b:b + 1, :n], [n], [0.667, 1.0, 0.8], forced_durations=forced[b:b + 1, :n], noise_w=nw[b:b + 1, :, :n],
+                      noise_z=nz[b:b + 1, :, : n * 4], want_pcm16=True)
+        L = int(one["lengths"][0])
+        assert L == int(out["lengths"][b])
+        assert np.array_equal(one["audio"][0, :L], out["audio"][b, :L]), b
+        assert np.array_equal(one["pcm"][0, :L], out["pcm"][b, :L]), b
+    eng.close()

@@ -43,11 +43,17 @@ def main():
         feeds.append({"input": rng.integers(1, 50, (1, n)).astype(np.int64), "input_lengths": np.array([n], np.int64),
                       "scales": np.array([0.667, 1.0, 0.8], np.float32)})
     modes = {"plain": (1, 0.0), "lanes": (3, 0.0), "batch": (1, 2.0), "batch+lanes": (3, 2.0)}
+    maxb = int(os.environ.get("MAXB", "32"))
+    if os.environ.get("MODES"):  # e.g. MODES="batch+lanes:2:1.0,batch+lanes:4:2.0" = name:lanes:window_ms (a sweep of the serving knobs)
+        modes = {}
+        for k, spec in enumerate(os.environ["MODES"].split(",")):
+            nm, ln, win = spec.split(":")
+            modes["%s[lanes=%s,window=%s,max=%d]#%d" % (nm, ln, win, maxb, k)] = (int(ln), float(win))
     for name, (lanes, window) in modes.items():
         so = SessionOptions()
         so.lanes = lanes
         so.micro_batch_window_ms = window
-        so.micro_batch_max = 32
+        so.micro_batch_max = maxb
         sess = InferenceSession(blob, sess_options=so)
         for f in feeds[:4]:
             sess.run_pcm16(f)
