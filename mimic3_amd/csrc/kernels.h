@@ -24,6 +24,7 @@ struct ConvArgs {
     const int* in_len = nullptr;   // [B] valid length of the input (x * mask) or null
     const int* in_len_host = nullptr;  // kernels_rbc.cpp: the host's copy of in_len (launcher: counts the items with work; null: read back)
     int nvalid = 0;                // kernels_rbc.cpp: (row, column block) items with work, filled by the launcher (mrf_valid_items)
+    int rb_loop = 0;               // k_enc_b3: 64-row output blocks a workgroup walks over one staged slice (launcher: 3 on large grids)
     const int* out_len = nullptr;  // [B] valid length of the output (y * mask) or null
     int B = 1, Cin = 0, Cout = 0, T = 0, K = 1, dil = 1;
     int pad = -1;            // left zero padding; -1 = "same" ((K*dil - dil) / 2), filled in by Engine::conv

@@ -1300,23 +1300,29 @@ __global__ __launch_bounds__(256) void k_enc_b3(ConvArgs a) {
     if (!(LAB_ABLATE(a) & 2))
         stage_planes<NG, NG == 12 ? 8 : 4>(a.x + (long)b * a.x_bs + (long)c0 * a.x_ld, a.x_ld, LD, t0 - a.pad, tend, a.in_slope, planes, PS, tid, 256);
     __syncthreads();
-    const int rt = blockIdx.y * 2 + wm;  // 32-row tile of the output
-    if (32 * rt >= a.Cout) return;
-    f32x16 acc[1][1];
-    MI355_UNROLL
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+    // a.rb_loop row blocks of 64 output channels per workgroup, one after the other over the SAME staged slice (large grids, round 6:
+    // at batch 256 each of a conv's 3 - 12 row-block workgroups staged and split the slice again — 9.5 VALU per MFMA, MFMA pipe 0.31
+    // busy).  No barrier inside the loop; an output element's products and their order do not change: same bits as rb_loop = 1.
+    const int R = a.rb_loop > 1 ? a.rb_loop : 1;
     const int ngt = a.Cin / 16;
-    const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
-    if (!(LAB_ABLATE(a) & 1)) b3_chunk<1, 1, NG, 1, W1>(acc, wp, planes + brow * LD + bcol + wn * 32, PS, LD, a.K, ngt, a.dil);
     const int t = t0 + wn * 32 + bcol;
-    if (t >= a.T) return;
-    if (a.ksplit == 1) {
-        epi_std_tile(a, b, 32 * rt, t, brow, acc[0][0], out_len);
-    } else {
-        float* pp = a.part + (((long)sl * a.B + b) * a.Cout + 32 * rt) * a.T + t;
+    for (int rr = 0; rr < R; ++rr) {
+        const int rt = (blockIdx.y * R + rr) * 2 + wm;  // 32-row tile of the output
+        if (32 * rt >= a.Cout) break;
+        f32x16 acc[1][1];
         MI355_UNROLL
-        for (int r = 0; r < 16; ++r)
-            if (32 * rt + tile_row(r, brow) < a.Cout) pp[(long)tile_row(r, brow) * a.T] = acc[0][0][r];
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+        const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
+        if (!(LAB_ABLATE(a) & 1)) b3_chunk<1, 1, NG, 1, W1>(acc, wp, planes + brow * LD + bcol + wn * 32, PS, LD, a.K, ngt, a.dil);
+        if (t >= a.T) continue;
+        if (a.ksplit == 1) {
+            epi_std_tile(a, b, 32 * rt, t, brow, acc[0][0], out_len);
+        } else {
+            float* pp = a.part + (((long)sl * a.B + b) * a.Cout + 32 * rt) * a.T + t;
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r)
+                if (32 * rt + tile_row(r, brow) < a.Cout) pp[(long)tile_row(r, brow) * a.T] = acc[0][0][r];
+        }
     }
 }
 
@@ -1441,7 +1447,15 @@ void launch_enc_conv_b3(const ConvArgs& a_in, hipStream_t s) {
     a.ablate = ablate;
     const int LD = ENC_TB + (a.K - 1) * a.dil;
     const size_t shmem = (size_t)3 * ng * 2 * LD * 16;
-    dim3 grid((a.T + ENC_TB - 1) / ENC_TB, (a.Cout + 63) / 64, a.B * a.ksplit);
+    // large grids: several 64-row blocks per workgroup over one staged slice — the most that divides the conv's row blocks and still
+    // leaves the launch four workgroups per CU (batch 256: FFN conv_1 six of twelve, q/k/v and conv_2 three; profiles/r06_enc_row_loop_ab.txt)
+    const int nrb = (a.Cout + 63) / 64;
+    const long wgs = (long)((a.T + ENC_TB - 1) / ENC_TB) * nrb * a.B * a.ksplit;
+    a.rb_loop = 1;
+    for (int r : {6, 4, 3, 2})
+        if (nrb % r == 0 && wgs / r >= 4L * current_device_cu_count()) { a.rb_loop = r; break; }
+    if (const char* f = lab_getenv("MI355VITS_ENC_ROWLOOP")) a.rb_loop = atoi(f) > 1 && nrb % atoi(f) == 0 ? atoi(f) : 1;  // lab / tests
+    dim3 grid((a.T + ENC_TB - 1) / ENC_TB, (nrb + a.rb_loop - 1) / a.rb_loop, a.B * a.ksplit);
     auto go = [&](auto kfn) {
 #ifndef MI355_EMU
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
     };
     struct Cursor { int r, base, nv; };
     auto locate = [&](int v, Cursor& c) MI355_INLINE_LAMBDA {  // v < a.nvalid: the loop ends inside the batch
-        while (v >= c.base + c.nv) {
+        while (v >= c.base + c.nv && c.r + 1 < a.B) {  // (the row bound: a count that disagreed with the table must not walk off it)
             c.base += c.nv;
             ++c.r;
             const int ln = row_len(c.r);

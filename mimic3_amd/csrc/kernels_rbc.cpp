@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512) void k_rb_conv(ConvArgs a) {
     auto decode = [&](int it, Cursor& c) MI355_INLINE_LAMBDA {
         Item o;
         it = rbc_item(it, nitems, a.item_order);
-        while (it >= c.base + c.nv) {  // (it < a.nvalid: ends inside the batch)
+        while (it >= c.base + c.nv && c.r + 1 < a.B) {  // (it < a.nvalid: ends inside the batch; the row bound guards a stale count)
             c.base += c.nv;
             ++c.r;
             c.nv = row_nv(c.r);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(768) void k_rb_conv_pw(ConvArgs a) {
     auto decode = [&](int it, Cursor& c) MI355_INLINE_LAMBDA {
         Item o;
         it = rbc_item(it, nitems, a.item_order);
-        while (it >= c.base + c.nv) {  // (it < a.nvalid: ends inside the batch)
+        while (it >= c.base + c.nv && c.r + 1 < a.B) {  // (it < a.nvalid: ends inside the batch; the row bound guards a stale count)
             c.base += c.nv;
             ++c.r;
             c.nv = row_nv(c.r);

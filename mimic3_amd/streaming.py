@@ -137,7 +137,11 @@ def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1
 
         f0: Future = Future()
         try:
-            f0.set_result((list(session.run_pcm16(_feed(sentences[plan[0][0]], scales, sid), volume=volume, direct=True)[0]), None))
+            try:
+                r0 = session.run_pcm16(_feed(sentences[plan[0][0]], scales, sid), volume=volume, direct=True)
+            except TypeError:  # a session-like object without the `direct` extension
+                r0 = session.run_pcm16(_feed(sentences[plan[0][0]], scales, sid), volume=volume)
+            f0.set_result((list(r0[0]), None))
         except Exception as e:  # noqa: BLE001 - raised at the sentence's turn below
             f0.set_exception(e)
         futs = [(plan[0], f0)]

@@ -264,3 +264,26 @@ def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, m
     for tag in ("ring2", "ring4_again", "epi0", "epi1", "epi2", "tw"):
         for k in range(3):
             assert np.array_equal(res[tag][k], res["ring4"][k]), (tag, k)
+
+
+def test_encoder_row_block_loop_is_bitwise_the_one_block_form(lab_lib, monkeypatch):
+    """Round 6: on large grids k_enc_b3 walks three 64-row output blocks per workgroup over ONE staged 192-channel slice (the
+    launcher's choice; MI355VITS_ENC_ROWLOOP forces it in the lab build) instead of staging and splitting the slice once per row
+    block.  An output element's products and their order are the same: encoder output, prior statistics, duration-predictor state,
+    durations, z and the waveform BIT FOR BIT against the one-block form, ragged rows included (the flow's pointwise convs at frame
+    resolution run the same kernel)."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=33, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 140
+    ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (6, Tx))
+    lengths = [Tx, 65, 1, 129, 128, 77]
+    res = {}
+    for tag, env in (("one", "1"), ("loop", "3")):
+        monkeypatch.setenv("MI355VITS_ENC_ROWLOOP", env)
+        eng = Engine(blob, library=lab_lib, device=0)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], debug_taps=True, seed=13)
+        res[tag] = [eng.tap(k) for k in ("x", "stats", "dp.h", "w_ceil", "z_p", "z")] + [out["lengths"].copy(), out["audio"].copy()]
+        eng.close()
+    for k, (a, b) in enumerate(zip(res["one"], res["loop"])):
+        assert np.array_equal(a, b), k

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 TAG=${TAG:-r05}
-python -c "from mimic3_amd._native import default_library; print(default_library().probe_device())" > $O/${TAG}_probe.txt 2>&1; cat $O/${TAG}_probe.txt | tail -2
+python -c "from mimic3_amd._native import hooks_library; print(hooks_library().probe_device())" > $O/${TAG}_probe.txt 2>&1; cat $O/${TAG}_probe.txt | tail -2
 if [ -n "$TESTS" ]; then timeout ${TEST_TIMEOUT:-1200} python -m pytest $TESTS -q -m gpu -x > $O/${TAG}_pytest.log 2>&1; tail -4 $O/${TAG}_pytest.log; fi
 for v in $VARIANTS; do
   t=${v%%:*}; e=${v#*:}; e=${e//,/ }
