@@ -150,13 +150,14 @@ void pack_conv_weights_p16(const float* w, int Cout, int Cin, int K, uint32_t* o
 bool mrf_p_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
 // sum over the rows of ceil(min(len, T) / block): the (row, column block) items of a ragged batch that have work.  len_host = the
 // host's copy of the device array len (nullptr: copied back, a synchronising call — unit-test hooks only); len == nullptr: every row T
-int mrf_valid_items(const int* len_host, const int* len_dev, int B, int T, int block);
+// extra: positions a row has beyond its length (polyphase upsamplers: len input positions -> len + 1 output positions)
+int mrf_valid_items(const int* len_host, const int* len_dev, int B, int T, int block, int extra = 0);
 void launch_mrf_p(MrfArgs a, hipStream_t s);
 // The same stage, same bits, as a row sweep (kernels_mrfs.cpp): work item = (row, segment), one pass per resblock with the
 // waves specialised by conv, every conv's fragments in registers for the whole segment, no halo recompute; y accumulates the
 // resblocks in place.  mrf_s_segment: the segment length for a grid, 0 = the stage is too small for the sweep to pay.
 bool mrf_s_supported(int C, int nrb, const int* k, const int* d1, const int* d2);
-int mrf_s_segment(int C, int B, int T, int cus);
+int mrf_s_segment(int C, int B, int T, int cus, const int* len_host = nullptr);
 void launch_mrf_s(MrfArgs a, hipStream_t s);
 // One dense conv of a 128-channel ResBlock2 (HiFi-GAN stage 0) in MATH_BF16X3 with all input channels resident in LDS (kernels_rbc.cpp):
 // y (+)= (res + bias + conv(lrelu(x * mask))) * out_scale; a.w = pack_conv_weights_p16 fragments; K / dilation pairs of the "_low" voices.

@@ -597,7 +597,7 @@ inline bool shape_p(int C, int nrb, const int* k, const int* d1, const int* d2, 
 }
 }  // namespace
 
-int mrf_valid_items(const int* len_host, const int* len_dev, int B, int T, int block) {
+int mrf_valid_items(const int* len_host, const int* len_dev, int B, int T, int block, int extra) {
     if (B <= 0 || T <= 0 || block <= 0) return 0;
     const int full = (T + block - 1) / block;
     if (!len_dev) return B * full;
@@ -609,7 +609,7 @@ int mrf_valid_items(const int* len_host, const int* len_dev, int B, int T, int b
     }
     long n = 0;
     for (int b = 0; b < B; ++b) {
-        const int ln = len_host[b] > T ? T : len_host[b];
+        const int ln = len_host[b] <= 0 ? 0 : (len_host[b] + extra > T ? T : len_host[b] + extra);
         if (ln > 0) n += (ln + block - 1) / block;
     }
     return (int)n;

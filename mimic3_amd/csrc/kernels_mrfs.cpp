@@ -453,7 +453,7 @@ bool mrf_s_supported(int C, int nrb, const int* k, const int* d1, const int* d2)
 // Segment length for a grid: the sweep pays (r1 + r2) columns + three to five iterations of pipeline fill per (segment,
 // resblock), so segments should be long; the chip wants at least one item per CU and an even number of them per CU.
 // Returns 0 when the stage is too small for the sweep to pay (the caller runs k_mrf_p: same bits).
-int mrf_s_segment(int C, int B, int T, int cus) {
+int mrf_s_segment(int C, int B, int T, int cus, const int* len_host) {
     // measured on the MI355X at the bench shape (profiles/r04_mrf_sweep.txt): 64 channels 2.42 -> 2.1 ms per launch; 32 channels
     // 2.36 -> 3.1 ms (half the matrix work per tile and per byte of y / x traffic: the three passes' 4 x HBM bytes and the
     // per-tile costs outweigh what the sweep saves there) — the 32-channel stage stays on k_mrf_p
@@ -461,8 +461,18 @@ int mrf_s_segment(int C, int B, int T, int cus) {
     if ((long)C * T * 4 >= 0x7fffffffL) return 0;  // a row's bytes must fit the buffer range (32-bit lane offsets): k_mrf_p otherwise
     const int TS = 16 * MRFS_NT * (4 / (C / 16));
     const int min_blocks = 24;  // fill of <= 5 iterations: <= 20 % even at the shortest segment
-    const long total_blocks = (long)B * ((T + TS - 1) / TS);
+    // ragged batches (round 6): a row's segments past its length are not computed, so the segment length follows the blocks that
+    // HAVE work — len_host = the host's copy of the rows' lengths (nullptr: every row T)
+    std::vector<int> rb((size_t)B);
+    long total_blocks = 0;
+    for (int b = 0; b < B; ++b) {
+        const int ln = len_host ? (len_host[b] > T ? T : (len_host[b] < 0 ? 0 : len_host[b])) : T;
+        rb[(size_t)b] = (ln + TS - 1) / TS;
+        total_blocks += rb[(size_t)b];
+    }
     if (total_blocks < (long)cus * min_blocks) return 0;
+    bool uniform = true;
+    for (int b = 0; b < B; ++b) uniform = uniform && rb[(size_t)b] == (T + TS - 1) / TS;
     // segments per row: the count that keeps the chip busiest — items / (rounds x CUs) of the persistent loop — times the
     // share of a sweep that is not pipeline fill (N of N + 5 iterations); ties go to the fewer, longer segments
     const int row_blocks = (T + TS - 1) / TS;
@@ -470,10 +480,13 @@ int mrf_s_segment(int C, int B, int T, int cus) {
     double best = 0.0;
     for (int pr = 1; pr <= 4 * cus && row_blocks / pr >= min_blocks; ++pr) {
         const int n = (row_blocks + pr - 1) / pr;  // blocks per segment
-        const int segs = (row_blocks + n - 1) / n;
-        const long items = (long)B * segs;
+        long items = 0;
+        for (int b = 0; b < B; ++b) items += (rb[(size_t)b] + n - 1) / n;
         const long rounds = (items + cus - 1) / cus;
-        const double eff = (double)items / (double)(rounds * cus) * (double)n / (double)(n + 5);
+        // uniform rows: round 4's measure (fill of the persistent rounds x share of a sweep that is not pipeline fill); ragged rows:
+        // the chip's work (blocks with work, spread evenly) over what the busiest CU does (its rounds of n + 5 iterations)
+        const double eff = uniform ? (double)items / (double)(rounds * cus) * (double)n / (double)(n + 5)
+                                   : ((double)total_blocks / (double)cus) / ((double)rounds * (double)(n + 5));
         if (eff > best + 1e-9) {
             best = eff;
             best_pr = pr;

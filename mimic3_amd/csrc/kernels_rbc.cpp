@@ -734,8 +734,9 @@ __global__ __launch_bounds__(512) void k_ups_pl(ConvArgs a) {
         lq[p] = (unsigned)p * PS16 + (unsigned)(q * LDP + n) * 16u;
         OPAQUE_V(lq[p]);
     }
-    const int nblk = (a.T + N - 1) / N;  // a.T = output positions = Tin + 1
-    const int nitems = nblk * a.B;
+    // work items = the (row, block of N output positions) pairs that have work: row b holds ceil((len_b + 1) / N) of them (a.T = Tin + 1
+    // positions for a full row); a.nvalid of them, numbered row by row, decoded with a forward-only cursor (ragged batches: k_rb_conv)
+    const int nitems = a.nvalid;
     const unsigned xrow = 4u * (unsigned)a.x_ld;
 
     struct Item { int b, t0, len, last; };
@@ -747,11 +748,25 @@ __global__ __launch_bounds__(512) void k_ups_pl(ConvArgs a) {
         return ((cptr_t)(a.in_len))[b];
 #endif
     };
-    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+    struct Cursor { int r, base, nv; };
+    auto row_nv = [&](int b) MI355_INLINE_LAMBDA {
+        int len = row_len(b);
+        if (len > a.Tin) len = a.Tin;
+        return len > 0 ? (len + 1 + N - 1) / N : 0;
+    };
+    auto decode = [&](int it, Cursor& c) MI355_INLINE_LAMBDA {
         Item o;
         it = rbc_item(it, nitems, a.item_order);
-        o.b = WAVE_UNIFORM(it / nblk);
-        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * N);
+        while (it >= c.base + c.nv && c.r + 1 < a.B) {
+            c.base += c.nv;
+            ++c.r;
+            c.nv = row_nv(c.r);
+        }
+        c.r = WAVE_UNIFORM(c.r);
+        c.base = WAVE_UNIFORM(c.base);
+        c.nv = WAVE_UNIFORM(c.nv);
+        o.b = c.r;
+        o.t0 = WAVE_UNIFORM((it - c.base) * N);
         int len = row_len(o.b);
         if (len > a.Tin) len = a.Tin;
         o.len = len;
@@ -811,10 +826,14 @@ __global__ __launch_bounds__(512) void k_ups_pl(ConvArgs a) {
     };
 
     if ((int)blockIdx.x >= nitems) return;
+    Cursor cur;
+    cur.r = 0;
+    cur.base = 0;
+    cur.nv = row_nv(0);
     float sv[ROUNDS][8];  // the half being staged: loaded one phase ahead of its stores
     {
         // prologue: half 0 of the first item (loaded and stored), the loads of its half 1, the first steps' weight fragments
-        const Item im = decode(blockIdx.x);
+        const Item im = decode(blockIdx.x, cur);
         const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
         MI355_UNROLL
         for (int r = 0; r < ROUNDS; ++r) stage_load(im, xb, 0, r, sv[r]);
@@ -836,9 +855,9 @@ __global__ __launch_bounds__(512) void k_ups_pl(ConvArgs a) {
 
     MI355_NOUNROLL
     for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const Item im = decode(it);
+        const Item im = decode(it, cur);
         const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;
-        const Item imn = decode(itn);
+        const Item imn = decode(itn, cur);
         const BufRsrc xbn = buf_rsrc(a.x + (long)imn.b * a.x_bs);
         const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
         f32x4 acc[NCT];
@@ -983,8 +1002,7 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, mt = WAVE_UNIFORM(tid >> 6);
     const int q = lane >> 4, n = lane & 15;
     const BufRsrc wbuf = buf_rsrc(a.w);
-    const int nblk = (a.T + NPOS - 1) / NPOS;
-    const int nitems = nblk * a.B;
+    const int nitems = a.nvalid;  // (row, block of NPOS positions) pairs with work, numbered row by row (k_ups_pl has the argument)
     const unsigned xrow = 4u * (unsigned)a.x_ld;
     if ((int)blockIdx.x >= nitems) return;
 
@@ -997,18 +1015,31 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
         return ((cptr_t)(a.in_len))[b];
 #endif
     };
-    auto decode = [&](int it) MI355_INLINE_LAMBDA {
+    struct Cursor { int r, base, nv; };
+    auto row_nv = [&](int b) MI355_INLINE_LAMBDA {
+        int len = row_len(b);
+        if (len > a.Tin) len = a.Tin;
+        return len > 0 ? (len + 1 + NPOS - 1) / NPOS : 0;
+    };
+    auto decode = [&](int it, Cursor& c) MI355_INLINE_LAMBDA {
         Item o;
         it = rbc_item(it, nitems, a.item_order);
-        o.b = WAVE_UNIFORM(it / nblk);
-        o.t0 = WAVE_UNIFORM((it - o.b * nblk) * NPOS);
+        while (it >= c.base + c.nv && c.r + 1 < a.B) {
+            c.base += c.nv;
+            ++c.r;
+            c.nv = row_nv(c.r);
+        }
+        c.r = WAVE_UNIFORM(c.r);
+        c.base = WAVE_UNIFORM(c.base);
+        c.nv = WAVE_UNIFORM(c.nv);
+        o.b = c.r;
+        o.t0 = WAVE_UNIFORM((it - c.base) * NPOS);
         int len = row_len(o.b);
         if (len > a.Tin) len = a.Tin;
         o.len = len;
         o.last = o.len > 0 ? o.len - 1 : 0;
         return o;
     };
-    auto clampi = [&](int it) MI355_INLINE_LAMBDA { return it < nitems ? it : nitems - 1; };  // (past the last item: it again, unread)
     auto stage_load = [&](const Item& im, int round, float (&sv)[8]) MI355_INLINE_LAMBDA {
         const BufRsrc xb = buf_rsrc(a.x + (long)im.b * a.x_bs);
         int t2 = tid;
@@ -1063,8 +1094,14 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
 
     // prologue: the first item's planes into buffer 0, the second item's loads in flight
     float sv[ROUNDS][8];
+    Cursor csr;
+    csr.r = 0;
+    csr.base = 0;
+    csr.nv = row_nv(0);
+    // the item being computed, the one staged into the other buffer and the one whose loads are in flight: decoded ONCE each, in the
+    // order the workgroup meets them (the cursor only moves forward); past the last item: the previous one again, unread
+    Item im = decode(blockIdx.x, csr), im1 = im;
     {
-        const Item im = decode(blockIdx.x);
         MI355_UNROLL
         for (int r = 0; r < ROUNDS; ++r) stage_load(im, r, sv[r]);
         SCHED_FENCE();
@@ -1075,7 +1112,7 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
             MI355_UNROLL
             for (int pc = 0; pc < 4; ++pc) stage_piece(pc, sv[r], ph, sp);
         }
-        const Item im1 = decode(clampi(blockIdx.x + gridDim.x));
+        if ((int)(blockIdx.x + gridDim.x) < nitems) im1 = decode((int)(blockIdx.x + gridDim.x), csr);
         MI355_UNROLL
         for (int r = 0; r < ROUNDS; ++r) stage_load(im1, r, sv[r]);
     }
@@ -1084,8 +1121,8 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
     unsigned cur = 0;  // byte offset of the buffer this item computes from
     MI355_NOUNROLL
     for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const Item im = decode(it);
-        const Item im1 = decode(clampi(it + (int)gridDim.x)), im2 = decode(clampi(it + 2 * (int)gridDim.x));
+        Item im2 = im1;
+        if (it + 2 * (int)gridDim.x < nitems) im2 = decode(it + 2 * (int)gridDim.x, csr);
         const BufRsrc ybuf = buf_rsrc(a.y + (long)im.b * a.y_bs);
         const unsigned other = cur == 0u ? BUF : 0u;  // the buffer item i + 1 is staged into
         const bool edge = im.t0 == 0 || 4 * (im.t0 + NPOS) + 1 >= a.shuf_T;  // position 0 or the row's last position belongs to this item
@@ -1180,6 +1217,8 @@ __global__ __launch_bounds__(512) void k_ups64(ConvArgs a) {
         });
         __syncthreads();
         cur = other;
+        im = im1;
+        im1 = im2;
     }
 }
 
@@ -1356,7 +1395,9 @@ void launch_ups_pl(ConvArgs a, hipStream_t s) {
     a.item_order = RBC_ITEM_ORDER;
     if (const char* f = lab_getenv("MI355VITS_RBC_ITEM_ORDER")) a.item_order = atoi(f);  // lab / tests: 0 = items w, w + W, ... as in round 4
     auto go = [&](auto kfn, size_t lds, int ncols) {
-        const long nitems = (long)((a.T + ncols - 1) / ncols) * a.B;
+        a.nvalid = mrf_valid_items(a.in_len_host, a.in_len, a.B, a.T, ncols, 1);  // a row of len input positions has len + 1 output positions
+        const long nitems = a.nvalid;
+        if (nitems <= 0) return;
         dim3 grid((unsigned)(nitems < cus ? nitems : cus));
         set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), (int)RBC_LDS_LIMIT);
         LAUNCH_KERNEL(kfn, grid, dim3(512), lds, s, a);

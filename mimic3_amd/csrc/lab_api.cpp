@@ -131,7 +131,7 @@ int mi355vits_test_conv_transpose1d(int device, int impl, int B, int Cin, int Co
             ConvArgs u;
             u.x = dx.as<float>(); u.x_bs = (long)Cin * Tin; u.x_ld = Tin;
             u.y = dy.as<float>(); u.y_bs = (long)Cout * Tin * stride; u.y_ld = Tin * stride;
-            u.w = dpp.as<float>(); u.bias = dbias.as<float>(); u.in_len = dlen.as<int>();
+            u.w = dpp.as<float>(); u.bias = dbias.as<float>(); u.in_len = dlen.as<int>(); u.in_len_host = lens.data();
             u.Cin = Cin; u.Cout = stride * Cout; u.K = taps; u.dil = 1;
             u.in_slope = in_slope; u.pad = taps - 1; u.Tin = Tin;
             u.shuf_s = stride; u.shuf_p = (K - stride) / 2; u.shuf_cout = Cout; u.shuf_T = Tin * stride;

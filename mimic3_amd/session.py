@@ -379,14 +379,21 @@ class _MicroBatcher:
                     self._run_counted(group)
 
     def _run_counted(self, group):
-        try:
-            self._run_group(group)
-        finally:
-            with self._inflight_cv:
-                self._inflight -= 1
-                self._inflight_cv.notify_all()
+        released = [False]
 
-    def _run_group(self, group):
+        def lane_done():  # the batch's lane is free again: the dispatcher may hand out the next batch
+            if not released[0]:
+                released[0] = True
+                with self._inflight_cv:
+                    self._inflight -= 1
+                    self._inflight_cv.notify_all()
+
+        try:
+            self._run_group(group, lane_done)
+        finally:
+            lane_done()
+
+    def _run_group(self, group, lane_done=None):
         try:
             tx = max(int(g[0].shape[1]) for g in group)
             B = len(group)
@@ -402,7 +409,8 @@ class _MicroBatcher:
             if session is None:
                 raise RuntimeError("session closed")
             out = session._engine_run(ids, lens, group[0][2], sid, **kw)
-            del session
+            del session  # (the batch stays "in flight" through the slicing below: handing the next batch out earlier was measured —
+            # 19.1k -> 16.9k x real time at 64 clients, the batches shrink from 15.5 to 12.2: profiles/r06_serve_policies.txt)
             with self._count_lock:
                 self.batches += 1
                 self.requests += B
@@ -419,7 +427,7 @@ class _MicroBatcher:
                 # a bad request must not poison its batch-mates: fall back to one call per request
                 for g in group:
                     if not g[5].done():
-                        self._run_group([g])
+                        self._run_group([g], None)
                 return
             for g in group:  # every waiter gets its error; nobody hangs
                 if not g[5].done():
