@@ -1256,7 +1256,7 @@ void Engine::flow_and_decoder(int B, int Ty, const mi355vits_run_args& args) {
                     // 64 channels: one pass per resblock (k_mrf_s).  32 channels: k_mrf_p (its single-pass sweep, k_mrf_s1, measured equal in
                     // round 4 — 2.33 vs 2.34 ms, 2.37 vs 2.36 with 48-column steps — and was deleted in round 5: DESIGN.md §6)
                     bool sw_ok = ch != 32 && mrf_s_supported(ch, nk, m.k, m.d1, m.d2);
-                    int seg = !sw_ok ? 0 : mrf_s_segment(ch, B, (int)T, current_device_cu_count(), m.len_host);
+                    int seg = !sw_ok ? 0 : mrf_s_segment(ch, B, (int)T, current_device_cu_count(), lab_getenv("MI355VITS_MRFS_UNIFORM_SEG") ? nullptr : m.len_host);
                     if (const char* f = lab_getenv("MI355VITS_MRF_SWEEP_SEG")) seg = sw_ok ? atoi(f) : 0;  // lab / tests
                     if (seg > 0) {
                         m.seg = seg;

@@ -107,13 +107,16 @@ def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1
 
     A failing sentence: its batch is retried row by row, the error surfaces at that sentence's turn, later ones are not
     delivered."""
-    sentences = [list(s) for s in sentences]
-    plan = plan_batches([len(s) for s in sentences], head=head, max_batch=max_batch)
-    if not plan:
+    sentences = list(sentences)  # (shallow: the rows are read when their batch's feed is built)
+    if not sentences:
         return
     pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="mi355vits-plan")
     done: Dict[int, object] = {}
     valid = computed = tvalid = tcomputed = 0
+
+    def prepare():
+        lens = [len(s) for s in sentences]
+        return plan_batches(lens, head=head, max_batch=max_batch), lens
 
     def run_batch(idx):
         try:
@@ -131,21 +134,25 @@ def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1
             return out, None
 
     if first_alone:
-        # sentence 0 in the caller's own thread, straight onto a lane: no pool hand-over, no micro-batcher queue in front of the audio
-        # the listener is waiting for (bench.py longform: 3.4 -> 2.x ms to the first chunk)
+        # sentence 0 in the caller's own thread, straight onto a lane: no pool hand-over, no micro-batcher queue, and the plan of the
+        # rest is made on a pool thread WHILE it runs (the engine call releases the GIL) — nothing but the call itself stands between
+        # the request and the audio the listener is waiting for
         from concurrent.futures import Future
 
+        prep = pool.submit(prepare)
         f0: Future = Future()
         try:
             try:
-                r0 = session.run_pcm16(_feed(sentences[plan[0][0]], scales, sid), volume=volume, direct=True)
+                r0 = session.run_pcm16(_feed(sentences[0], scales, sid), volume=volume, direct=True)
             except TypeError:  # a session-like object without the `direct` extension
-                r0 = session.run_pcm16(_feed(sentences[plan[0][0]], scales, sid), volume=volume)
+                r0 = session.run_pcm16(_feed(sentences[0], scales, sid), volume=volume)
             f0.set_result((list(r0[0]), None))
         except Exception as e:  # noqa: BLE001 - raised at the sentence's turn below
             f0.set_exception(e)
+        plan, lens = prep.result()
         futs = [(plan[0], f0)]
     else:
+        plan, lens = prepare()
         futs = [(idx, pool.submit(run_batch, idx)) for idx in plan]
     try:
         nxt = 0
@@ -159,8 +166,8 @@ def stream_planned(session, sentences: Sequence[Sequence[int]], scales=(0.667, 1
             if lengths is not None:
                 valid += int(np.sum(lengths))
                 computed += int(np.max(lengths)) * len(idx)
-                tvalid += sum(len(sentences[i]) for i in idx)
-                tcomputed += max(len(sentences[i]) for i in idx) * len(idx)
+                tvalid += sum(lens[i] for i in idx)
+                tcomputed += max(lens[i] for i in idx) * len(idx)
             for i, r in zip(idx, rows):
                 done[i] = r
             while nxt in done:
