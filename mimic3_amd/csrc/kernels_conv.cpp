@@ -1326,6 +1326,103 @@ __global__ __launch_bounds__(256) void k_enc_b3(ConvArgs a) {
     }
 }
 
+// epi_std_tile for full 32-row tiles (Cout % 32 == 0) with buffer addressing: a row's byte offset rides in an SGPR (wave-uniform:
+// tile base + the accumulator row's part), the lane's part (its column and brow) in ONE VGPR, lanes past the row's columns are
+// switched off by the buffer range check — no 64-bit address arithmetic, no divergent branch around a tile.  Operation for operation
+// the arithmetic of epi_std_tile (a.cond / a.shuf_s not supported: callers check).
+__device__ __forceinline__ void epi_std_tile_buf(const ConvArgs& a, int b, int co0, int t, bool t_ok, int brow, const f32x16& acc, int out_len) {
+    const BufRsrc yb = buf_rsrc(a.y + (long)b * a.y_bs);
+    const unsigned vy = t_ok ? 4u * (unsigned)(t + 4 * brow * a.y_ld) : BUF_OOB;
+    float v[16], rv[16], yv[16];
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    if (a.bias) {
+        const BufRsrc bb = buf_rsrc(a.bias);
+        float bv[16];
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) bv[r] = buf_load_f32(bb, 16u * (unsigned)brow, 4u * (unsigned)(co0 + (r & 3) + 8 * (r >> 2)));
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) v[r] += bv[r];
+    }
+    if (a.res) {
+        const BufRsrc rb = buf_rsrc(a.res + (long)b * a.res_bs);
+        const unsigned vr = t_ok ? 4u * (unsigned)(t + 4 * brow * a.res_ld) : BUF_OOB;
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) rv[r] = buf_load_f32(rb, vr, 4u * (unsigned)((co0 + (r & 3) + 8 * (r >> 2)) * a.res_ld));
+    }
+    if (a.accumulate) {
+        MI355_UNROLL
+        for (int r = 0; r < 16; ++r) yv[r] = buf_load_f32(yb, vy, 4u * (unsigned)((co0 + (r & 3) + 8 * (r >> 2)) * a.y_ld));
+    }
+    MI355_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        float q = v[r];
+        if (a.relu) q = fmaxf(q, 0.0f);
+        if (a.mask_before_res && t >= out_len) q = 0.0f;
+        if (a.res) q = a.res_sub ? rv[r] - q : rv[r] + q;
+        q *= a.out_scale;
+        if (!a.mask_before_res && t >= out_len) q = 0.0f;
+        if (a.accumulate) q += yv[r];
+        buf_store_f32(yb, vy, 4u * (unsigned)((co0 + (r & 3) + 8 * (r >> 2)) * a.y_ld), q);
+    }
+}
+
+// k_enc_b3 for LARGE grids (round 6; batch 256: 32,768 phoneme columns, and the flow's pointwise convs at frame resolution).  The
+// 64 x 64 form above streams every weight fragment through the L1 for ONE 32-column tile (and twice: its two column-tile waves load
+// the same rows): 8 waves x 3 KiB per 192 MFMA cycles = 128 B per clock against the L1's 64 — the matrix pipe cannot pass 0.5
+// (measured 0.31 - 0.35 busy).  Here a workgroup owns 32 NCT columns (128) x NW 32-row tiles: the slice of those columns is staged
+// once (150 KiB at 192 channels), wave w streams row tile w's fragments — nobody else's — and every fragment feeds NCT column tiles
+// (24 MFMAs = 768 cycles per 3 KiB: 32 B per clock and CU with eight waves); a.rb_loop row blocks of NW tiles one after the other.
+// b3_chunk walks k-groups and taps in the same order for every accumulator: an output element has the bits of the 64 x 64 form.
+template <bool W1, int NG, int NCT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_enc_b3w(ConvArgs a) {
+    DYN_SMEM(float, smem);
+    uint4* planes = reinterpret_cast<uint4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
+    const int brow = lane >> 5, bcol = lane & 31;
+    const int b = blockIdx.z / a.ksplit, sl = blockIdx.z - b * a.ksplit;
+    const int t0 = blockIdx.x * (32 * NCT);
+    const int c0 = sl * 16 * NG;
+    int tend = a.in_len ? a.in_len[b] : a.T;
+    if (tend > a.T) tend = a.T;
+    const int out_len = a.out_len ? a.out_len[b] : a.T;
+    const int LD = 32 * NCT + (a.K - 1) * a.dil;
+    const int PS = NG * 2 * LD;
+    if (!(LAB_ABLATE(a) & 2))
+        stage_planes<NG, NG == 12 ? 8 : 4>(a.x + (long)b * a.x_bs + (long)c0 * a.x_ld, a.x_ld, LD, t0 - a.pad, tend, a.in_slope, planes, PS, tid, 64 * NW);
+    __syncthreads();
+    const int R = a.rb_loop > 1 ? a.rb_loop : 1;
+    const int ngt = a.Cin / 16;
+    for (int rr = 0; rr < R; ++rr) {
+        const int rt = (blockIdx.y * R + rr) * NW + wid;  // 32-row tile of the output
+        if (32 * rt >= a.Cout) break;
+        f32x16 acc[1][NCT];
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j)
+            MI355_UNROLL
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
+        const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
+        if (!(LAB_ABLATE(a) & 1)) b3_chunk_lean<1, NCT, NG, W1>(acc, wp, planes + brow * LD + bcol, PS, LD, a.K, ngt, a.dil);  // (B fragments single-buffered: the double-buffered loop spills at four column tiles)
+        // (lane coordinates made opaque here: the epilogue's 4 x 16 row addresses are loop-invariant, and hoisted in front of the row-block
+        // loop they spill — 544 bytes of scratch and a drain per reload)
+        int bcol_e = bcol, brow_e = brow;
+        OPAQUE_V(bcol_e);
+        OPAQUE_V(brow_e);
+        MI355_UNROLL
+        for (int j = 0; j < NCT; ++j) {
+            const int t = t0 + 32 * j + bcol_e;
+            if (a.ksplit == 1) {
+                epi_std_tile_buf(a, b, 32 * rt, t, t < a.T, brow_e, acc[0][j], out_len);
+            } else {  // a slice's raw sums (the following LayerNorm launch adds the slices up)
+                const BufRsrc pb = buf_rsrc(a.part + (((long)sl * a.B + b) * a.Cout + 32 * rt) * a.T);
+                const unsigned vp = t < a.T ? 4u * (unsigned)(t + 4 * brow_e * a.T) : BUF_OOB;
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) buf_store_f32(pb, vp, 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * a.T), acc[0][j][r]);
+            }
+        }
+    }
+}
+
 // The attention block's tail in one launch:  y = LN_c(res + conv1x1(x) + bias)   (o-proj + residual + LayerNorm; 192 channels).
 // A workgroup owns 32 columns of ALL 192 output rows (six waves = six 32-row tiles over the one 192-channel slice, staged once as
 // planes like k_enc_b3), so the LayerNorm's channel statistics never leave the CU: the conv result (+ bias + residual) goes through
@@ -1445,9 +1542,43 @@ void launch_enc_conv_b3(const ConvArgs& a_in, hipStream_t s) {
     if (a.ksplit > 1 && !a.part) throw std::runtime_error("enc_conv_b3: split conv without a partial-sum buffer");
     static const int ablate = lab_getenv("MI355VITS_CONV_ABLATE") ? atoi(lab_getenv("MI355VITS_CONV_ABLATE")) : 0;
     a.ablate = ablate;
+    // large grids: the 128-column form (k_enc_b3w) when it still gives every CU a workgroup: one staged slice per 128 columns, every
+    // row tile's fragments streamed by ONE wave and used for four column tiles; all of the conv's row blocks in one workgroup
+    {
+        constexpr int NCT = 4;
+        const int nrt = (a.Cout + 31) / 32;
+        const int nw = nrt % 8 == 0 ? 8 : (nrt % 6 == 0 ? 6 : 8);
+        const int nblk = (nrt + nw - 1) / nw;
+        const long wgs_w = (long)((a.T + 32 * NCT - 1) / (32 * NCT)) * a.B * a.ksplit;  // (with every row block inside the workgroup)
+        // (the buffer-addressed epilogue: whole 32-row tiles; fewer than six row tiles — the couplings' 192 -> 96 post conv — leave most of
+        // the workgroup's waves without work: +21 % measured, profiles/r06_enc_wide_ab.txt)
+        bool wide = wgs_w >= current_device_cu_count() && a.Cout % 32 == 0 && !a.cond && nrt >= 6;
+        if (const char* f = lab_getenv("MI355VITS_ENC_WIDE")) wide = atoi(f) != 0 && a.Cout % 32 == 0 && !a.cond && (nrt >= 6 || atoi(f) > 1);  // lab / tests (2: also below six row tiles)
+        if (wide) {
+            a.rb_loop = nblk;
+            const int LDw = 32 * NCT + (a.K - 1) * a.dil;
+            const size_t shw = (size_t)3 * ng * 2 * LDw * 16;
+            dim3 gridw((a.T + 32 * NCT - 1) / (32 * NCT), 1, a.B * a.ksplit);
+            auto gow = [&](auto kfn, int threads) {
+#ifndef MI355_EMU
+                set_max_dynamic_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);
+#endif
+                LAUNCH_KERNEL(kfn, gridw, dim3(threads), shw, s, a);
+            };
+            const bool w1 = a.math == MATH_BF16W;
+            if (ng == ENC_NG) {
+                if (nw == 8) { if (w1) gow(k_enc_b3w<true, ENC_NG, NCT, 8>, 512); else gow(k_enc_b3w<false, ENC_NG, NCT, 8>, 512); }
+                else { if (w1) gow(k_enc_b3w<true, ENC_NG, NCT, 6>, 384); else gow(k_enc_b3w<false, ENC_NG, NCT, 6>, 384); }
+            } else {
+                if (nw == 8) { if (w1) gow(k_enc_b3w<true, ENC_NG / 2, NCT, 8>, 512); else gow(k_enc_b3w<false, ENC_NG / 2, NCT, 8>, 512); }
+                else { if (w1) gow(k_enc_b3w<true, ENC_NG / 2, NCT, 6>, 384); else gow(k_enc_b3w<false, ENC_NG / 2, NCT, 6>, 384); }
+            }
+            return;
+        }
+    }
     const int LD = ENC_TB + (a.K - 1) * a.dil;
     const size_t shmem = (size_t)3 * ng * 2 * LD * 16;
-    // large grids: several 64-row blocks per workgroup over one staged slice — the most that divides the conv's row blocks and still
+    // otherwise, on grids that are still large: several 64-row blocks per workgroup over one staged slice — the most that divides the conv's row blocks and still
     // leaves the launch four workgroups per CU (batch 256: FFN conv_1 six of twelve, q/k/v and conv_2 three; profiles/r06_enc_row_loop_ab.txt)
     const int nrb = (a.Cout + 63) / 64;
     const long wgs = (long)((a.T + ENC_TB - 1) / ENC_TB) * nrb * a.B * a.ksplit;

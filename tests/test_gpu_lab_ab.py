@@ -279,6 +279,7 @@ def test_encoder_row_block_loop_is_bitwise_the_one_block_form(lab_lib, monkeypat
     ids = np.random.default_rng(5).integers(1, cfg.num_symbols, (6, Tx))
     lengths = [Tx, 65, 1, 129, 128, 77]
     res = {}
+    monkeypatch.setenv("MI355VITS_ENC_WIDE", "0")  # (the 64 x 64 form on both sides; the 128-column form has its own test below)
     for tag, env in (("one", "1"), ("loop", "3")):
         monkeypatch.setenv("MI355VITS_ENC_ROWLOOP", env)
         eng = Engine(blob, library=lab_lib, device=0)
@@ -286,4 +287,28 @@ def test_encoder_row_block_loop_is_bitwise_the_one_block_form(lab_lib, monkeypat
         res[tag] = [eng.tap(k) for k in ("x", "stats", "dp.h", "w_ceil", "z_p", "z")] + [out["lengths"].copy(), out["audio"].copy()]
         eng.close()
     for k, (a, b) in enumerate(zip(res["one"], res["loop"])):
+        assert np.array_equal(a, b), k
+
+
+def test_encoder_128_column_form_is_bitwise_the_64_column_form(lab_lib, monkeypatch):
+    """Round 6: on grids that give every CU a workgroup the encoder's dense convs (and the flow's pointwise convs at frame resolution)
+    run k_enc_b3w — 128 columns x all of the conv's 32-row tiles per workgroup, a row tile's weight fragments streamed by ONE wave and
+    used for four column tiles, buffer-addressed epilogue — instead of 64 x 64 tiles (MI355VITS_ENC_WIDE forces either in the lab
+    build).  b3_chunk / b3_chunk_lean walk k-groups and taps in the same order per accumulator and the epilogue is operation for
+    operation the same: every text-side tap, the durations, z and the waveform BIT FOR BIT, ragged rows included."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=34, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    Tx = 150
+    ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (6, Tx))
+    lengths = [Tx, 65, 1, 129, 128, 77]
+    res = {}
+    for tag, env in (("narrow", "0"), ("wide", "1")):
+        monkeypatch.setenv("MI355VITS_ENC_WIDE", env)
+        eng = Engine(blob, library=lab_lib, device=0)
+        eng.profile_enable(True)
+        out = eng.run(ids, lengths, [0.667, 1.0, 0.8], debug_taps=True, seed=14)
+        res[tag] = [eng.tap(k) for k in ("x", "stats", "dp.h", "w_ceil", "z_p", "z")] + [out["lengths"].copy(), out["audio"].copy()]
+        eng.close()
+    for k, (a, b) in enumerate(zip(res["narrow"], res["wide"])):
         assert np.array_equal(a, b), k
