@@ -386,7 +386,12 @@ void launch_rel_attention_mfma(const float* qkv, const float* emb_rel_k, const f
     if (!one_wave) {
         const size_t sh4 = (32 * 32 + 2 * 4 * 32 + 4 * 16 * 64) * sizeof(float);
         static const bool no_pre = lab_getenv("MI355VITS_ATTN_NO_PREFETCH") != nullptr;
-        const bool pre = H / n_heads == 96 && !no_pre;  // the "_low" / default voices' head: all operands prefetched
+        // the "_low" / default voices' head: all operands prefetched up front (one L2 wait per workgroup: latency, 256 registers, two
+        // workgroups per CU) — on grids of >= 4 workgroups per CU the 76-register form runs six workgroups per CU instead and hides its
+        // round trips behind them: 1.01 -> 0.55 ms per step at batch 256, 0.152 -> 0.181 at batch 32 (profiles/r06_attention_ab.txt).
+        // The MFMA sequence per output is the same: identical bits, so the choice may follow the grid.
+        const bool big = (long)grid.x * grid.y * grid.z >= 4L * current_device_cu_count();
+        const bool pre = H / n_heads == 96 && !no_pre && (!big || lab_getenv("MI355VITS_ATTN_PREFETCH"));
         if (T <= 128 && pre) {
             auto k = k_rel_attention_mfma4<1, 48>;
             LAUNCH_KERNEL(k, grid, dim3(256), sh4, s, qkv, emb_rel_k, emb_rel_v, len, T, H, n_heads, window, out);

@@ -312,3 +312,27 @@ def test_encoder_128_column_form_is_bitwise_the_64_column_form(lab_lib, monkeypa
         eng.close()
     for k, (a, b) in enumerate(zip(res["narrow"], res["wide"])):
         assert np.array_equal(a, b), k
+
+
+def test_attention_high_occupancy_form_is_bitwise_the_prefetched_form(lab_lib, monkeypatch):
+    """Round 6: on grids of >= 4 workgroups per CU the rel-pos attention runs its 76-register form (six workgroups per CU, operands
+    fetched trip by trip) instead of the one that prefetches every operand up front (256 registers, built for batch-1 latency).  The
+    MFMA sequence per output is the same: encoder output, prior statistics, durations and the waveform BIT FOR BIT, ragged rows,
+    T <= 128 and T <= 256."""
+    cfg = VitsConfig.apope_low()
+    w = W.synthetic_weights(cfg, seed=35, frames_per_id=1.0)
+    blob = W.pack(cfg, w)
+    for Tx, lengths in ((120, [120, 65, 1, 119]), (200, [200, 129, 130, 7])):
+        ids = np.random.default_rng(7).integers(1, cfg.num_symbols, (4, Tx))
+        res = {}
+        for tag in ("prefetch", "trips"):
+            if tag == "trips":
+                monkeypatch.setenv("MI355VITS_ATTN_NO_PREFETCH", "1")
+            else:
+                monkeypatch.delenv("MI355VITS_ATTN_NO_PREFETCH", raising=False)
+            eng = Engine(blob, library=lab_lib, device=0)
+            out = eng.run(ids, lengths, [0.667, 1.0, 0.8], debug_taps=True, seed=15)
+            res[tag] = [eng.tap(k) for k in ("x", "stats", "w_ceil")] + [out["lengths"].copy(), out["audio"].copy()]
+            eng.close()
+        for k, (a, b) in enumerate(zip(res["prefetch"], res["trips"])):
+            assert np.array_equal(a, b), (Tx, k)
