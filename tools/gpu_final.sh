@@ -4,7 +4,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 timeout 1700 python -m pytest tests -q -m gpu > $O/${TAG}_pytest_gpu_final.log 2>&1; grep "passed\|failed" $O/${TAG}_pytest_gpu_final.log | tail -2
 ( time timeout 900 python bench.py > $O/${TAG}_bench_final.json 2> $O/${TAG}_bench_final.err ) 2>&1 | tail -3; head -2 $O/${TAG}_bench_final.err
 TAG=$TAG bash tools/profile.sh > $O/${TAG}_profile.log 2>&1
