@@ -451,9 +451,10 @@ def main():
     if strong and 256 % n_gpus:
         raise SystemExit(f"--gpus {n_gpus} does not divide BASELINE's batch of 256: pass --batch (utterances per GPU)")
     B, Tx, fpi = (256 // n_gpus if strong else args.batch), args.tx, args.frames_per_id
-    # handles in flight per GPU: a 256-row batch fills the chip for 68 ms and takes 27 GB of workspace per handle — two overlap the
-    # text side of one batch with the decoder of the other just as well as three
-    n_streams = max(1, args.streams) if B < 128 else min(int(os.environ.get("MI355VITS_BENCH_BIG_STREAMS", "2")), max(1, args.streams))
+    # handles in flight per GPU: a 256-row batch fills the chip for 65 ms and takes 27 GB of workspace per handle (288 GB of HBM) — three
+    # overlap one batch's launch-bound text side and its tail with the other batches' decoders: 64.3 - 64.4 ms per step against 64.7 - 66.0
+    # with two and 67.1 with one (round 6, one lease, alternating: profiles/r06_b256_handles.txt)
+    n_streams = max(1, args.streams) if B < 128 else min(int(os.environ.get("MI355VITS_BENCH_BIG_STREAMS", "3")), max(1, args.streams))
     # single-process: every step of every device is one batch of B utterances; the job's step = n_gpus batches
     wl = Workload(cfg, weights, devices, n_streams, B, Tx, fpi, rank, world, multispeaker_sid=cfg.is_multispeaker,
                   math=args.math)
