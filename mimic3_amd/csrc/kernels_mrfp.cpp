@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         for (int u = 0; u < RB; ++u) {
             float v[8];
             MI355_UNROLL
-            for (int e = 0; e < 8; ++e) v[e] = s_in ? lrelu_f(sv[u][e], 0.1f) : 0.0f;
+            for (int e = 0; e < 8; ++e) v[e] = s_in ? fmaxf(sv[u][e], 0.1f * sv[u][e]) : 0.0f;  // = lrelu_f(v, 0.1f) bit for bit, one instruction fewer
             uint4 h, m, l;
             MRFP_SPLIT(v[0], v[1], h.x, m.x, l.x);
             MRFP_SPLIT(v[2], v[3], h.y, m.y, l.y);
@@ -249,7 +249,8 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
         if (piece < 0 || piece > 3) return;
         const int tt = nx.t0 - R + pc;
         const bool s_in = tt >= 0 && tt < nx.len;
-        const float v0 = s_in ? lrelu_f(sv[2 * piece], 0.1f) : 0.0f, v1 = s_in ? lrelu_f(sv[2 * piece + 1], 0.1f) : 0.0f;
+        const float a0 = sv[2 * piece], a1 = sv[2 * piece + 1];  // (leaky-relu as max(v, 0.1 v): the bits of lrelu_f, one instruction fewer)
+        const float v0 = s_in ? fmaxf(a0, 0.1f * a0) : 0.0f, v1 = s_in ? fmaxf(a1, 0.1f * a1) : 0.0f;
         MRFP_SPLIT(v0, v1, h4[piece], m4[piece], l4[piece]);
         if (piece == 3) {
             const int o = u * LDX + pc;
@@ -386,13 +387,17 @@ __global__ __launch_bounds__(512) void k_mrf_p(MrfArgs a) {
             const float b1[4] = {bv1.x, bv1.y, bv1.z, bv1.w};
             // ---- conv1: raw x at every tile's own columns (global, clamped: columns outside the row are masked in the epilogue)
             f32x4 acc1[NT1];
+            // (buffer loads: the row's base in SGPRs, this lane's channel row + column in ONE VGPR, the four channels' row offsets in
+            // SGPRs — no 64-bit address arithmetic per element; the same values)
+            const BufRsrc xres = buf_rsrc(xb);
+            const unsigned rowb = 4u * (unsigned)(co0 * a.x_ld);
             MI355_UNROLL
             for (int ti = 0; ti < NT1; ++ti) {
                 if (tile_on(ti)) {
                     const int t = t0 - r2 + tile_e0(ti) + n;
                     const int tc = t < 0 ? 0 : (t > last ? last : t);
                     MI355_UNROLL
-                    for (int r = 0; r < 4; ++r) acc1[ti][r] = (LAB_ABLATE(a) & 32) ? 0.0f : xb[(long)(co0 + r) * a.x_ld + tc];
+                    for (int r = 0; r < 4; ++r) acc1[ti][r] = (LAB_ABLATE(a) & 32) ? 0.0f : buf_load_f32(xres, rowb + 4u * (unsigned)tc, 4u * (unsigned)(r * a.x_ld));
                 }
             }
             stamp(3 + 8 * j);
