@@ -251,14 +251,25 @@ const ConvW& Engine::add_conv_data(const std::string& key, const std::vector<flo
             std::vector<uint32_t> b3(bf16x3_packed_words_mode(Cout, Cin, K, pe));
             pack_conv_weights_bf16x3_mode(w.data(), Cout, Cin, K, pe, 1, b3.data());
             c.packed_b3s = stage(reinterpret_cast<const float*>(b3.data()), b3.size());
-            if (epi == EPI_GATE && Cout % 32 == 0) {  // plain row order for k_wn_layer_b3
+            // k_wn_layer_b3 gates in registers: 32-row tile q of a gate conv = the tanh rows of channels 16 q .. 16 q + 15, then their sigmoid
+            // rows (a lane of the 32 x 32 accumulator tile then holds both halves of its eight channels; kernels_wn.cpp)
+            std::vector<float> wg;
+            if (epi == EPI_GATE && Cout % 32 == 0) {
+                const int Hh = Cout / 2;
+                const size_t row = (size_t)Cin * K;
+                wg.resize(w.size());
+                for (int q = 0; q < Cout / 32; ++q)
+                    for (int r = 0; r < 32; ++r) {
+                        const int src = (r < 16 ? 0 : Hh) + 16 * q + (r & 15);
+                        memcpy(wg.data() + ((size_t)32 * q + r) * row, w.data() + (size_t)src * row, row * sizeof(float));
+                    }
                 std::vector<uint32_t> bw(bf16x3_packed_words_mode(Cout, Cin, K, EPI_STD));
-                pack_conv_weights_bf16x3_mode(w.data(), Cout, Cin, K, EPI_STD, 1, bw.data());
+                pack_conv_weights_bf16x3_mode(wg.data(), Cout, Cin, K, EPI_STD, 1, bw.data());
                 c.packed_b3w = stage(reinterpret_cast<const float*>(bw.data()), bw.size());
             }
-            if (Cin % 16 == 0 && Cout % 32 == 0) {  // MATH_F16X2: WaveNet layers, staged convs, polyphase upsamplers (plain rows)
+            if (Cin % 16 == 0 && Cout % 32 == 0) {  // MATH_F16X2: WaveNet layers (gate convs: the tile order above), staged convs, polyphase upsamplers (plain rows)
                 std::vector<uint32_t> h2(f16x2_packed_words(Cout, Cin, K));
-                if (pack_conv_weights_f16x2(w.data(), Cout, Cin, K, h2.data(), 1))
+                if (pack_conv_weights_f16x2(wg.empty() ? w.data() : wg.data(), Cout, Cin, K, h2.data(), 1))
                     c.packed_h2s = stage(reinterpret_cast<const float*>(h2.data()), h2.size());
             }
         }

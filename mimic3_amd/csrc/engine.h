@@ -94,10 +94,10 @@ struct ConvW {
     size_t packed4 = NO_OFF; // same records regrouped [tile][tap][4 pairs][lane][4] for 16-byte A loads (fused MRF stage)
     size_t packed_b3 = NO_OFF;  // three bf16 planes in bf16-MFMA fragment order (pack_conv_weights_bf16x3), 32-bit words
     size_t packed_b3s = NO_OFF; // the same for the staged split-bf16 conv kernel (layout 1, this conv's tile map)
-    size_t packed_b3w = NO_OFF; // WaveNet in-layer convs: layout 1 in plain row order (fused split-bf16 layer kernel)
+    size_t packed_b3w = NO_OFF; // WaveNet in-layer convs: layout 1, 32-row tiles of (16 tanh rows, their 16 sigmoid rows) (fused split-bf16 layer kernel)
     size_t packed_h2 = NO_OFF;    // fused-MRF convs: two fp16 planes, weights x 2^13 (MATH_F16X2), when every |w| < 7.99
     size_t packed_p = NO_OFF;     // fused-MRF convs (Cin = Cout, taps 3 / 5 / 7): pack_conv_weights_p16 fragments (k_mrf_p)
-    size_t packed_h2s = NO_OFF;   // WaveNet layer convs: the same in plane order (layout 1), plain rows
+    size_t packed_h2s = NO_OFF;   // WaveNet layer convs: the same in plane order (layout 1), plain rows (gate convs: packed_b3w's tile order)
     size_t bias = NO_OFF;
     int Cout = 0, Cin = 0, K = 1;
     int epi = EPI_STD;  // tile map the packed copy was built for

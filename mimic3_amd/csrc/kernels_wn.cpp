@@ -474,10 +474,9 @@ constexpr int WNB_EPI = 1;   // epilogue form of the four-wave, 96-column kernel
 // RA: weight-fragment ring of the four-wave form (b3.h b3_chunk_ra): 2 = one group ahead (rounds 2 - 4), 4 = three groups ahead
 // EP: the epilogue's old-value loads (h residual: L2 hits, skip accumulator: HBM) — 0 = one tile ahead of the stores (rounds 2 - 4), 1 = three
 // tiles ahead (48 loads in flight per lane: the nine tiles of a wave were nine dependent round trips), 2 = three ahead AND the first three
-// tiles' loads issued in front of the gate phase (no vector-memory instruction in it: they land under its VALU / LDS work and the res/skip
-// conv's first weight fragments do not queue behind them in the in-order memory counter)
+// tiles' loads issued in front of the barrier behind the gate phase (they land under the res/skip conv's first steps; lab form)
 // TW ("two workgroups per CU"): 64-column tiles whose LDS fits twice into a CU (h planes 68 columns = 76.5 KiB, u planes
-// 72 KiB, the raw in-layer result gated ONE 32-column tile at a time: 48 KiB) with <= 256 registers per wave, so that one workgroup's
+// 72 KiB) with <= 256 registers per wave, so that one workgroup's
 // HBM phases (staging, the h / skip read-modify-write) run under the other's matrix loops — at the price of streaming the layer's
 // fragments once per 64 instead of once per 96 columns.  The same products in the same order per output element: bit-identical.
 template <bool W1, int NT, bool H2, int MW, int RA, int EP, bool TW>
@@ -490,7 +489,6 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
     constexpr float ACC = H2 ? F16X2_ACC_SCALE : 1.0f, UNACC = H2 ? 1.0f / F16X2_ACC_SCALE : 1.0f;
     DYN_SMEM(float, smem);
     uint4* planes = reinterpret_cast<uint4*>(smem);
-    float* R = smem;  // [2H][T_B] raw in-layer result, later scratch of the epilogue
     const int tid = threadIdx.x, lane = tid & 63, w = WAVE_UNIFORM(tid >> 6);
     const int brow = lane >> 5, bcol = lane & 31;
     const int b = blockIdx.y;
@@ -516,8 +514,6 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
     // (speaker conditioning without a branch per element — a test per load makes hipcc wait for each one in turn)
     const float* condp = a.cond ? a.cond + (long)b * a.cond_bs : a.b_in;
     const float cond_on = a.cond ? 1.0f : 0.0f;
-    constexpr int ITEMS = NG * 2 * T_B / NTH;  // gate items per thread — four waves: 9 (96 columns), 6 (64) or 3 (32); twelve: 3 or 1
-    float u[ITEMS][8];
     {
         f32x16 acc[MW][NT];
         const uint4* wp[MW];
@@ -526,7 +522,8 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
             const int q = w + NWV * i;
             MI355_UNROLL
             for (int r = 0; r < 16; ++r) {
-                const int c = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * brow;
+                // tile q = the tanh rows (tile rows 0 - 15) and the sigmoid rows (16 - 31) of channels 16 q .. 16 q + 15: see the gate below
+                const int c = (r < 8 ? 0 : H) + 16 * q + (r & 3) + 8 * ((r >> 2) & 1) + 4 * brow;
                 const float v = (a.b_in[c] + cond_on * condp[c]) * ACC;  // unconditional loads: all in flight together
                 MI355_UNROLL
                 for (int j = 0; j < NT; ++j) acc[i][j][r] = v;
@@ -540,42 +537,43 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
             else if constexpr (RA > 2) b3_chunk_ra<MW, NT, NG, NT, W1, RA>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
             else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         }
-        __syncthreads();  // every wave is done with the h planes: the raw result takes their place
+        __syncthreads();  // every wave is done with the h planes: u's planes take their place (column pitch T_B)
         WN_TS(2);
-        if constexpr (TW) {
-            // one 32-column tile of the raw result at a time ([2H][32] = 48 KiB): store, gate into registers, next tile
+        WN_TS(3);
+        // ---- gate in registers (round 6): the in-layer conv's rows are stored permuted (Engine::add_conv_data, packed_b3w / packed_h2s of a gate
+        // conv) so that 32-row tile q holds tanh rows of channels 16 q .. 16 q + 15 in its rows 0 - 15 and their sigmoid rows in 16 - 31: accumulator
+        // r < 8 and r + 8 of a lane are the two halves of ONE channel, and a lane's eight gated values of a (row tile, column tile) are exactly
+        // the eight k-slots of one B-operand record (16-channel group q, half brow, its column) of the res/skip conv — the raw result never
+        // goes through LDS (rounds 2 - 5: 144 ds_write_b32 + a barrier + 144 ds_read_b32 per lane).  Same values, same gate: same bits.
+        constexpr int PSU0 = NG * 2 * T_B;
+        MI355_UNROLL
+        for (int i = 0; i < MW; ++i)
             MI355_UNROLL
             for (int j = 0; j < NT; ++j) {
+                float u[8];
                 MI355_UNROLL
-                for (int i = 0; i < MW; ++i)
-                    MI355_UNROLL
-                    for (int r = 0; r < 16; ++r) R[(32 * (w + NWV * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * 32 + bcol] = acc[i][j][r] * UNACC;
-                __syncthreads();
-                MI355_UNROLL
-                for (int it = 0; it < ITEMS / NT; ++it) {
-                    const int idx = tid + NTH * it;
-                    const int gh = idx >> 5, col = idx & 31;
-                    const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
-                    MI355_UNROLL
-                    for (int e = 0; e < 8; ++e) {
-                        const int c = cbase + 8 * (e >> 2) + (e & 3);
-                        u[j * (ITEMS / NT) + it][e] = wn_gate_f(R[c * 32 + col], R[(H + c) * 32 + col]);
-                    }
+                for (int e = 0; e < 8; ++e) u[e] = wn_gate_f(acc[i][j][e] * UNACC, acc[i][j][e + 8] * UNACC);
+                const int idx = (2 * (w + NWV * i) + brow) * T_B + 32 * j + bcol;
+                if constexpr (H2) {
+                    uint4 h4, m4;
+                    split2_pk(u[0] * F16X2_X_SCALE, u[1] * F16X2_X_SCALE, h4.x, m4.x);
+                    split2_pk(u[2] * F16X2_X_SCALE, u[3] * F16X2_X_SCALE, h4.y, m4.y);
+                    split2_pk(u[4] * F16X2_X_SCALE, u[5] * F16X2_X_SCALE, h4.z, m4.z);
+                    split2_pk(u[6] * F16X2_X_SCALE, u[7] * F16X2_X_SCALE, h4.w, m4.w);
+                    planes[idx] = h4;
+                    planes[PSU0 + idx] = m4;
+                } else {
+                    uint4 h4, m4, l4;
+                    split3_pk(u[0], u[1], h4.x, m4.x, l4.x);
+                    split3_pk(u[2], u[3], h4.y, m4.y, l4.y);
+                    split3_pk(u[4], u[5], h4.z, m4.z, l4.z);
+                    split3_pk(u[6], u[7], h4.w, m4.w, l4.w);
+                    planes[idx] = h4;
+                    planes[PSU0 + idx] = m4;
+                    planes[2 * PSU0 + idx] = l4;
                 }
-                __syncthreads();  // the tile has been consumed: the next one (or u's planes) takes its place
             }
-        } else {
-            MI355_UNROLL
-            for (int i = 0; i < MW; ++i)
-                MI355_UNROLL
-                for (int j = 0; j < NT; ++j)
-                    MI355_UNROLL
-                    for (int r = 0; r < 16; ++r)
-                        R[(32 * (w + NWV * i) + (r & 3) + 8 * (r >> 2) + 4 * brow) * T_B + j * 32 + bcol] = acc[i][j][r] * UNACC;
-        }
     }
-    if constexpr (!TW) __syncthreads();
-    WN_TS(3);
     const int ntr = a.Crs / 32;
     const float* src[MW];
     float* dst[MW];
@@ -630,47 +628,7 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
         for (int k = 0; k < EPA; ++k) load_tile_b(k / NT, k % NT, old[k]);
         SCHED_FENCE();
     }
-    // ---- gate: a thread takes (16-channel group, half, column) items = the eight k-slots of one B-operand record
-    if constexpr (!TW) {
-        MI355_UNROLL
-        for (int it = 0; it < ITEMS; ++it) {
-            const int idx = tid + NTH * it;
-            const int gh = idx / T_B, col = idx - gh * T_B;
-            const int cbase = (gh >> 1) * 16 + (gh & 1) * 4;
-            MI355_UNROLL
-            for (int e = 0; e < 8; ++e) {
-                const int c = cbase + 8 * (e >> 2) + (e & 3);
-                const float at = R[c * T_B + col], as = R[(H + c) * T_B + col];
-                const float gate = wn_gate_f(at, as);
-                u[it][e] = gate;
-            }
-        }
-        __syncthreads();  // the raw result has been consumed: u's planes take its place (column pitch T_B)
-    }
     constexpr int PSU = NG * 2 * T_B;
-    MI355_UNROLL
-    for (int it = 0; it < ITEMS; ++it) {
-        // = gh * T_B + col (TW: item it = tile j = it / (ITEMS / NT), (gh, column of the tile) = tid + NTH * (it % (ITEMS / NT)))
-        const int idx = TW ? (((tid + NTH * (it % (ITEMS / NT))) >> 5) * T_B + (it / (ITEMS / NT)) * 32 + ((tid + NTH * (it % (ITEMS / NT))) & 31)) : tid + NTH * it;
-        if constexpr (H2) {
-            uint4 h4, m4;
-            split2_pk(u[it][0] * F16X2_X_SCALE, u[it][1] * F16X2_X_SCALE, h4.x, m4.x);
-            split2_pk(u[it][2] * F16X2_X_SCALE, u[it][3] * F16X2_X_SCALE, h4.y, m4.y);
-            split2_pk(u[it][4] * F16X2_X_SCALE, u[it][5] * F16X2_X_SCALE, h4.z, m4.z);
-            split2_pk(u[it][6] * F16X2_X_SCALE, u[it][7] * F16X2_X_SCALE, h4.w, m4.w);
-            planes[idx] = h4;
-            planes[PSU + idx] = m4;
-        } else {
-            uint4 h4, m4, l4;
-            split3_pk(u[it][0], u[it][1], h4.x, m4.x, l4.x);
-            split3_pk(u[it][2], u[it][3], h4.y, m4.y, l4.y);
-            split3_pk(u[it][4], u[it][5], h4.z, m4.z, l4.z);
-            split3_pk(u[it][6], u[it][7], h4.w, m4.w, l4.w);
-            planes[idx] = h4;
-            planes[PSU + idx] = m4;
-            planes[2 * PSU + idx] = l4;
-        }
-    }
     __syncthreads();
     WN_TS(4);
     // ---- res/skip 1x1 conv: Crs / 32 row tiles (12, last layer 6), tile q on wave q % 4
@@ -804,9 +762,7 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     if (tw) nt = 2;
     const int tb = 32 * nt;
     a.ldx = tw ? tb + (a.K - 1) * a.dil : ((tb + (a.K - 1) * a.dil + 3 + 3) & ~3);
-    size_t shmem = (size_t)3 * WNB_NG * 2 * a.ldx * 16;
-    const size_t raw = (size_t)2 * WNB_H * (tw ? 32 : tb) * sizeof(float);
-    if (raw > shmem) shmem = raw;
+    const size_t shmem = (size_t)3 * WNB_NG * 2 * a.ldx * 16;  // the h planes; u's planes (column pitch tb <= ldx) take their place
     dim3 grid((a.T + tb - 1) / tb, a.B);
     // four waves (one per SIMD, the whole register file each) is the product's form.  The twelve-wave form (three per SIMD; MW = 1)
     // is bit-identical and measured EQUAL on the MI355X (16 layers 1.77 vs 1.76 ms, profiles/r04_wn_experiments.txt): the matrix
