@@ -1374,8 +1374,9 @@ __device__ __forceinline__ void epi_std_tile_buf(const ConvArgs& a, int b, int c
 // once (150 KiB at 192 channels), wave w streams row tile w's fragments — nobody else's — and every fragment feeds NCT column tiles
 // (24 MFMAs = 768 cycles per 3 KiB: 32 B per clock and CU with eight waves); a.rb_loop row blocks of NW tiles one after the other.
 // b3_chunk walks k-groups and taps in the same order for every accumulator: an output element has the bits of the 64 x 64 form.
-template <bool W1, int NG, int NCT, int NW>
+template <bool W1, int NG, int NCT, int NW, bool SIX = false>
 __global__ __launch_bounds__(64 * NW) void k_enc_b3w(ConvArgs a) {
+    static_assert(!SIX || (NW == 8 && NCT == 4), "six row tiles x four column tiles dealt to eight waves");
     DYN_SMEM(float, smem);
     uint4* planes = reinterpret_cast<uint4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = WAVE_UNIFORM(tid >> 6);
@@ -1393,32 +1394,74 @@ __global__ __launch_bounds__(64 * NW) void k_enc_b3w(ConvArgs a) {
     __syncthreads();
     const int R = a.rb_loop > 1 ? a.rb_loop : 1;
     const int ngt = a.Cin / 16;
-    for (int rr = 0; rr < R; ++rr) {
-        const int rt = (blockIdx.y * R + rr) * NW + wid;  // 32-row tile of the output
-        if (32 * rt >= a.Cout) break;
-        f32x16 acc[1][NCT];
-        MI355_UNROLL
-        for (int j = 0; j < NCT; ++j)
+    // one 32 x 32 output tile through the conv's epilogue (lane coordinates opaque: the epilogue's 4 x 16 row addresses are loop-invariant,
+    // and hoisted in front of the row-block loop they spill — 544 bytes of scratch and a drain per reload)
+    auto store_tile = [&](int rt, int j, const f32x16& acc, int bcol_e, int brow_e) MI355_INLINE_LAMBDA {
+        const int t = t0 + 32 * j + bcol_e;
+        if (a.ksplit == 1) {
+            epi_std_tile_buf(a, b, 32 * rt, t, t < a.T, brow_e, acc, out_len);
+        } else {  // a slice's raw sums (the following LayerNorm launch adds the slices up)
+            const BufRsrc pb = buf_rsrc(a.part + (((long)sl * a.B + b) * a.Cout + 32 * rt) * a.T);
+            const unsigned vp = t < a.T ? 4u * (unsigned)(t + 4 * brow_e * a.T) : BUF_OOB;
             MI355_UNROLL
-            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
-        const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
-        if (!(LAB_ABLATE(a) & 1)) b3_chunk_lean<1, NCT, NG, W1>(acc, wp, planes + brow * LD + bcol, PS, LD, a.K, ngt, a.dil);  // (B fragments single-buffered: the double-buffered loop spills at four column tiles)
-        // (lane coordinates made opaque here: the epilogue's 4 x 16 row addresses are loop-invariant, and hoisted in front of the row-block
-        // loop they spill — 544 bytes of scratch and a drain per reload)
-        int bcol_e = bcol, brow_e = brow;
-        OPAQUE_V(bcol_e);
-        OPAQUE_V(brow_e);
-        MI355_UNROLL
-        for (int j = 0; j < NCT; ++j) {
-            const int t = t0 + 32 * j + bcol_e;
-            if (a.ksplit == 1) {
-                epi_std_tile_buf(a, b, 32 * rt, t, t < a.T, brow_e, acc[0][j], out_len);
-            } else {  // a slice's raw sums (the following LayerNorm launch adds the slices up)
-                const BufRsrc pb = buf_rsrc(a.part + (((long)sl * a.B + b) * a.Cout + 32 * rt) * a.T);
-                const unsigned vp = t < a.T ? 4u * (unsigned)(t + 4 * brow_e * a.T) : BUF_OOB;
+            for (int r = 0; r < 16; ++r) buf_store_f32(pb, vp, 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * a.T), acc[r]);
+        }
+    };
+    for (int rr = 0; rr < R; ++rr) {
+        if constexpr (SIX) {
+            // Row blocks of SIX row tiles on eight waves (192-row convs: FFN conv_2, q / k / v, the couplings' pre conv): with one row tile per
+            // wave six waves sit on four SIMDs — two SIMDs carry two waves, the workgroup takes 2 x 4 tile units.  Here the 24 (row tile,
+            // column tile) units are dealt three to a wave: waves 0 - 5 take column tiles 0 - 2 of row tile w, waves 6 / 7 column tile 3 of
+            // row tiles 0 - 2 / 3 - 5 (their fragments feed one column tile each: 12 instead of 6 fragment streams per workgroup, still
+            // below the L1's rate with two waves per SIMD).  b3_chunk_lean walks k-groups and taps in one order for every accumulator:
+            // an output element has the bits of the other forms.
+            const int rt0 = (blockIdx.y * R + rr) * 6;
+            if (32 * rt0 >= a.Cout) break;
+            int bcol_e = bcol, brow_e = brow;
+            if (wid < 6) {
+                const int rt = rt0 + wid;
+                f32x16 acc[1][3];
                 MI355_UNROLL
-                for (int r = 0; r < 16; ++r) buf_store_f32(pb, vp, 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * a.T), acc[0][j][r]);
+                for (int j = 0; j < 3; ++j)
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
+                const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
+                if (!(LAB_ABLATE(a) & 1)) b3_chunk_lean<1, 3, NG, W1>(acc, wp, planes + brow * LD + bcol, PS, LD, a.K, ngt, a.dil);
+                OPAQUE_V(bcol_e);
+                OPAQUE_V(brow_e);
+                MI355_UNROLL
+                for (int j = 0; j < 3; ++j) store_tile(rt, j, acc[0][j], bcol_e, brow_e);
+            } else {
+                const int rtb = rt0 + 3 * (wid - 6);
+                f32x16 acc[3][1];
+                const uint4* wp[3];
+                MI355_UNROLL
+                for (int i = 0; i < 3; ++i) {
+                    MI355_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.0f;
+                    wp[i] = reinterpret_cast<const uint4*>(a.wb3) + ((long)(rtb + i) * a.K * ngt + c0 / 16) * 192 + lane;
+                }
+                if (!(LAB_ABLATE(a) & 1)) b3_chunk_lean<3, 1, NG, W1>(acc, wp, planes + brow * LD + bcol + 96, PS, LD, a.K, ngt, a.dil);
+                OPAQUE_V(bcol_e);
+                OPAQUE_V(brow_e);
+                MI355_UNROLL
+                for (int i = 0; i < 3; ++i) store_tile(rtb + i, 3, acc[i][0], bcol_e, brow_e);
             }
+        } else {
+            const int rt = (blockIdx.y * R + rr) * NW + wid;  // 32-row tile of the output
+            if (32 * rt >= a.Cout) break;
+            f32x16 acc[1][NCT];
+            MI355_UNROLL
+            for (int j = 0; j < NCT; ++j)
+                MI355_UNROLL
+                for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
+            const uint4* wp[1] = {reinterpret_cast<const uint4*>(a.wb3) + ((long)rt * a.K * ngt + c0 / 16) * 192 + lane};
+            if (!(LAB_ABLATE(a) & 1)) b3_chunk_lean<1, NCT, NG, W1>(acc, wp, planes + brow * LD + bcol, PS, LD, a.K, ngt, a.dil);  // (B fragments single-buffered: the double-buffered loop spills at four column tiles)
+            int bcol_e = bcol, brow_e = brow;
+            OPAQUE_V(bcol_e);
+            OPAQUE_V(brow_e);
+            MI355_UNROLL
+            for (int j = 0; j < NCT; ++j) store_tile(rt, j, acc[0][j], bcol_e, brow_e);
         }
     }
 }
@@ -1566,11 +1609,16 @@ void launch_enc_conv_b3(const ConvArgs& a_in, hipStream_t s) {
                 LAUNCH_KERNEL(kfn, gridw, dim3(threads), shw, s, a);
             };
             const bool w1 = a.math == MATH_BF16W;
+            // row blocks of six tiles: dealt to eight waves (SIX) unless the lab switch asks for the round-6a form (one row tile per wave, six waves)
+            bool six8 = nw == 6;
+            if (const char* f = lab_getenv("MI355VITS_ENC_SIX8")) six8 = six8 && atoi(f) != 0;
             if (ng == ENC_NG) {
                 if (nw == 8) { if (w1) gow(k_enc_b3w<true, ENC_NG, NCT, 8>, 512); else gow(k_enc_b3w<false, ENC_NG, NCT, 8>, 512); }
+                else if (six8) { if (w1) gow(k_enc_b3w<true, ENC_NG, NCT, 8, true>, 512); else gow(k_enc_b3w<false, ENC_NG, NCT, 8, true>, 512); }
                 else { if (w1) gow(k_enc_b3w<true, ENC_NG, NCT, 6>, 384); else gow(k_enc_b3w<false, ENC_NG, NCT, 6>, 384); }
             } else {
                 if (nw == 8) { if (w1) gow(k_enc_b3w<true, ENC_NG / 2, NCT, 8>, 512); else gow(k_enc_b3w<false, ENC_NG / 2, NCT, 8>, 512); }
+                else if (six8) { if (w1) gow(k_enc_b3w<true, ENC_NG / 2, NCT, 8, true>, 512); else gow(k_enc_b3w<false, ENC_NG / 2, NCT, 8, true>, 512); }
                 else { if (w1) gow(k_enc_b3w<true, ENC_NG / 2, NCT, 6>, 384); else gow(k_enc_b3w<false, ENC_NG / 2, NCT, 6>, 384); }
             }
             return;

@@ -748,6 +748,15 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     const char* nt_s = lab_getenv("MI355VITS_WN_B3_NT");  // read per launch: tests flip it inside one process
     const long nwg3 = (long)((a.T + 95) / 96) * a.B;
     int nt = nt_s ? atoi(nt_s) : (nwg3 < 128 ? 1 : 3);
+    // 128-column tiles (round 6: they fit since the gate left LDS — 153 KiB of h planes; a fragment group feeds 72 instead of 54 MFMAs, the
+    // per-workgroup phases are paid once per 128 columns: 0.96 of the 96-column form's time per column, profiles/r06_wn_nt4_ab.txt) when the
+    // persistent rounds of the grid come out shorter: rounds x tile cost (4/3 x 0.96 = 1.28 of a 96-column tile).  Same bits.
+    if (!nt_s && nt == 3 && a.math != MATH_F16X2) {
+        const long cus = current_device_cu_count();
+        const long nwg4 = (long)((a.T + 127) / 128) * a.B;
+        if ((double)((nwg4 + cus - 1) / cus) * 1.28 < (double)((nwg3 + cus - 1) / cus)) nt = 4;
+    }
+    if (nt == 4 && (a.math == MATH_F16X2 || ((long)a.h_ld * 128 >= 0x7fffffffL || (long)a.s_ld * 128 >= 0x7fffffffL || (a.K - 1) * a.dil > 8))) nt = 3;  // (buffer-addressed epilogue; 160 KiB of LDS)
     // the two-workgroups-per-CU form (64-column tiles, k_wn_layer_b3_tw): large grids of the default / bf16-weights math
     // Measured on the MI355X (profiles/r05_wn_two_per_cu_ab.txt): 8.5 % SLOWER than the 96-column form at batch 256 (14.3 vs 13.2 ms per 16
     // layers x 256 rows), 31 % slower at batch 32 (384 workgroups on 512 slots) — what the overlap of the HBM phases gains, the 1.5 x
@@ -782,7 +791,11 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
         else go(k_wn_layer_b3_tw<false>, 256);
     } else
 #endif
-    if (nt == 1) {
+    if (nt == 4 && a.math != MATH_F16X2) {
+        // (weight fragments one group ahead: the three-ahead ring of the 96-column form spills at four column tiles — 148 B of scratch)
+        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 4, false, 3, 2, 1>, 256);
+        else go(k_wn_layer_b3<false, 4, false, 3, 2, 1>, 256);
+    } else if (nt == 1) {
         if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 1, true>, 256);
         else if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 1>, 256);
         else go(k_wn_layer_b3<false, 1>, 256);

@@ -457,10 +457,41 @@ def test_encoder_convs_on_the_slice_kernel(emu_lib):
         assert rel_rms(full["audio"][b, :Lb], ref["audio"][b, :Lb]) < 2e-5
 
 
+def test_encoder_wide_forms_are_bitwise_the_64_column_form(emu_lib):
+    """k_enc_b3w (128 columns x all of a conv's 32-row tiles per workgroup) against the 64 x 64 form, and its two ways of running a block
+    of SIX row tiles (FFN conv_2, q / k / v, the couplings' pre conv: 192 output rows): one row tile per wave on six waves
+    (MI355VITS_ENC_SIX8=0) or the 24 (row tile, column tile) units dealt three to a wave on eight waves (the default since round 6).
+    Same products in the same order per output element: every text-side tap, z and the waveform bit for bit, ragged rows included."""
+    import os
+
+    cfg = VitsConfig.tiny_h192()
+    cfg.filter_channels = 768
+    w = W.synthetic_weights(cfg, seed=43, frames_per_id=2.0)
+    blob = W.pack(cfg, w)
+    ids = np.random.default_rng(9).integers(1, cfg.num_symbols, (3, 150))
+    lengths = np.array([150, 33, 129])
+    res = {}
+    for tag, env in (("narrow", {"MI355VITS_ENC_WIDE": "0"}), ("six", {"MI355VITS_ENC_WIDE": "1", "MI355VITS_ENC_SIX8": "0"}),
+                     ("eight", {"MI355VITS_ENC_WIDE": "1"})):
+        os.environ.update(env)
+        try:
+            eng = Engine(blob, library=emu_lib)
+            eng.set_math("bf16x3")
+            out = eng.run(ids, lengths, (0.667, 1.0, 0.8), debug_taps=True, seed=17)
+            res[tag] = [eng.tap(k) for k in ("x", "stats", "dp.h", "w_ceil", "z_p", "z")] + [out["lengths"].copy(), out["audio"].copy()]
+            eng.close()
+        finally:
+            for k in env:
+                del os.environ[k]
+    for tag in ("six", "eight"):
+        for k, (a, b) in enumerate(zip(res["narrow"], res[tag])):
+            assert np.array_equal(a, b), (tag, k)
+
+
 @pytest.mark.parametrize("n_speakers", [1, 3])
 def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
-    """k_wn_layer_b3 (H = 192: 96 columns x all 384 rows per workgroup, operands split 3 x bf16, raw result gated through
-    LDS, res/skip from the u planes): flow output `z` and the waveform vs the oracle, ragged batch with rows shorter and
+    """k_wn_layer_b3 (H = 192: 96 columns x all 384 rows per workgroup, operands split 3 x bf16, the gate in registers,
+    res/skip from the u planes): flow output `z` and the waveform vs the oracle, ragged batch with rows shorter and
     longer than one 96-column tile, speaker conditioning; and against the f32 fused kernel."""
     cfg = VitsConfig.tiny_h192(n_speakers=n_speakers)
     w = W.synthetic_weights(cfg, seed=71, frames_per_id=2.0)
@@ -482,7 +513,7 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
     import os
 
     by_nt = {}
-    for nt in ("1", "3"):
+    for nt in ("1", "3", "4"):  # (4: the 128-column form of round 6)
         os.environ["MI355VITS_WN_B3_NT"] = nt
         try:
             eng = Engine(blob, library=emu_lib)
@@ -491,7 +522,7 @@ def test_bf16x3_fused_wavenet_layer_kernel(emu_lib, n_speakers):
             eng.close()
         finally:
             del os.environ["MI355VITS_WN_B3_NT"]
-    assert np.array_equal(by_nt["1"], by_nt["3"])
+    assert np.array_equal(by_nt["1"], by_nt["3"]) and np.array_equal(by_nt["4"], by_nt["3"])
     # ... and the twelve-wave form of the 96-column tile (one row tile per wave, three waves per SIMD) against the four-wave one
     by_nw = {}
     for nw in ("4", "12"):

@@ -247,7 +247,8 @@ def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, m
     forced = np.full((B, Tx), 6, np.int32)
     res = {}
     monkeypatch.setenv("MI355VITS_WN_B3_NT", "3")
-    for tag, ring in (("ring4", None), ("ring2", "2"), ("ring4_again", None), ("epi0", "e0"), ("epi1", "e1"), ("epi2", "e2"), ("tw", "tw")):
+    for tag, ring in (("ring4", None), ("ring2", "2"), ("ring4_again", None), ("epi0", "e0"), ("epi1", "e1"), ("epi2", "e2"), ("tw", "tw"), ("nt4", "nt4")):
+        monkeypatch.setenv("MI355VITS_WN_B3_NT", "4" if ring == "nt4" else "3")  # (nt4: the 128-column tiles large grids run since round 6)
         monkeypatch.delenv("MI355VITS_WN_RING", raising=False)
         monkeypatch.delenv("MI355VITS_WN_EPI", raising=False)
         monkeypatch.delenv("MI355VITS_WN_TW", raising=False)
@@ -255,13 +256,13 @@ def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, m
             monkeypatch.setenv("MI355VITS_WN_TW", "1")
         elif ring is not None and ring.startswith("e"):  # the epilogue forms (old values one / three tiles ahead / + issued before the gate)
             monkeypatch.setenv("MI355VITS_WN_EPI", ring[1:])
-        elif ring is not None:
+        elif ring is not None and ring != "nt4":
             monkeypatch.setenv("MI355VITS_WN_RING", ring)
         eng = Engine(blob, library=lab_lib, device=0)
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
         res[tag] = eng.tap("z"), out["audio"].copy(), out["lengths"].copy()
         eng.close()
-    for tag in ("ring2", "ring4_again", "epi0", "epi1", "epi2", "tw"):
+    for tag in ("ring2", "ring4_again", "epi0", "epi1", "epi2", "tw", "nt4"):
         for k in range(3):
             assert np.array_equal(res[tag][k], res["ring4"][k]), (tag, k)
 
@@ -303,15 +304,20 @@ def test_encoder_128_column_form_is_bitwise_the_64_column_form(lab_lib, monkeypa
     ids = np.random.default_rng(6).integers(1, cfg.num_symbols, (6, Tx))
     lengths = [Tx, 65, 1, 129, 128, 77]
     res = {}
-    for tag, env in (("narrow", "0"), ("wide", "1")):
+    for tag, env, six8 in (("narrow", "0", None), ("wide", "1", None), ("wide6", "1", "0")):  # (wide6: six-row-tile blocks on six waves, the round-6a form)
         monkeypatch.setenv("MI355VITS_ENC_WIDE", env)
+        if six8 is None:
+            monkeypatch.delenv("MI355VITS_ENC_SIX8", raising=False)
+        else:
+            monkeypatch.setenv("MI355VITS_ENC_SIX8", six8)
         eng = Engine(blob, library=lab_lib, device=0)
         eng.profile_enable(True)
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], debug_taps=True, seed=14)
         res[tag] = [eng.tap(k) for k in ("x", "stats", "dp.h", "w_ceil", "z_p", "z")] + [out["lengths"].copy(), out["audio"].copy()]
         eng.close()
-    for k, (a, b) in enumerate(zip(res["narrow"], res["wide"])):
-        assert np.array_equal(a, b), k
+    for tag in ("wide", "wide6"):
+        for k, (a, b) in enumerate(zip(res["narrow"], res[tag])):
+            assert np.array_equal(a, b), (tag, k)
 
 
 def test_attention_high_occupancy_form_is_bitwise_the_prefetched_form(lab_lib, monkeypatch):
