@@ -240,6 +240,69 @@ __device__ __forceinline__ void b3_chunk_lean(f32x16 (&acc)[MT][NT], const uint4
     }
 }
 
+// b3_chunk_lean with the WEIGHT fragments RA - 1 groups ahead (b3_chunk_ra's ring): the form for FOUR column tiles per wave (k_wn_layer_b3's
+// 128-column tiles, round 6) — 3 x 4 accumulator tiles are 192 registers, the double-buffered B fragments of b3_chunk_ra another 96 and the
+// ring 144: more than the file.  Single-buffered B (48) + the ring fits without a spill, and the fragments keep their three groups
+// (3 x 72 MFMAs = 3.6 us) of cover for the boxes whose L2 loses them to the activation stream.  Same products in the same order per accumulator.
+template <int MT, int NT, int NG, bool W1, int RA>
+__device__ __forceinline__ void b3_chunk_lean_ra(f32x16 (&acc)[MT][NT], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS, int LD,
+                                                 int K, int groups_per_tap, int dil) {
+    static_assert(RA >= 2 && NG % RA == 0 && RA - 1 <= NG, "ring of RA weight-fragment buffers");
+    uint4 ra[RA][MT][3];
+    uint4 rb[NT][3];
+    constexpr int NPA = W1 ? 1 : 3;
+    constexpr int D = RA - 1;  // groups ahead
+    const int ntot = K * NG;
+    auto load_a = [&](int n, uint4 (&dst)[MT][3]) MI355_INLINE_LAMBDA {
+        const int nc = n < ntot ? n : ntot - 1;  // past the last group: the last again (every load unconditional)
+        const int k = nc / NG, g = nc - k * NG;
+        const long woff = ((long)k * groups_per_tap + g) * 192;
+        MI355_UNROLL
+        for (int i = 0; i < MT; ++i)
+            MI355_UNROLL
+            for (int p = 0; p < NPA; ++p) dst[i][p] = wp[i][woff + p * 64];
+    };
+    MI355_UNROLL
+    for (int d = 0; d < D; ++d) load_a(d, ra[d]);
+    MI355_UNROLL
+    for (int j = 0; j < NT; ++j)
+        MI355_UNROLL
+        for (int p = 0; p < 3; ++p) rb[j][p] = xq[p * PS + j * 32];
+    for (int k = 0; k < K; ++k) {
+        const bool last_tap = k == K - 1;
+        MI355_UNROLL
+        for (int g = 0; g < NG; ++g) {
+            const bool wrap = g + 1 == NG;
+            const int xoff = wrap ? (last_tap ? k * dil + g * 2 * LD : (k + 1) * dil) : k * dil + (g + 1) * 2 * LD;
+            load_a(k * NG + g + D, ra[(g + D) % RA]);
+            SCHED_FENCE();
+            MI355_UNROLL
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (!W1) {
+                    MI355_UNROLL
+                    for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[g % RA][i][2], rb[j][0], acc[i][j]);  // small terms first
+                }
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[j][2], acc[i][j]);
+                if constexpr (!W1) {
+                    MI355_UNROLL
+                    for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[g % RA][i][1], rb[j][1], acc[i][j]);
+                    MI355_UNROLL
+                    for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[g % RA][i][1], rb[j][0], acc[i][j]);
+                }
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[j][1], acc[i][j]);
+                MI355_UNROLL
+                for (int i = 0; i < MT; ++i) acc[i][j] = MFMA_32x32x16_BF16(ra[g % RA][i][0], rb[j][0], acc[i][j]);
+                SCHED_FENCE();
+                MI355_UNROLL
+                for (int p = 0; p < 3; ++p) rb[j][p] = xq[p * PS + xoff + j * 32];
+                SCHED_FENCE();
+            }
+        }
+    }
+}
+
 // MATH_F16X2 form of b3_chunk_lean (B fragments single-buffered, two fp16 planes, three products)
 template <int MT, int NT, int NG>
 __device__ __forceinline__ void h2_chunk_lean(f32x16 (&acc)[MT][NT], const uint4* const (&wp)[MT], const uint4* __restrict__ xq, int PS, int LD,

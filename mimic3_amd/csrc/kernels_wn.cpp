@@ -534,6 +534,7 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
             // (twelve waves: 170 registers each — the form with the B fragments single-buffered, same products in the same order)
             if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
             else if constexpr (MW == 1 || TW) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);  // (TW: 256 registers)
+            else if constexpr (RA > 2 && NT >= 4) b3_chunk_lean_ra<MW, NT, NG, W1, RA>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);  // (four column tiles: B single-buffered)
             else if constexpr (RA > 2) b3_chunk_ra<MW, NT, NG, NT, W1, RA>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
             else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * LD + bcol + toff, PS, LD, a.K, NG, a.dil);
         }
@@ -651,6 +652,7 @@ __device__ __forceinline__ void wn_layer_b3_body(const WnArgs& a) {
             if (two || MW == 1) {  // (twelve waves, six tiles: waves 6 .. 11 recompute the last tile, discarded below)
                 if constexpr (H2) h2_chunk<MW, NT, NG, NT>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else if constexpr (MW == 1 || TW) b3_chunk_lean<MW, NT, NG, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
+                else if constexpr (RA > 2 && NT >= 4) b3_chunk_lean_ra<MW, NT, NG, W1, RA>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else if constexpr (RA > 2) b3_chunk_ra<MW, NT, NG, NT, W1, RA>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
                 else b3_chunk<MW, NT, NG, NT, W1>(acc, wp, planes + brow * T_B + bcol, PSU, T_B, 1, NG, 0);
             } else if constexpr (MW == 3) {  // 6 tiles: waves 0, 1 two tiles, waves 2, 3 one (second index clamped)
@@ -792,8 +794,12 @@ void launch_wn_layer_b3(WnArgs a, hipStream_t s) {
     } else
 #endif
     if (nt == 4 && a.math != MATH_F16X2) {
-        // (weight fragments one group ahead: the three-ahead ring of the 96-column form spills at four column tiles — 148 B of scratch)
-        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 4, false, 3, 2, 1>, 256);
+        // weight fragments three groups ahead as in the 96-column form, the B fragments single-buffered (b3_chunk_lean_ra: with both
+        // double-buffered the loop spills 148 B at four column tiles); MI355VITS_WN_RING=2: one group ahead, B double-buffered
+        int ring = WNB_RING;
+        if (const char* f = lab_getenv("MI355VITS_WN_RING")) ring = atoi(f);
+        if (a.math == MATH_BF16W) go(k_wn_layer_b3<true, 4, false, 3, 4, 1>, 256);
+        else if (ring > 2) go(k_wn_layer_b3<false, 4, false, 3, 4, 1>, 256);
         else go(k_wn_layer_b3<false, 4, false, 3, 2, 1>, 256);
     } else if (nt == 1) {
         if (a.math == MATH_F16X2) go(k_wn_layer_b3<false, 1, true>, 256);

@@ -247,8 +247,8 @@ def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, m
     forced = np.full((B, Tx), 6, np.int32)
     res = {}
     monkeypatch.setenv("MI355VITS_WN_B3_NT", "3")
-    for tag, ring in (("ring4", None), ("ring2", "2"), ("ring4_again", None), ("epi0", "e0"), ("epi1", "e1"), ("epi2", "e2"), ("tw", "tw"), ("nt4", "nt4")):
-        monkeypatch.setenv("MI355VITS_WN_B3_NT", "4" if ring == "nt4" else "3")  # (nt4: the 128-column tiles large grids run since round 6)
+    for tag, ring in (("ring4", None), ("ring2", "2"), ("ring4_again", None), ("epi0", "e0"), ("epi1", "e1"), ("epi2", "e2"), ("tw", "tw"), ("nt4", "nt4"), ("nt4r2", "nt4r2")):
+        monkeypatch.setenv("MI355VITS_WN_B3_NT", "4" if (ring or "").startswith("nt4") else "3")  # (nt4: the 128-column tiles large grids run since round 6)
         monkeypatch.delenv("MI355VITS_WN_RING", raising=False)
         monkeypatch.delenv("MI355VITS_WN_EPI", raising=False)
         monkeypatch.delenv("MI355VITS_WN_TW", raising=False)
@@ -256,13 +256,15 @@ def test_wavenet_layer_weight_ring_depths_agree_bitwise_on_the_device(lab_lib, m
             monkeypatch.setenv("MI355VITS_WN_TW", "1")
         elif ring is not None and ring.startswith("e"):  # the epilogue forms (old values one / three tiles ahead / + issued before the gate)
             monkeypatch.setenv("MI355VITS_WN_EPI", ring[1:])
+        elif ring == "nt4r2":  # 128-column tiles with the fragments one group ahead (B double-buffered) instead of three (B single-buffered)
+            monkeypatch.setenv("MI355VITS_WN_RING", "2")
         elif ring is not None and ring != "nt4":
             monkeypatch.setenv("MI355VITS_WN_RING", ring)
         eng = Engine(blob, library=lab_lib, device=0)
         out = eng.run(ids, lengths, [0.667, 1.0, 0.8], forced_durations=forced, seed=3, debug_taps=True)
         res[tag] = eng.tap("z"), out["audio"].copy(), out["lengths"].copy()
         eng.close()
-    for tag in ("ring2", "ring4_again", "epi0", "epi1", "epi2", "tw", "nt4"):
+    for tag in ("ring2", "ring4_again", "epi0", "epi1", "epi2", "tw", "nt4", "nt4r2"):
         for k in range(3):
             assert np.array_equal(res[tag][k], res["ring4"][k]), (tag, k)
 
