@@ -1,6 +1,6 @@
 """Randomised soak of the product library on one MI355X: ragged batches of random shapes, every batch checked row by row.
 
-    python tools/gpu_soak.py [--seconds 240] [--seed 1]
+    python tools/gpu_soak.py [--seconds 240] [--seed 1] [--large-every 4]
 
 Per iteration: a random voice (apope_low / vctk_low), batch size, phoneme counts, per-phoneme forced durations (so the rows' frame counts
 are ragged too) and noise scales; the batch runs once, then
@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--large-every", type=int, default=0, help="every N-th batch is a large one (64 - 256 rows x 64 - 128 phonemes x up to 8 frames per phoneme)")
     a = ap.parse_args()
     from mimic3_amd import weights as W
     from mimic3_amd._native import Engine
@@ -39,19 +40,26 @@ def main():
         w = W.synthetic_weights(cfg, seed=21, frames_per_id=3.0)
         voices[name] = (cfg, w, Engine(W.pack(cfg, w), device=0))
     t_end = time.time() + a.seconds
-    it = fails = rows = orc = 0
+    it = fails = rows = orc = nlarge = 0
     frames = 0
     while time.time() < t_end:
         name = ("apope_low", "vctk_low")[it % 2]
         cfg, w, eng = voices[name]
-        B = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 32, 48]))
-        Tx = int(rng.choice([1, 7, 33, 64, 65, 128, 129, 200]))
+        large = a.large_every > 0 and it % a.large_every == a.large_every - 1
+        if large:  # grids on which the launchers pick their large-grid forms (128-column WaveNet tiles, the row-sweep MRF stage, the 128-column
+            # encoder convs, the high-occupancy attention): the solo runs below take the small-grid forms of the same kernels — same bits
+            B = int(rng.choice([64, 96, 128, 200, 256]))
+            Tx = int(rng.choice([64, 100, 128]))
+            nlarge += 1
+        else:
+            B = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 32, 48]))
+            Tx = int(rng.choice([1, 7, 33, 64, 65, 128, 129, 200]))
         lengths = rng.integers(1, Tx + 1, size=B)
         lengths[rng.integers(0, B)] = Tx
         ids = np.zeros((B, Tx), np.int64)
         for b in range(B):
             ids[b, : lengths[b]] = rng.integers(1, cfg.num_symbols, size=lengths[b])
-        fmax = int(rng.choice([1, 2, 4, 8]))
+        fmax = int(rng.choice([4, 6, 8])) if large else int(rng.choice([1, 2, 4, 8]))
         forced = rng.integers(1, fmax + 1, size=(B, Tx)).astype(np.int32)
         sid = rng.integers(0, cfg.n_speakers, size=B).astype(np.int64) if cfg.n_speakers > 1 else None
         scales = [float(rng.choice([0.0, 0.667])), 1.0, 0.8]
@@ -85,7 +93,7 @@ def main():
         it += 1
     for _, _, e in voices.values():
         e.close()
-    print(f"soak: {it} batches, {rows} rows checked batched == alone (bitwise), {orc} rows vs the oracle, {frames} frames synthesised, {fails} failures", flush=True)
+    print(f"soak: {it} batches ({nlarge} large), {rows} rows checked batched == alone (bitwise), {orc} rows vs the oracle, {frames} frames synthesised, {fails} failures", flush=True)
     sys.exit(1 if fails else 0)
 
 
